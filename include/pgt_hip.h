@@ -1,0 +1,163 @@
+/* libpgt_hip.so — C-ABI of the MI355X-native PGTFormer forward path.
+ *
+ * Every entry point replaces a group of PyTorch/ATen calls on the reference's inference path
+ * (kepengxu/PGTFormer); the reference has no native code, so the "FFI it would bind" is the set of
+ * nn.Module forward()s cited per function below (file:line relative to the reference repo).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless noted; the caller owns
+ *    every buffer (inputs, outputs, workspaces); the library never allocates or frees on the path.
+ *  - activations are channels-last: an image batch is (N, H, W, C) with pixel stride `ld*` elements
+ *    (>= C, so channel slices of a wider buffer can be read/written in place); token matrices are
+ *    (rows, C) with row stride `ld*`.
+ *  - `dtype` selects the activation/weight storage type of the call: PGT_F32 (exact-f32 MFMA, parity
+ *    mode) or PGT_BF16 (bf16 MFMA, fp32 accumulate).  Biases, norm gains/shifts, statistics and
+ *    relative-position biases are always fp32.
+ *  - every function enqueues on `stream` (a hipStream_t) and returns immediately: no internal
+ *    synchronisation, HIP-graph capturable.  Return 0 on success, negative errno-style code on
+ *    error; the message is available from pgt_last_error() (thread-local).
+ */
+#ifndef PGT_HIP_H
+#define PGT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pgt_stream_t; /* hipStream_t */
+
+enum { PGT_F32 = 0, PGT_BF16 = 1 };
+enum { PGT_ACT_NONE = 0, PGT_ACT_RELU = 1, PGT_ACT_GELU = 2, PGT_ACT_SILU = 3, PGT_ACT_LEAKY02 = 4, PGT_ACT_SIGMOID = 5 };
+enum { PGT_EPI_PLAIN = 0, PGT_EPI_SFT = 1 };
+
+const char* pgt_version(void);
+const char* pgt_last_error(void); /* host pointer, thread-local, valid until the next failing call */
+
+/* ---- convolution / linear (implicit GEMM on MFMA) -------------------------------------------
+ * Replaces nn.Conv2d(k=1|3|7, stride 1|2) and nn.Linear on the path: TDResnetBlock convs
+ * (modules/rstt_layers.py:875-904), Downsample/Upsample (archs/tdcrqvae3_arch.py:45-76, with the
+ * (0,1,0,1) pad and the nearest x2 resize folded in), q/kv/proj/fc1/fc2 (rstt_layers.py:126-234),
+ * MHA in/out projections and FFN (archs/codeformer_arch.py:121-137), every conv of BiSeNet with its
+ * eval-BatchNorm folded (archs/pgtformer_arch.py:40-379) and of Fuse_sft_block (:460-484).
+ * w: (Cout, KH*KW*Cin) row-major, k index = (ky*KW + kx)*Cin + ci, dtype = d->dtype.
+ * y[m, co] = epi(act(conv + bias[co])), m = (n*Ho + oy)*Wo + ox:
+ *   PGT_EPI_PLAIN:  v = act(.) [+ residual[m*ldr + co]]; if post_relu v = max(v, 0)
+ *   PGT_EPI_SFT:    v = dec + sft_w * (dec * act(.) + shift)          (pgtformer_arch.py:478-479)
+ */
+typedef struct pgt_conv_desc {
+    int32_t dtype;
+    int32_t N, H, W, Cin; /* stored input geometry                                         */
+    int32_t ldx;          /* input pixel stride (elements)                                 */
+    int32_t ups;          /* 1: convolve the nearest-x2 up-sampled image (2H x 2W)         */
+    int32_t KH, KW, stride, pad_t, pad_l;
+    int32_t Ho, Wo, Cout;
+    int32_t ldy;
+    int32_t act, post_relu;
+    int32_t ldr;
+    int32_t epi, ld_dec, ld_shift;
+    float sft_w;
+    int32_t out_f32;            /* 1: store y as fp32 even when dtype is bf16 (logits, distances) */
+    int32_t force_bm, force_bn; /* 0 = heuristic; 64|128 pins the workgroup tile (tests, tuning)  */
+} pgt_conv_desc;
+
+int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
+               const void* residual, const void* sft_dec, const void* sft_shift, void* y,
+               pgt_stream_t stream);
+
+/* ---- normalisation ---------------------------------------------------------------------------
+ * GroupNorm(groups, eps) statistics -> per-(n,c) affine so that GN(x) = x*scale + shift
+ * (Normalize(), rstt_layers.py:754-755; normalize(), pgtformer_arch.py:406-407).  Deterministic
+ * two-stage reduction; `workspace` needs pgt_groupnorm_workspace_bytes() bytes. */
+size_t pgt_groupnorm_workspace_bytes(int32_t N, int32_t HW, int32_t C, int32_t groups);
+int pgt_groupnorm_affine(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
+                         int32_t groups, float eps, const float* gamma, const float* beta,
+                         float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                         pgt_stream_t stream);
+/* y = act(x * scale[n,c] + shift[n,c])  (GN apply + SiLU/swish, AdaIN apply, eval-BN apply) */
+int pgt_affine_act(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N,
+                   int32_t HW, int32_t C, const float* scale, const float* shift, int32_t act,
+                   pgt_stream_t stream);
+/* LayerNorm over the last dim (nn.LayerNorm eps 1e-5; rstt_layers.py:298,335; codeformer_arch.py:128,134;
+ * pgtformer_arch.py:532).  y = LN(x); if y2 != NULL also y2 = LN(x) + pos (q = k = LN(x) + query_pos). */
+int pgt_layernorm(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t C,
+                  const float* gamma, const float* beta, float eps, void* y, int32_t ldy,
+                  const void* pos, int32_t ldpos, void* y2, int32_t ldy2, pgt_stream_t stream);
+/* per-(n,c) mean and UNBIASED variance over HW pixels (calc_mean_std, codeformer_arch.py:15-29) */
+int pgt_channel_stats(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
+                      float* mean, float* var_unbiased, pgt_stream_t stream);
+/* AdaIN coefficients: scale = sqrt(var_s+eps)/sqrt(var_c+eps), shift = mean_s - mean_c*scale
+ * (adaptive_instance_normalization, codeformer_arch.py:32-46); n = N*C entries */
+int pgt_adain_affine(const float* mean_c, const float* var_c, const float* mean_s, const float* var_s,
+                     float eps, float* scale, float* shift, int32_t n, pgt_stream_t stream);
+
+/* ---- attention -------------------------------------------------------------------------------
+ * (T,Wh,Ww)-window multi-head self-attention with cyclic shift, relative-position bias and the
+ * 9-region shift mask (WindowAttention3D.forward rstt_layers.py:195-234 + window_partition/reverse
+ * :55-88 + torch.roll :307-327 + mask :552-568).  qkv: (B*T*H*W, 3C) rows in (b,t,y,x) order, columns
+ * [q | k | v], head h at columns h*hd; q is NOT pre-scaled.  bias: dense (heads, N, N) fp32 with
+ * N = T*wh*ww (gathered once at weight-pack time from relative_position_bias_table/_index).
+ * out: (B*T*H*W, C) written at the un-shifted token positions. */
+int pgt_window_attention(int32_t dtype, const void* qkv, int32_t ldqkv, void* out, int32_t ldo,
+                         const float* bias, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C,
+                         int32_t heads, int32_t wh, int32_t ww, int32_t sh, int32_t sw,
+                         pgt_stream_t stream);
+/* global multi-head attention, flash style (nn.MultiheadAttention inside TransformerSALayer,
+ * codeformer_arch.py:105,129): per batch b, softmax(q k^T * scale) v over L tokens.
+ * q,k,v: (B*L, heads*hd) row-major with row strides ldq/ldk/ldv. */
+int pgt_mha(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v,
+            int32_t ldv, void* out, int32_t ldo, int32_t B, int32_t L, int32_t heads, int32_t hd,
+            float scale, pgt_stream_t stream);
+
+/* ---- quantiser -------------------------------------------------------------------------------
+ * codes[r] = first argmax_j logits[r, j]  (logits.argmax(-1), pgtformer_arch.py:663) */
+int pgt_argmax_rows(const float* logits, int32_t ld, int32_t rows, int32_t K, int32_t* codes,
+                    pgt_stream_t stream);
+/* nearest code: codes[r] = first argmin_j (xnorm[r] + enorm[j]) - 2*dot[r,j]
+ * (VQEmbedding.compute_distances/find_nearest_embedding, tdcrqvae3_arch.py:100-126; also
+ * VectorQuantizer.forward distance+argmin, archs/vqgan_arch.py:48-54) */
+int pgt_rq_argmin(const float* dot, int32_t ld, const float* xnorm, const float* enorm, int32_t rows,
+                  int32_t K, int32_t* codes, pgt_stream_t stream);
+/* out[r,:] (+)= codebook[codes[r],:] ; optionally resid[r,:] -= codebook[codes[r],:]
+ * (VQEmbedding.embed :201-203, RQBottleneck.embed_code :355-368, quantize loop :318-325).
+ * codebook fp32 (K+1, D); out/resid dtype = `dtype`. accumulate: 0 = overwrite, 1 = add */
+int pgt_embed_rows(int32_t dtype, const float* codebook, int32_t D, const int32_t* codes, int32_t rows,
+                   void* out, int32_t ldo, int32_t accumulate, void* resid, int32_t ldres,
+                   pgt_stream_t stream);
+/* out[r] = sum_c x[r,c]^2 (fp32) */
+int pgt_row_sumsq(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t C, float* out,
+                  pgt_stream_t stream);
+
+/* ---- BiSeNet glue / element-wise --------------------------------------------------------------
+ * 3x3 stride-2 pad-1 max-pool, NHWC (nn.MaxPool2d(3,2,1), pgtformer_arch.py:84) */
+int pgt_maxpool3x3s2(int32_t dtype, const void* x, int32_t N, int32_t H, int32_t W, int32_t C, void* y,
+                     pgt_stream_t stream);
+/* y[n,p,c] = x[n,p,c] * gate[n,c] + addvec[n,c] + addt[n,p,c]   (gate/addvec/addt optional; ARM and
+ * FFM gating and the nearest-broadcast adds, pgtformer_arch.py:200-207, 235-247, 324-334) */
+int pgt_gate_add(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
+                 const void* gate, const void* addvec, const void* addt, int32_t ldt, void* y,
+                 int32_t ldy, pgt_stream_t stream);
+/* bilinear resize with align_corners=True (F.interpolate, pgtformer_arch.py:375-376) */
+int pgt_resize_bilinear_ac(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t Hi, int32_t Wi,
+                           int32_t C, void* y, int32_t ldy, int32_t Ho, int32_t Wo, pgt_stream_t stream);
+/* strided 2-D copy with dtype conversion (channel concat, casts) */
+int pgt_copy2d(int32_t src_dtype, const void* src, int32_t lds, int32_t dst_dtype, void* dst, int32_t ldd,
+               int64_t rows, int32_t cols, pgt_stream_t stream);
+
+/* ---- driver edges (inference.py:6-19) ----------------------------------------------------------
+ * input window -> channels-last 8-channel (RGB + 5 zero) tensors: raw = v/255 (encoder input) and
+ * norm = (v/255 - mean)/std (BiSeNet input, transforms.Normalize pgtformer_arch.py:554-556,606).
+ * src_kind 0: uint8 (N,H,W,3) HWC frames; 1: fp32 (N,3,H,W) in [0,1] */
+int pgt_prep_input(int32_t dtype, const void* src, int32_t src_kind, int32_t N, int32_t H, int32_t W,
+                   void* raw, void* norm, pgt_stream_t stream);
+/* (N,H,W,C) activations -> fp32 (N,C,H,W) */
+int pgt_nhwc_to_nchw_f32(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t H, int32_t W,
+                         int32_t C, float* y, pgt_stream_t stream);
+/* one frame (H,W,C=3) -> uint8 HWC: floor(clamp(x,0,1)*255)  (truncation, inference.py:16-18) */
+int pgt_frame_to_u8(int32_t dtype, const void* x, int32_t ldx, int32_t H, int32_t W, uint8_t* y,
+                    pgt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGT_HIP_H */

@@ -1,0 +1,375 @@
+"""PGTFormer top-level model, BiSeNet face-parsing condition net and the SFT fusion block, HIP-backed.
+
+Host-side mirror of the reference's archs/pgtformer_arch.py: same class names, constructor kwargs,
+state-dict keys (961 tensors) and `forward(x, w, detach_16, code_only, adain)` return tuple, so a
+reference checkpoint loads with `load_state_dict(strict=True)`; every arithmetic op is a gfx950 kernel
+launched through `pgtformer_amd.ops` (no ATen compute, no CPU fallback).
+
+Layout: a reference (B*T, C, H, W) tensor lives here as channels-last (B*T, H, W, C).  In that layout
+every token re-ordering of the reference forward (pgtformer_arch.py:614, :640, :646) is the identity:
+(t, y, x)-major rows of a (B*T*H*W, C) matrix.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..modules.rstt_layers import Conv2d, HipModule, LayerNorm, Linear, TDResnetBlock, _f32  # noqa: F401
+from ..ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU
+from ..registry import ARCH_REGISTRY
+from .codeformer_arch import TransformerSALayer, adaptive_instance_normalization
+from .tdcrqvae3_arch import TDCRQVAE3
+
+
+# ----------------------------------------------------------------------------------------------
+# BiSeNet (reference: pgtformer_arch.py:34-397).  Eval-mode BatchNorm is folded into the preceding
+# conv at pack time; ReLU / sigmoid / residual adds are conv epilogues.
+# ----------------------------------------------------------------------------------------------
+def _bn(c):
+    return nn.BatchNorm2d(c)
+
+
+class BasicBlock(HipModule):
+    def __init__(self, in_chan, out_chan, stride=1):
+        super().__init__()
+        self.conv1 = Conv2d(in_chan, out_chan, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = _bn(out_chan)
+        self.conv2 = Conv2d(out_chan, out_chan, 3, padding=1, bias=False)
+        self.bn2 = _bn(out_chan)
+        self.downsample = None
+        if in_chan != out_chan or stride != 1:
+            self.downsample = nn.Sequential(Conv2d(in_chan, out_chan, 1, stride=stride, bias=False), _bn(out_chan))
+            self.downsample[0]._bn_ref = (self.downsample[1],)
+        self.conv1._bn_ref = (self.bn1,)
+        self.conv2._bn_ref = (self.bn2,)
+
+    def forward(self, x):
+        r = self.conv1.run(x, act=ACT_RELU)
+        sc = x if self.downsample is None else self.downsample[0].run(x)
+        return self.conv2.run(r, res=sc, post_relu=True)   # relu(shortcut + bn2(conv2(.)))
+
+
+def create_layer_basic(in_chan, out_chan, bnum, stride=1):
+    layers = [BasicBlock(in_chan, out_chan, stride=stride)]
+    for _ in range(bnum - 1):
+        layers.append(BasicBlock(out_chan, out_chan, stride=1))
+    return nn.Sequential(*layers)
+
+
+class Resnet18(HipModule):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = Conv2d(3, 64, 7, stride=2, padding=3, bias=False, cin_pad=8)
+        self.bn1 = _bn(64)
+        self.conv1._bn_ref = (self.bn1,)
+        self.layer1 = create_layer_basic(64, 64, bnum=2, stride=1)
+        self.layer2 = create_layer_basic(64, 128, bnum=2, stride=2)
+        self.layer3 = create_layer_basic(128, 256, bnum=2, stride=2)
+        self.layer4 = create_layer_basic(256, 512, bnum=2, stride=2)
+
+    def forward(self, x):
+        x = ops.maxpool3x3s2(self.conv1.run(x, act=ACT_RELU))
+        for blk in self.layer1:
+            x = blk(x)
+        feat8 = x
+        for blk in self.layer2:
+            feat8 = blk(feat8)
+        feat16 = feat8
+        for blk in self.layer3:
+            feat16 = blk(feat16)
+        feat32 = feat16
+        for blk in self.layer4:
+            feat32 = blk(feat32)
+        return feat8, feat16, feat32
+
+
+class ConvBNReLU(HipModule):
+    def __init__(self, in_chan, out_chan, ks=3, stride=1, padding=1):
+        super().__init__()
+        self.conv = Conv2d(in_chan, out_chan, ks, stride=stride, padding=padding, bias=False)
+        self.bn = _bn(out_chan)
+        self.conv._bn_ref = (self.bn,)
+
+    def forward(self, x, **kw):
+        return self.conv.run(x, act=ACT_RELU, **kw)
+
+
+class BiSeNetOutput(HipModule):
+    def __init__(self, in_chan, mid_chan, n_classes):
+        super().__init__()
+        self.conv = ConvBNReLU(in_chan, mid_chan, ks=3, stride=1, padding=1)
+        self.conv_out = Conv2d(mid_chan, n_classes, 1, bias=False)
+
+    def forward(self, x, out=None):
+        return self.conv_out.run(self.conv(x), out=out)
+
+
+def _global_avg(x):
+    """(N,H,W,C) -> (N,1,1,C) in x.dtype (F.avg_pool2d over the full map)."""
+    mean, _ = ops.channel_stats(x, want_var=False)
+    return ops.cast(mean, x.dtype).reshape(x.shape[0], 1, 1, x.shape[3])
+
+
+class AttentionRefinementModule(HipModule):
+    def __init__(self, in_chan, out_chan):
+        super().__init__()
+        self.conv = ConvBNReLU(in_chan, out_chan, ks=3, stride=1, padding=1)
+        self.conv_atten = Conv2d(out_chan, out_chan, 1, bias=False)
+        self.bn_atten = _bn(out_chan)
+        self.conv_atten._bn_ref = (self.bn_atten,)
+
+    def forward(self, x):
+        """returns (feat, atten) — the product is fused with the following add by the caller."""
+        feat = self.conv(x)
+        atten = self.conv_atten.run(_global_avg(feat), act=ACT_SIGMOID)
+        return feat, atten.reshape(feat.shape[0], feat.shape[3])
+
+
+class ContextPath(HipModule):
+    def __init__(self):
+        super().__init__()
+        self.resnet = Resnet18()
+        self.arm16 = AttentionRefinementModule(256, 128)
+        self.arm32 = AttentionRefinementModule(512, 128)
+        self.conv_head32 = ConvBNReLU(128, 128, ks=3, stride=1, padding=1)
+        self.conv_head16 = ConvBNReLU(128, 128, ks=3, stride=1, padding=1)
+        self.conv_avg = ConvBNReLU(512, 128, ks=1, stride=1, padding=0)
+
+    def forward(self, x):
+        feat8, feat16, feat32 = self.resnet(x)
+        n = x.shape[0]
+        avg = self.conv_avg(_global_avg(feat32)).reshape(n, 128)     # broadcast add == nearest up of 1x1
+        f32, a32 = self.arm32(feat32)
+        feat32_sum = ops.gate_add(f32, gate=a32, addvec=avg)
+        feat32_up = self.conv_head32(feat32_sum, ups=True)              # nearest x2 fused in the conv gather
+        f16, a16 = self.arm16(feat16)
+        feat16_sum = ops.gate_add(f16, gate=a16, addt=feat32_up)
+        feat16_up = self.conv_head16(feat16_sum, ups=True)
+        return feat8, feat16_up, feat32_up
+
+
+class FeatureFusionModule(HipModule):
+    def __init__(self, in_chan, out_chan):
+        super().__init__()
+        self.convblk = ConvBNReLU(in_chan, out_chan, ks=1, stride=1, padding=0)
+        self.conv1 = Conv2d(out_chan, out_chan // 4, 1, bias=False)
+        self.conv2 = Conv2d(out_chan // 4, out_chan, 1, bias=False)
+
+    def forward(self, fsp, fcp):
+        n, h, w, c1 = fsp.shape
+        fcat = torch.empty((n, h, w, c1 + fcp.shape[3]), device=fsp.device, dtype=fsp.dtype)
+        ops.copy_into(fsp, fcat[..., :c1])
+        ops.copy_into(fcp, fcat[..., c1:])
+        feat = self.convblk(fcat)
+        atten = self.conv2.run(self.conv1.run(_global_avg(feat), act=ACT_RELU), act=ACT_SIGMOID)
+        return ops.gate_add(feat, gate=atten.reshape(n, feat.shape[3]), addt=feat)   # feat*atten + feat
+
+
+class BiSeNet(HipModule):
+    def __init__(self, n_classes):
+        super().__init__()
+        self.n_classes = n_classes
+        self.cp = ContextPath()
+        self.ffm = FeatureFusionModule(256, 256)
+        self.conv_out = BiSeNetOutput(256, 256, n_classes)
+        self.conv_out16 = BiSeNetOutput(128, 64, n_classes)
+        self.conv_out32 = BiSeNetOutput(128, 64, n_classes)
+
+    def forward(self, x):
+        """x: (N,512,512,8) ImageNet-normalised -> (N,32,32,64): 3*n_classes parsing logits + zero pad."""
+        nc = self.n_classes
+        feat_res8, feat_cp8, feat_cp16 = self.cp(x)
+        feat_fuse = self.ffm(feat_res8, feat_cp8)
+        n = x.shape[0]
+        cpad = (3 * nc + 7) // 8 * 8
+        outf = torch.zeros((n, 32, 32, cpad), device=x.device, dtype=x.dtype)
+        ops.resize_bilinear_ac(self.conv_out(feat_fuse), 32, 32, out=outf[..., 0:nc])
+        ops.resize_bilinear_ac(self.conv_out16(feat_cp8), 32, 32, out=outf[..., nc:2 * nc])
+        f32 = self.conv_out32(feat_cp16)
+        assert f32.shape[1] == 32 and f32.shape[2] == 32, "the reference concatenates this head un-resized"
+        ops.copy_into(f32, outf[..., 2 * nc:3 * nc])
+        return outf
+
+
+# ----------------------------------------------------------------------------------------------
+# SFT fusion (reference: pgtformer_arch.py:402-484)
+# ----------------------------------------------------------------------------------------------
+def normalize(in_channels):
+    from ..modules.rstt_layers import GroupNorm
+    return GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class ResBlock(HipModule):
+    def __init__(self, in_channels, out_channels=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = in_channels if out_channels is None else out_channels
+        self.norm1 = normalize(in_channels)
+        self.conv1 = Conv2d(in_channels, self.out_channels, 3, padding=1)
+        self.norm2 = normalize(self.out_channels)
+        self.conv2 = Conv2d(self.out_channels, self.out_channels, 3, padding=1)
+        if self.in_channels != self.out_channels:
+            self.conv_out = Conv2d(in_channels, self.out_channels, 1)
+
+    def forward(self, x_in):
+        h = self.conv1.run(self.norm1.run(x_in, ACT_SILU))
+        h = self.norm2.run(h, ACT_SILU)
+        sc = self.conv_out.run(x_in) if self.in_channels != self.out_channels else x_in
+        return self.conv2.run(h, res=sc)
+
+
+class Fuse_sft_block(HipModule):
+    """Controllable feature fusion with the temporal 1x1 mix over T-stacked channels."""
+
+    def __init__(self, in_ch, out_ch, t=3):
+        super().__init__()
+        self.tcc = 32
+        self.encode_enc = ResBlock(2 * in_ch + self.tcc, out_ch)
+        self.scale = nn.Sequential(Conv2d(in_ch, out_ch, 3, padding=1), nn.LeakyReLU(0.2, True),
+                                   Conv2d(out_ch, out_ch, 3, padding=1))
+        self.shift = nn.Sequential(Conv2d(in_ch, out_ch, 3, padding=1), nn.LeakyReLU(0.2, True),
+                                   Conv2d(out_ch, out_ch, 3, padding=1))
+        self.t = t
+        self.tconvenc = Conv2d(in_ch, self.tcc, 1)
+        self.tconvdec = Conv2d(in_ch, self.tcc, 1)
+        self.tfusion0 = Conv2d(2 * t * self.tcc, self.tcc * self.t, 1)
+        self.tfusion1 = Conv2d(self.tcc, self.tcc, 1)
+        self.in_ch, self.out_ch = in_ch, out_ch
+
+    def _pack(self, device, dtype):
+        # scale.0 and shift.0 read the same tensor: one conv with the two filter banks stacked on Cout
+        def packed(conv):
+            w = conv.weight.detach().float()
+            return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+        self.w_ss0 = torch.cat([packed(self.scale[0]), packed(self.shift[0])], 0).to(device=device, dtype=dtype).contiguous()
+        self.b_ss0 = _f32(torch.cat([self.scale[0].bias.detach(), self.shift[0].bias.detach()], 0), device)
+
+    def forward(self, enc_feat, dec_feat, temb=None, w=1):
+        """enc_feat, dec_feat: (B*T, h, w, C) (reference: :460-484)."""
+        n, h, wd, c = dec_feat.shape
+        t, tcc = self.t, self.tcc
+        b = n // t
+        dev, dt = dec_feat.device, dec_feat.dtype
+        # per-frame 1x1 -> T frames stacked on channels: [enc t0..t2 | dec t0..t2]
+        stacked = torch.empty((b, h, wd, 2 * t * tcc), device=dev, dtype=dt)
+        for bi in range(b):
+            for ti in range(t):
+                f = bi * t + ti
+                self.tconvenc.run(enc_feat[f:f + 1], out=stacked[bi:bi + 1, :, :, ti * tcc:(ti + 1) * tcc])
+                self.tconvdec.run(dec_feat[f:f + 1], out=stacked[bi:bi + 1, :, :, (t + ti) * tcc:(t + ti + 1) * tcc])
+        fut0 = self.tfusion0.run(stacked)                                   # (b,h,w,T*32)  temporal fusion
+        cat = torch.empty((n, h, wd, 2 * c + tcc), device=dev, dtype=dt)    # [enc | dec | fut]
+        ops.copy_into(enc_feat, cat[..., :c])
+        ops.copy_into(dec_feat, cat[..., c:2 * c])
+        for bi in range(b):
+            for ti in range(t):
+                f = bi * t + ti
+                self.tfusion1.run(fut0[bi:bi + 1, :, :, ti * tcc:(ti + 1) * tcc], out=cat[f:f + 1, :, :, 2 * c:])
+        e = self.encode_enc(cat)
+        ss = ops.conv2d(e, self.w_ss0, self.b_ss0, kh=3, kw=3, pad=(1, 1, 1, 1), act=ACT_LEAKY02)  # (n,h,w,2C)
+        co = self.out_ch
+        shift = self.shift[2].run(ss[..., co:])
+        # out = dec + w*(dec*scale + shift) as the epilogue of the last scale conv
+        return self.scale[2].run(ss[..., :co], sft=(dec_feat, shift, w))
+
+
+# ----------------------------------------------------------------------------------------------
+# PGTFormer (reference: pgtformer_arch.py:490-714)
+# ----------------------------------------------------------------------------------------------
+@ARCH_REGISTRY.register()
+class PGTFormer(TDCRQVAE3):
+    def __init__(self, ddconfig, dim_embd=512, n_head=8, n_layers=9, connect_list=("32", "64", "128", "256"),
+                 fix_modules=("quantizer", "decoder", "conditionnet"), w=0, detach_16=True, adain=False, tf=3,
+                 droprate=0.0, **kwargs):
+        super().__init__(ddconfig=ddconfig, tf=tf, **kwargs)
+        self.fix_modules = list(fix_modules) if fix_modules is not None else None
+        self.t, self.w, self.detach_16, self.adain = tf, w, detach_16, adain
+        self.connect_list = list(connect_list)
+        self.n_layers, self.dim_embd, self.dim_mlp, self.n_head = n_layers, dim_embd, dim_embd * 2, n_head
+        self.conditionnet = BiSeNet(19)
+        self.convpos = Conv2d(57, 512, 1, cin_pad=64)
+        self.feat_emb = Linear(512, dim_embd)
+        self.ft_layers = nn.Sequential(*[TransformerSALayer(embed_dim=dim_embd, nhead=n_head, dim_mlp=self.dim_mlp,
+                                                            dropout=droprate) for _ in range(n_layers)])
+        self.codebook_size = self.quantizer.n_embed[-1]
+        self.quantizer_depth = self.quantizer.code_shape[-1]
+        self.idx_pred_layer = nn.Sequential(LayerNorm(dim_embd),
+                                            Linear(dim_embd, self.quantizer_depth * self.codebook_size, bias=False))
+        self.channels = {"16": 512, "32": 512, "64": 256, "128": 256, "256": 128, "512": 64}
+        self.fuse_encoder_indices = {"512": 0, "256": 1, "128": 2, "64": 3, "32": 4, "16": 5}
+        self.fuse_convs_dict = nn.ModuleDict()
+        for f_size in self.connect_list:
+            in_ch = self.channels[f_size]
+            self.fuse_convs_dict[f_size] = Fuse_sft_block(in_ch, in_ch, t=tf)
+        self.requires_grad_(False)   # inference-only build
+        nn.Module.eval(self)
+
+    def eval(self):
+        # the reference's train() override returns None, so `m = m.eval()` breaks there
+        # (pgtformer_arch.py:577-581); here eval() returns self as nn.Module promises.
+        return nn.Module.eval(self)
+
+    @torch.no_grad()
+    def forward(self, x, w=None, detach_16=True, code_only=None, adain=None):
+        """x: (B*T,3,512,512) fp32 in [0,1] (or uint8 (B*T,512,512,3)).  Returns the reference's tuple
+        (out (B*T,3,512,512) fp32, logits (B*T,32,32,1,1024) fp32, lq_feat (B*T,32,32,512) fp32)."""
+        out_nhwc, logits, lq = self.forward_nhwc(x, w=w, code_only=code_only, adain=adain)
+        lq32 = ops.cast(lq, torch.float32)
+        if code_only:
+            return logits, lq32
+        return ops.nhwc_to_nchw_f32(out_nhwc), logits, lq32
+
+    @torch.no_grad()
+    def forward_nhwc(self, x, w=None, code_only=None, adain=None):
+        """Same computation, channels-last results and no layout conversion: out (B*T,512,512,3) in the
+        decoder dtype, logits fp32, lq_feat (B*T,32,32,512) in the encoder dtype."""
+        self._check_ready()
+        w = self.w if w is None else w
+        adain = self.adain if adain is None else adain
+        t = self.t
+        raw, nx = self._ingest(x)
+        bt = raw.shape[0]
+        b = bt // t
+        # condition branch: BiSeNet parsing map -> positional embedding of the code transformer
+        cond = self.convpos.run(self.conditionnet(nx))                      # (bt,32,32,512)
+        th, tw = cond.shape[1], cond.shape[2]
+        pos = cond.reshape(bt * th * tw, cond.shape[3])                      # rows (b,t,y,x) == (T*H*W, B) order
+        # encoder
+        z, feats = self.encoder(raw, return_multi_res_feats=True)
+        enc_feat = {}
+        for f_size in self.connect_list:
+            f = feats[self.fuse_encoder_indices[f_size]]
+            enc_feat[str(f.shape[2])] = f
+        lq_feat = self.quant_conv.run(z)                                     # (bt,32,32,512)
+        # code-prediction transformer over the T*32*32 tokens of each window
+        L = t * th * tw
+        q = self.feat_emb.run(lq_feat.reshape(bt * th * tw, lq_feat.shape[3]))
+        for layer in self.ft_layers:
+            q = layer(q, b, L, query_pos=pos)
+        ln = self.idx_pred_layer[0].run(q)
+        logits2d = ops.linear(ln, self.idx_pred_layer[1].pw, None, out_f32=True)   # (bt*32*32, depth*K) fp32
+        logits = logits2d.reshape(bt, *self.quantizer.code_shape, self.codebook_size)
+        if code_only:
+            return None, logits, lq_feat
+        # quantisation: first-max code per token, codebook gather, AdaIN against the LQ features
+        depth = self.quantizer_depth
+        codes = ops.argmax_rows(logits2d.reshape(bt * th * tw * depth, self.codebook_size))
+        self.last_codes = codes.reshape(bt, th, tw, depth)
+        quant = self.quantizer.embed_code(self.last_codes, self.dec_dt)      # (bt,32,32,512)
+        if adain:
+            quant = adaptive_instance_normalization(quant, lq_feat)
+        z_q = self.post_quant_conv.run(quant)
+
+        def fuse(f_size, h):
+            if f_size in self.connect_list and w > 0:
+                return self.fuse_convs_dict[f_size](ops.cast(enc_feat[f_size], self.dec_dt), h, temb=None, w=w)
+            return h
+
+        out = self.decoder(z_q, fuse=fuse)                                   # (bt,512,512,3)
+        return out, logits, lq_feat
+
+    @torch.no_grad()
+    def restore_middle_u8(self, window_u8, w=1.0):
+        """Driver fast path (reference: inference.py:12-19): uint8 (3,H,W,3) window -> restored middle
+        frame as uint8 (H,W,3) with floor(clamp(x,0,1)*255), without leaving the device."""
+        out, _, _ = self.forward_nhwc(window_u8, w=w)
+        return ops.frame_to_u8(out[self.t // 2])

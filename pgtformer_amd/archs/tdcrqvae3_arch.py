@@ -1,0 +1,301 @@
+"""Stage-I temporal RQ-VAE (`TDCRQVAE3`), HIP-backed.
+
+Mirror of the reference archs/tdcrqvae3_arch.py surface that the inference path touches: same class
+names, constructor kwargs and state-dict keys (Encoder :460, Decoder :577, VQEmbedding :80,
+RQBottleneck :206, TDCRQVAE3 :711).  Activations are channels-last (B*T, H, W, C); `forward` takes the
+reference's (B*T, 3, H, W) fp32 tensor (or uint8 (B*T,H,W,3) frames) and returns the reference's
+tuple.  EMA-codebook training updates and their collectives (:138-186) are out of scope.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, prepare_tree)
+from ..ops import ACT_SILU
+from ..registry import ARCH_REGISTRY
+
+
+class Upsample(HipModule):
+    """nearest x2 + conv3x3, fused into one implicit-GEMM launch (reference: :34-52)."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.conv = Conv2d(in_channels, in_channels, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv.run(x, ups=True)
+
+
+class Downsample(HipModule):
+    """pad (0,1,0,1) + conv3x3 stride 2 (reference: :55-76); the pad is the gather's bounds check."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.conv = Conv2d(in_channels, in_channels, 3, stride=2, padding=0, pad4=(0, 1, 0, 1))
+
+    def forward(self, x):
+        return self.conv.run(x)
+
+
+class VQEmbedding(nn.Embedding, HipModule):
+    """Codebook with EMA buffers (kept for checkpoint compatibility; reference: :80-97)."""
+
+    def __init__(self, n_embed, embed_dim, ema=True, decay=0.99, restart_unused_codes=True, eps=1e-5):
+        nn.Embedding.__init__(self, n_embed + 1, embed_dim, padding_idx=n_embed)
+        self.n_embed = n_embed
+        self.register_buffer("cluster_size_ema", torch.zeros(n_embed))
+        self.register_buffer("embed_ema", self.weight[:-1, :].detach().clone())
+
+    def _pack(self, device, dtype):
+        w = self.weight.detach().float()
+        self.book = w.to(device).contiguous()                      # fp32 (K+1, D) for the gather
+        self.book_t = w[:-1].to(device=device, dtype=dtype).contiguous()   # (K, D) distance GEMM operand
+        self.enorm = w[:-1].pow(2.0).sum(1).to(device).contiguous()  # |e_j|^2 (reference :111)
+
+    def find_nearest_embedding(self, x2d):
+        """x2d (rows, D) -> int32 codes: argmin_j |x|^2 + |e_j|^2 - 2 x.e_j (reference: :100-126)."""
+        dot = ops.linear(x2d, self.book_t, None, out_f32=True)
+        return ops.rq_argmin(dot, ops.row_sumsq(x2d), self.enorm)
+
+
+class RQBottleneck(HipModule):
+    """Residual quantiser (reference: :206-368), inference methods only."""
+
+    def __init__(self, latent_shape, code_shape, n_embed, decay=0.99, shared_codebook=False,
+                 restart_unused_codes=True, commitment_loss="cumsum"):
+        super().__init__()
+        assert len(code_shape) == len(latent_shape) == 3
+        assert all(l % c == 0 for c, l in zip(code_shape[:2], latent_shape[:2]))
+        self.latent_shape, self.code_shape = torch.Size(latent_shape), torch.Size(code_shape)
+        self.shape_divisor = torch.Size([latent_shape[i] // code_shape[i] for i in range(3)])
+        assert self.shape_divisor[0] == 1 and self.shape_divisor[1] == 1, "spatial folding unused by PGTFormer"
+        depth = code_shape[-1]
+        embed_dim = latent_shape[2]
+        self.shared_codebook = shared_codebook
+        self.n_embed = list(n_embed) if isinstance(n_embed, (list, tuple)) else [n_embed] * depth
+        if shared_codebook:
+            book = VQEmbedding(self.n_embed[0], embed_dim)
+            self.codebooks = nn.ModuleList([book for _ in range(depth)])
+        else:
+            self.codebooks = nn.ModuleList([VQEmbedding(self.n_embed[i], embed_dim) for i in range(depth)])
+
+    def quantize(self, x):
+        """x (B,h,w,D) -> (aggregated quant (B,h,w,D), codes int32 (B,h,w,d)) (reference: :294-328)."""
+        b, h, w, d = x.shape
+        depth = self.code_shape[-1]
+        rows = b * h * w
+        x2 = x.reshape(rows, d)
+        resid = x2 if depth == 1 else x2.clone()
+        agg = torch.empty((rows, d), device=x.device, dtype=x.dtype)
+        codes = []
+        for i in range(depth):
+            book = self.codebooks[i]
+            c = book.find_nearest_embedding(resid)
+            ops.embed_rows(book.book, c, x.dtype, out=agg, accumulate=i > 0, resid=resid if depth > 1 else None)
+            codes.append(c)
+        return agg.reshape(b, h, w, d), torch.stack(codes, -1).reshape(b, h, w, depth)
+
+    def embed_code(self, code, dtype=torch.float32):
+        """codes (B,h,w,d) int -> summed embeddings (B,h,w,D) (reference: :355-368)."""
+        assert tuple(code.shape[1:]) == tuple(self.code_shape)
+        b, h, w, depth = code.shape
+        code = code.to(torch.int32)
+        out = None
+        for i in range(depth):
+            ci = code[..., i].contiguous().reshape(-1)
+            out = ops.embed_rows(self.codebooks[i].book, ci, dtype, out=out, accumulate=i > 0)
+        return out.reshape(b, h, w, -1)
+
+
+class Encoder(HipModule):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), depths, num_res_blocks, num_heads, num_frames,
+                 window_sizes, attn_resolutions, dropout=0.0, resamp_with_conv=True, in_channels, resolution,
+                 z_channels, double_z=True, **ignore_kwargs):
+        super().__init__()
+        self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = Conv2d(in_channels, ch, 3, padding=1, cin_pad=8)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(TDResnetBlock(in_channels=block_in, out_channels=block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(EncoderLayer(block_in, depths[i_level], num_heads=num_heads[i_level],
+                                             num_frames=num_frames, window_size=window_sizes[i_level], mlp_ratio=1))
+            down = nn.Module()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res //= 2
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = TDResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.mid.attn_1 = EncoderLayer(block_in, depths[-1], num_heads=num_heads[-1], num_frames=num_frames,
+                                       window_size=window_sizes[-1], mlp_ratio=1)
+        self.mid.block_2 = TDResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
+
+    def forward(self, x, return_multi_res_feats=False):
+        """x: (B*T, H, W, 8) channel-padded input (reference: :540-573)."""
+        feats = []
+        h = self.conv_in.run(x)
+        for i_level in range(self.num_resolutions):
+            lvl = self.down[i_level]
+            for i_block in range(self.num_res_blocks):
+                h = lvl.block[i_block](h)
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block](h)
+            feats.append(h)
+            if i_level != self.num_resolutions - 1:
+                h = lvl.downsample(h)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        h = self.conv_out.run(self.norm_out.run(h, ACT_SILU))
+        return (h, feats) if return_multi_res_feats else h
+
+
+class Decoder(HipModule):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), depths, num_res_blocks, num_heads, num_frames,
+                 window_sizes, attn_resolutions, dropout=0.0, resamp_with_conv=True, in_channels, resolution,
+                 z_channels, give_pre_end=False, **ignorekwargs):
+        super().__init__()
+        self.ch, self.num_frames = ch, num_frames
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.resolution, self.give_pre_end = resolution, give_pre_end
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = Conv2d(z_channels, block_in, 3, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = TDResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.mid.attn_1 = EncoderLayer(block_in, depths[-1], num_heads=num_heads[-1], num_frames=num_frames,
+                                       window_size=window_sizes[-1], mlp_ratio=1)
+        self.mid.block_2 = TDResnetBlock(in_channels=block_in, out_channels=block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(TDResnetBlock(in_channels=block_in, out_channels=block_out))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(EncoderLayer(block_in, depths[i_level], num_heads=num_heads[i_level],
+                                             num_frames=num_frames, window_size=window_sizes[i_level], mlp_ratio=1))
+            up = nn.Module()
+            up.block, up.attn = block, attn
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+                curr_res *= 2
+            self.up.insert(0, up)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = Conv2d(block_in, out_ch, 3, padding=1)
+
+    def forward(self, z, fuse=None):
+        """z: (B*T, h, w, z_channels) (reference: :672-707; with `fuse`, the loop inlined in
+        PGTFormer.forward, archs/pgtformer_arch.py:684-710). fuse(f_size:str, h) -> h."""
+        self.last_z_shape = z.shape
+        h = self.conv_in.run(z)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
+            for i_block in range(self.num_res_blocks + 1):
+                h = lvl.block[i_block](h)
+                if len(lvl.attn) > 0:
+                    h = lvl.attn[i_block](h)
+            if fuse is not None:
+                h = fuse(str(h.shape[2]), h)
+            if i_level != 0:
+                h = lvl.upsample(h)
+        if self.give_pre_end:
+            return h
+        return self.conv_out.run(self.norm_out.run(h, ACT_SILU))
+
+
+@ARCH_REGISTRY.register()
+class TDCRQVAE3(HipModule):
+    """Stage-I temporal RQ-VAE (reference: :711-872). `prepare(device, precision)` must be called after
+    weights are loaded; precision in {"fp32", "bf16", "mixed"} ("mixed": encoder side fp32, decoder bf16)."""
+
+    def __init__(self, *, embed_dim=64, n_embed=512, decay=0.99, loss_type="mse", latent_loss_weight=0.25,
+                 bottleneck_type="rq", ddconfig=None, checkpointing=False, tf=3, **kwargs):
+        super().__init__()
+        assert loss_type in ("mse", "l1")
+        assert bottleneck_type == "rq", "invalid 'bottleneck_type' (must be 'rq')"
+        self.encoder = Encoder(**ddconfig)
+        self.decoder = Decoder(**ddconfig)
+        self.t = tf
+        self.quantizer = RQBottleneck(latent_shape=kwargs["latent_shape"], code_shape=kwargs["code_shape"],
+                                      n_embed=n_embed, decay=decay, shared_codebook=kwargs["shared_codebook"],
+                                      restart_unused_codes=kwargs["restart_unused_codes"])
+        self.code_shape = kwargs["code_shape"]
+        self.quant_conv = Conv2d(ddconfig["z_channels"], embed_dim, 1)
+        self.post_quant_conv = Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        self.loss_type, self.latent_loss_weight = loss_type, latent_loss_weight
+        self.enc_dt = self.dec_dt = None
+
+    # -- precision / weight repack ------------------------------------------------------------
+    ENC_SIDE = ("encoder", "quant_conv", "quantizer", "conditionnet", "convpos", "feat_emb", "ft_layers", "idx_pred_layer")
+
+    def prepare(self, device="cuda", precision="bf16"):
+        dts = {"fp32": (torch.float32, torch.float32), "bf16": (torch.bfloat16, torch.bfloat16),
+               "mixed": (torch.float32, torch.bfloat16)}
+        if precision not in dts:
+            raise ValueError(f"precision must be one of {list(dts)}")
+        self.enc_dt, self.dec_dt = dts[precision]
+        self.precision = precision
+        self.dev = torch.device(device)
+        for name, child in self.named_children():
+            prepare_tree(child, self.dev, self.enc_dt if name in self.ENC_SIDE else self.dec_dt)
+        self._prepare_extra()
+        return self
+
+    def _prepare_extra(self):
+        pass
+
+    def _check_ready(self):
+        if self.enc_dt is None:
+            raise RuntimeError("call model.prepare(device, precision) after loading weights")
+
+    # -- stage-I API (reference: :760-813) ----------------------------------------------------
+    def _ingest(self, x):
+        """(B*T,3,H,W) fp32 in [0,1] or uint8 (B*T,H,W,3) -> raw / ImageNet-normalised (B*T,H,W,8)."""
+        self._check_ready()
+        x = x.to(self.dev)
+        return ops.prep_input(x.contiguous(), self.enc_dt)
+
+    def encode(self, x):
+        raw, _ = self._ingest(x)
+        return self.quant_conv.run(self.encoder(raw))  # (B*T,h,w,embed_dim) == reference's NHWC z_e
+
+    def decode(self, z_q):
+        z = self.post_quant_conv.run(ops.cast(z_q, self.dec_dt))
+        return ops.nhwc_to_nchw_f32(self.decoder(z))
+
+    @torch.no_grad()
+    def forward(self, input, code_only=False):
+        z_e = self.encode(input)
+        z_q, codes = self.quantizer.quantize(z_e)
+        quant_loss = None  # commitment loss is a training quantity (reference :340-352)
+        if code_only:
+            return z_q, quant_loss, codes.long()
+        return self.decode(z_q), quant_loss, codes.long()
+
+    @torch.no_grad()
+    def get_codes(self, input):
+        return self.quantizer.quantize(self.encode(input))[1].long()
+
+    @torch.no_grad()
+    def decode_code(self, code):
+        return self.decode(self.quantizer.embed_code(code.to(self.dev), self.dec_dt))
+
+    def get_last_layer(self):
+        return self.decoder.conv_out.weight

@@ -1,0 +1,103 @@
+// Shared device helpers for the PGTFormer gfx950 kernels.  CDNA4 only: 64-wide wavefronts, MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct bf16_t {
+    uint16_t v;
+};
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemIO<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(p->v); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f2bf(v); }
+};
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return ElemIO<T>::ld(p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { ElemIO<T>::st(p, v); }
+
+// 16-byte vector of T unpacked to floats (8 bf16 or 4 f32) and back
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(const uint4& q, float* f) {
+        f[0] = __uint_as_float(q.x); f[1] = __uint_as_float(q.y);
+        f[2] = __uint_as_float(q.z); f[3] = __uint_as_float(q.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const uint4& q, float* f) {
+        f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
+        f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
+        f[4] = __uint_as_float(q.z << 16); f[5] = __uint_as_float(q.z & 0xffff0000u);
+        f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        return make_uint4((uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16),
+                          (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
+                          (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16),
+                          (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+    }
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_LEAKY02 = 4, ACT_SIGMOID = 5 };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact erf GELU
+        case ACT_SILU: return v / (1.f + expf(-v));
+        case ACT_LEAKY02: return v > 0.f ? v : 0.2f * v;
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// error reporting shared by the C-ABI translation units
+void pgt_set_error(const char* fmt, ...);
+#define PGT_CHECK(cond, ...)            \
+    do {                                \
+        if (!(cond)) {                  \
+            pgt_set_error(__VA_ARGS__); \
+            return -22;                 \
+        }                               \
+    } while (0)
+#define PGT_LAUNCH_CHECK()                                                  \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) {                                             \
+            pgt_set_error("HIP launch failed: %s", hipGetErrorString(e_)); \
+            return -5;                                                      \
+        }                                                                   \
+    } while (0)

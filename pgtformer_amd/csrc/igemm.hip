@@ -1,0 +1,276 @@
+// Implicit-GEMM convolution / linear layer on MFMA for gfx950 (K1, K2, K3, K4 of SURVEY.md §2.3).
+//
+//   y[m, co] = epi( sum_{ky,kx,ci} x[n, iy, ix, ci] * w[co, (ky*KW+kx)*Cin + ci] + bias[co] )
+//
+// Activations are channels-last (N,H,W,C): a pixel's channels are contiguous, so the GEMM A-operand
+// (M = N*Ho*Wo output pixels, K = KH*KW*Cin) is gathered 16 bytes at a time straight from HBM with
+// no im2col buffer; zero padding, the asymmetric (0,1,0,1) pad of the stride-2 Downsample
+// (reference: archs/tdcrqvae3_arch.py:67-76) and the nearest x2 up-sampling of Upsample
+// (reference: :45-52) are folded into the gather's address computation.  Linear layers and 1x1
+// convs are the KH=KW=1 case (reference: nn.Linear / nn.Conv2d(k=1) call sites listed in §8a).
+//
+// Tile: BM x BN outputs per 256-thread workgroup (4 waves in 2x2), K consumed 128 bytes per row per
+// step (64 bf16 / 32 f32).  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t;
+// LDS rows are padded 128->144 B so the ds_read_b128 fragment reads and ds_write_b128 staging
+// writes are bank-conflict free.  bf16 uses v_mfma_f32_32x32x16_bf16, f32 uses the exact
+// v_mfma_f32_32x32x2_f32 (parity mode); both accumulate in fp32.
+#include "common.h"
+#include "pgt_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowBytes = 128;          // K bytes per tile row
+constexpr int kRowStride = kRowBytes + 16;  // padded LDS row stride
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane half h holds 4 consecutive k of an 8-wide k group; MFMA j pairs (j, 4+j): the k order is
+    // the same for A and B so the contraction is unchanged.
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+struct ConvP {
+    const char* x;
+    const char* w;
+    const float* bias;
+    const char* res;
+    const char* dec;
+    const char* shift;
+    char* y;
+    int N, H, W, Cin, ldx, ups, KH, KW, stride, pad_t, pad_l, Ho, Wo, Cout, ldy;
+    int act, post_relu, ldr, epi, ld_dec, ld_shift, out_f32;
+    float sft_w;
+    int M, K, nbm, nbn;
+};
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
+    constexpr int ES = sizeof(T);
+    constexpr int CH = 16 / ES;            // elements per 16-byte chunk
+    constexpr int BK = kRowBytes / ES;     // K elements per tile step
+    constexpr int AR = BM / 32;            // A rows staged per thread
+    constexpr int BR = BN / 32;
+    constexpr int MI = BM / 64;            // 32x32 MFMA tiles per wave along M
+    constexpr int NI = BN / 64;
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * kRowStride];
+    char* As = smem;
+    char* Bs = smem + BM * kRowStride;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: the 8 XCDs each take a contiguous run of tiles (n fastest) so the
+    // workgroups that share an A tile / a halo run on the same L2 (bijective for any grid size).
+    const int nblk = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    const int sw = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (sw / p.nbn) * BM;
+    const int n0 = (sw % p.nbn) * BN;
+
+    const int cc = tid & 7;    // 16-byte chunk column of this thread within the 128-byte tile row
+    const int r0 = tid >> 3;   // first tile row of this thread (then +32, +64, ...)
+
+    // per-row output-pixel coordinates for the A gather
+    int iy0[AR], ix0[AR], pbase[AR];
+    const int Hv = p.H << p.ups, Wv = p.W << p.ups;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < p.M) {
+            const int ox = m % p.Wo;
+            const int t = m / p.Wo;
+            const int oy = t % p.Ho;
+            const int n = t / p.Ho;
+            iy0[i] = oy * p.stride - p.pad_t;
+            ix0[i] = ox * p.stride - p.pad_l;
+            pbase[i] = n * p.H * p.W;
+        } else {
+            iy0[i] = -(1 << 28);
+            ix0[i] = 0;
+            pbase[i] = 0;
+        }
+    }
+    // K position of this thread's chunk: tap (ky,kx) and channel c, advanced incrementally
+    int kg = cc * CH;
+    int c = kg % p.Cin;
+    int tap = kg / p.Cin;
+    int ky = tap / p.KW, kx = tap % p.KW;
+
+    uint4 ra[AR], rb[BR];
+    auto gload = [&]() {
+        const bool kval = ky < p.KH;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kval && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+                const long pix = (long)pbase[i] + (long)(iy >> p.ups) * p.W + (ix >> p.ups);
+                v = *reinterpret_cast<const uint4*>(p.x + (pix * p.ldx + c) * ES);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int n = n0 + r0 + 32 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (n < p.Cout && kg < p.K) v = *reinterpret_cast<const uint4*>(p.w + ((long)n * p.K + kg) * ES);
+            rb[i] = v;
+        }
+    };
+    auto advance = [&]() {
+        kg += BK;
+        c += BK;
+        while (c >= p.Cin) {
+            c -= p.Cin;
+            if (++kx == p.KW) { kx = 0; ++ky; }
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<uint4*>(As + (r0 + 32 * i) * kRowStride + cc * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<uint4*>(Bs + (r0 + 32 * i) * kRowStride + cc * 16) = rb[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload();
+    advance();
+    sstore();
+    __syncthreads();
+    const char* a_rd = As + (wm * (BM / 2) + (lane & 31)) * kRowStride + (lane >> 5) * 16;
+    const char* b_rd = Bs + (wn * (BN / 2) + (lane & 31)) * kRowStride + (lane >> 5) * 16;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            gload();
+            advance();
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const uint4*>(a_rd + i * 32 * kRowStride + s * 32);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const uint4*>(b_rd + j * 32 * kRowStride + s * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+        }
+        __syncthreads();
+        if (more) {
+            sstore();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: bias, activation, residual, (post-ReLU | SFT modulate), store
+    T* y = reinterpret_cast<T*>(p.y);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    const T* dec = reinterpret_cast<const T*>(p.dec);
+    const T* shf = reinterpret_cast<const T*>(p.shift);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float v = apply_act(acc[i][j][e] + bv, p.act);
+                if (p.epi == 1) {
+                    // SFT: out = dec + w * (dec * scale + shift)  (reference: pgtformer_arch.py:478-479)
+                    const float d = ldf(dec + (long)m * p.ld_dec + n);
+                    const float s = ldf(shf + (long)m * p.ld_shift + n);
+                    v = d + p.sft_w * (d * v + s);
+                } else {
+                    if (res) v += ldf(res + (long)m * p.ldr + n);
+                    if (p.post_relu) v = v > 0.f ? v : 0.f;
+                }
+                if (p.out_f32) reinterpret_cast<float*>(p.y)[(long)m * p.ldy + n] = v;
+                else stf(y + (long)m * p.ldy + n, v);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN> int launch(const ConvP& p0, hipStream_t st) {
+    ConvP p = p0;
+    p.nbm = (p.M + BM - 1) / BM;
+    p.nbn = (p.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(p.nbm * p.nbn), dim3(kThreads), 0, st, p);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm, int force_bn) {
+    int bn = p.Cout <= 64 ? 64 : 128;
+    long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
+    int bm = tiles128 >= 256 ? 128 : 64;
+    if (force_bm) bm = force_bm;
+    if (force_bn) bn = force_bn;
+    if (bm == 128 && bn == 128) return launch<T, 128, 128>(p, st);
+    if (bm == 128 && bn == 64) return launch<T, 128, 64>(p, st);
+    if (bm == 64 && bn == 128) return launch<T, 64, 128>(p, st);
+    return launch<T, 64, 64>(p, st);
+}
+
+}  // namespace
+
+extern "C" int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
+                          const void* residual, const void* sft_dec, const void* sft_shift, void* y,
+                          pgt_stream_t stream) {
+    PGT_CHECK(d && x && w && y, "pgt_conv2d: null argument");
+    PGT_CHECK(d->dtype == PGT_F32 || d->dtype == PGT_BF16, "pgt_conv2d: bad dtype %d", d->dtype);
+    const int es = d->dtype == PGT_F32 ? 4 : 2;
+    const int ch = 16 / es;
+    PGT_CHECK(d->Cin > 0 && d->Cin % ch == 0, "pgt_conv2d: Cin=%d must be a multiple of %d", d->Cin, ch);
+    PGT_CHECK(d->ldx % ch == 0 && d->ldx >= d->Cin, "pgt_conv2d: ldx=%d must be a multiple of %d and >= Cin", d->ldx, ch);
+    PGT_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "pgt_conv2d: x and w must be 16-byte aligned");
+    PGT_CHECK(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->Cout >= 1 && d->N >= 1, "pgt_conv2d: bad geometry");
+    PGT_CHECK(d->ups == 0 || d->ups == 1, "pgt_conv2d: ups must be 0 or 1");
+    PGT_CHECK(d->ldy >= d->Cout, "pgt_conv2d: ldy < Cout");
+    PGT_CHECK(d->epi == 0 || (sft_dec && sft_shift), "pgt_conv2d: SFT epilogue needs dec and shift");
+    ConvP p;
+    p.x = (const char*)x; p.w = (const char*)w; p.bias = bias; p.res = (const char*)residual;
+    p.dec = (const char*)sft_dec; p.shift = (const char*)sft_shift; p.y = (char*)y;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.ups = d->ups;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.ldy = d->ldy; p.act = d->act;
+    p.post_relu = d->post_relu; p.ldr = d->ldr; p.epi = d->epi; p.ld_dec = d->ld_dec;
+    p.ld_shift = d->ld_shift; p.sft_w = d->sft_w; p.out_f32 = d->out_f32;
+    p.M = d->N * d->Ho * d->Wo;
+    p.K = d->KH * d->KW * d->Cin;
+    p.nbm = p.nbn = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == PGT_F32) return dispatch<float>(p, st, d->force_bm, d->force_bn);
+    return dispatch<bf16_t>(p, st, d->force_bm, d->force_bn);
+}

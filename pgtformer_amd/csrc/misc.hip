@@ -1,0 +1,336 @@
+// Quantiser look-ups (K9, K10), BiSeNet glue (K13) and the driver-edge conversions.  All HBM-bound.
+#include "common.h"
+#include "pgt_internal.h"
+
+namespace {
+
+// first-index arg-extremum of a row: one wavefront per row, lanes stride the row, ties -> lowest index
+template <bool IS_MIN>
+__device__ __forceinline__ void wave_argext(float& best, int& bi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool take = IS_MIN ? (ob < best || (ob == best && oi < bi)) : (ob > best || (ob == best && oi < bi));
+        if (take) { best = ob; bi = oi; }
+    }
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int ld, int rows, int K,
+                                                          int* __restrict__ codes) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < K; j += 64) {
+        const float v = xr[j];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = j; }   // ascending j: keeps the first max
+    }
+    wave_argext<false>(best, bi);
+    if (lane == 0) codes[row] = bi;
+}
+
+__global__ __launch_bounds__(256) void rq_argmin_kernel(const float* __restrict__ dot, int ld, const float* __restrict__ xn,
+                                                        const float* __restrict__ en, int rows, int K,
+                                                        int* __restrict__ codes) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* dr = dot + (long)row * ld;
+    const float x2 = xn[row];
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < K; j += 64) {
+        // distance as the reference forms it: (|x|^2 + |e|^2) + (-2) * <x,e>  (addmm, alpha=-2)
+        const float v = (x2 + en[j]) - 2.0f * dr[j];
+        if (v < best || bi == 0x7fffffff) { best = v; bi = j; }
+    }
+    wave_argext<true>(best, bi);
+    if (lane == 0) codes[row] = bi;
+}
+
+template <typename T>
+__global__ void embed_rows_kernel(const float* __restrict__ book, int D, const int* __restrict__ codes, int rows,
+                                  T* __restrict__ out, int ldo, int accumulate, T* __restrict__ resid, int ldres) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * D) return;
+    const int r = (int)(i / D), c = (int)(i % D);
+    const float e = book[(long)codes[r] * D + c];
+    T* o = out + (long)r * ldo + c;
+    stf(o, accumulate ? ldf(o) + e : e);
+    if (resid) {
+        T* rr = resid + (long)r * ldres + c;
+        stf(rr, ldf(rr) - e);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const T* __restrict__ x, int ldx, int rows, int C,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = ldf(x + (long)row * ldx + c); s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, int N, int H, int W, int C, T* __restrict__ y) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * Ho * Wo * C) return;
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float m = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= H) continue;
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if (ix < 0 || ix >= W) continue;
+            m = fmaxf(m, ldf(x + (((long)n * H + iy) * W + ix) * C + c));
+        }
+    }
+    stf(y + i, m);
+}
+
+template <typename T>
+__global__ void gate_add_kernel(const T* __restrict__ x, int ldx, int N, int HW, int C, const T* __restrict__ gate,
+                                const T* __restrict__ addvec, const T* __restrict__ addt, int ldt, T* __restrict__ y,
+                                int ldy) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * HW * C) return;
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int n = (int)(pix / HW);
+    float v = ldf(x + pix * ldx + c);
+    if (gate) v *= ldf(gate + (long)n * C + c);
+    if (addvec) v += ldf(addvec + (long)n * C + c);
+    if (addt) v += ldf(addt + pix * ldt + c);
+    stf(y + pix * ldy + c, v);
+}
+
+template <typename T>
+__global__ void resize_bilinear_kernel(const T* __restrict__ x, int ldx, int N, int Hi, int Wi, int C, T* __restrict__ y,
+                                       int ldy, int Ho, int Wo) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * Ho * Wo * C) return;
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    // align_corners=True source coordinate, as ATen's area_pixel_compute_source_index
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const float fy = sy * oy, fx = sx * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const T* base = x + (long)n * Hi * Wi * ldx + c;
+    const float v00 = ldf(base + ((long)y0 * Wi + x0) * ldx), v01 = ldf(base + ((long)y0 * Wi + x1) * ldx);
+    const float v10 = ldf(base + ((long)y1 * Wi + x0) * ldx), v11 = ldf(base + ((long)y1 * Wi + x1) * ldx);
+    stf(y + (((long)n * Ho + oy) * Wo + ox) * ldy + c, hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+}
+
+template <typename S, typename D>
+__global__ void copy2d_kernel(const S* __restrict__ src, int lds, D* __restrict__ dst, int ldd, long rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    stf(dst + r * ldd + c, ldf(src + r * lds + c));
+}
+
+template <typename T>
+__global__ void prep_input_kernel(const void* __restrict__ src, int kind, int N, int H, int W, T* __restrict__ raw,
+                                  T* __restrict__ norm) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // pixel index
+    if (i >= (long)N * H * W) return;
+    const float mean[3] = {0.485f, 0.456f, 0.406f};
+    const float stdv[3] = {0.229f, 0.224f, 0.225f};
+    float r[8], nn[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = nn[c] = 0.f;
+    if (kind == 0) {
+        const uint8_t* s = (const uint8_t*)src + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] = (float)s[c] / 255.0f;
+    } else {
+        const long hw = (long)H * W;
+        const long n = i / hw, p = i % hw;
+        const float* s = (const float*)src + n * 3 * hw + p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] = s[c * hw];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nn[c] = (r[c] - mean[c]) / stdv[c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (raw) stf(raw + i * 8 + c, r[c]);
+        if (norm) stf(norm + i * 8 + c, nn[c]);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, int ldx, int N, int H, int W, int C, float* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // output index, NCHW
+    if (i >= (long)N * C * H * W) return;
+    const long hw = (long)H * W;
+    const long p = i % hw;
+    const int c = (int)((i / hw) % C);
+    const long n = i / (hw * C);
+    y[i] = ldf(x + (n * hw + p) * ldx + c);
+}
+
+template <typename T>
+__global__ void frame_to_u8_kernel(const T* __restrict__ x, int ldx, long npix, uint8_t* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * 3) return;
+    const long p = i / 3;
+    const int c = (int)(i % 3);
+    float v = ldf(x + p * ldx + c);
+    v = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+    y[i] = (uint8_t)v;   // truncation toward zero, like np.array(float, np.uint8)
+}
+
+inline dim3 grid1d(long n, int blk = 256) { return dim3((unsigned)((n + blk - 1) / blk)); }
+
+}  // namespace
+
+#define DT_DISPATCH(dtype, NAME, CALL_F32, CALL_BF16)              \
+    do {                                                           \
+        if ((dtype) == PGT_F32) { CALL_F32; }                      \
+        else if ((dtype) == PGT_BF16) { CALL_BF16; }               \
+        else PGT_CHECK(false, NAME ": bad dtype %d", (int)(dtype)); \
+        PGT_LAUNCH_CHECK();                                        \
+        return 0;                                                  \
+    } while (0)
+
+extern "C" int pgt_argmax_rows(const float* logits, int32_t ld, int32_t rows, int32_t K, int32_t* codes,
+                               pgt_stream_t stream) {
+    PGT_CHECK(logits && codes && K > 0, "argmax_rows: bad argument");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, rows, K, codes);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_rq_argmin(const float* dot, int32_t ld, const float* xnorm, const float* enorm, int32_t rows,
+                             int32_t K, int32_t* codes, pgt_stream_t stream) {
+    PGT_CHECK(dot && xnorm && enorm && codes && K > 0, "rq_argmin: bad argument");
+    hipLaunchKernelGGL(rq_argmin_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dot, ld, xnorm, enorm, rows, K, codes);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_embed_rows(int32_t dtype, const float* codebook, int32_t D, const int32_t* codes, int32_t rows,
+                              void* out, int32_t ldo, int32_t accumulate, void* resid, int32_t ldres,
+                              pgt_stream_t stream) {
+    PGT_CHECK(codebook && codes && out, "embed_rows: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g = grid1d((long)rows * D);
+    DT_DISPATCH(dtype, "embed_rows",
+                hipLaunchKernelGGL((embed_rows_kernel<float>), g, dim3(256), 0, st, codebook, D, codes, rows, (float*)out, ldo, accumulate, (float*)resid, ldres),
+                hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), g, dim3(256), 0, st, codebook, D, codes, rows, (bf16_t*)out, ldo, accumulate, (bf16_t*)resid, ldres));
+}
+
+extern "C" int pgt_row_sumsq(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t C, float* out,
+                             pgt_stream_t stream) {
+    PGT_CHECK(x && out, "row_sumsq: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g((rows + 3) / 4);
+    DT_DISPATCH(dtype, "row_sumsq",
+                hipLaunchKernelGGL((row_sumsq_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, rows, C, out),
+                hipLaunchKernelGGL((row_sumsq_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, C, out));
+}
+
+extern "C" int pgt_maxpool3x3s2(int32_t dtype, const void* x, int32_t N, int32_t H, int32_t W, int32_t C, void* y,
+                                pgt_stream_t stream) {
+    PGT_CHECK(x && y, "maxpool: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const dim3 g = grid1d((long)N * Ho * Wo * C);
+    DT_DISPATCH(dtype, "maxpool",
+                hipLaunchKernelGGL((maxpool_kernel<float>), g, dim3(256), 0, st, (const float*)x, N, H, W, C, (float*)y),
+                hipLaunchKernelGGL((maxpool_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, N, H, W, C, (bf16_t*)y));
+}
+
+extern "C" int pgt_gate_add(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
+                            const void* gate, const void* addvec, const void* addt, int32_t ldt, void* y, int32_t ldy,
+                            pgt_stream_t stream) {
+    PGT_CHECK(x && y, "gate_add: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g = grid1d((long)N * HW * C);
+    DT_DISPATCH(dtype, "gate_add",
+                hipLaunchKernelGGL((gate_add_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, N, HW, C, (const float*)gate, (const float*)addvec, (const float*)addt, ldt, (float*)y, ldy),
+                hipLaunchKernelGGL((gate_add_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, N, HW, C, (const bf16_t*)gate, (const bf16_t*)addvec, (const bf16_t*)addt, ldt, (bf16_t*)y, ldy));
+}
+
+extern "C" int pgt_resize_bilinear_ac(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t Hi, int32_t Wi,
+                                      int32_t C, void* y, int32_t ldy, int32_t Ho, int32_t Wo, pgt_stream_t stream) {
+    PGT_CHECK(x && y, "resize_bilinear: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g = grid1d((long)N * Ho * Wo * C);
+    DT_DISPATCH(dtype, "resize_bilinear",
+                hipLaunchKernelGGL((resize_bilinear_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, N, Hi, Wi, C, (float*)y, ldy, Ho, Wo),
+                hipLaunchKernelGGL((resize_bilinear_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, N, Hi, Wi, C, (bf16_t*)y, ldy, Ho, Wo));
+}
+
+extern "C" int pgt_copy2d(int32_t src_dtype, const void* src, int32_t lds, int32_t dst_dtype, void* dst, int32_t ldd,
+                          int64_t rows, int32_t cols, pgt_stream_t stream) {
+    PGT_CHECK(src && dst, "copy2d: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g = grid1d((long)rows * cols);
+    const dim3 b(256);
+    if (src_dtype == PGT_F32 && dst_dtype == PGT_F32)
+        hipLaunchKernelGGL((copy2d_kernel<float, float>), g, b, 0, st, (const float*)src, lds, (float*)dst, ldd, (long)rows, cols);
+    else if (src_dtype == PGT_F32 && dst_dtype == PGT_BF16)
+        hipLaunchKernelGGL((copy2d_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, lds, (bf16_t*)dst, ldd, (long)rows, cols);
+    else if (src_dtype == PGT_BF16 && dst_dtype == PGT_F32)
+        hipLaunchKernelGGL((copy2d_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, lds, (float*)dst, ldd, (long)rows, cols);
+    else if (src_dtype == PGT_BF16 && dst_dtype == PGT_BF16)
+        hipLaunchKernelGGL((copy2d_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, (long)rows, cols);
+    else
+        PGT_CHECK(false, "copy2d: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_prep_input(int32_t dtype, const void* src, int32_t src_kind, int32_t N, int32_t H, int32_t W,
+                              void* raw, void* norm, pgt_stream_t stream) {
+    PGT_CHECK(src && (raw || norm), "prep_input: null argument");
+    PGT_CHECK(src_kind == 0 || src_kind == 1, "prep_input: src_kind must be 0 (u8 NHWC) or 1 (f32 NCHW)");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g = grid1d((long)N * H * W);
+    DT_DISPATCH(dtype, "prep_input",
+                hipLaunchKernelGGL((prep_input_kernel<float>), g, dim3(256), 0, st, src, src_kind, N, H, W, (float*)raw, (float*)norm),
+                hipLaunchKernelGGL((prep_input_kernel<bf16_t>), g, dim3(256), 0, st, src, src_kind, N, H, W, (bf16_t*)raw, (bf16_t*)norm));
+}
+
+extern "C" int pgt_nhwc_to_nchw_f32(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t H, int32_t W,
+                                    int32_t C, float* y, pgt_stream_t stream) {
+    PGT_CHECK(x && y, "nhwc_to_nchw: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g = grid1d((long)N * C * H * W);
+    DT_DISPATCH(dtype, "nhwc_to_nchw",
+                hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, N, H, W, C, y),
+                hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, N, H, W, C, y));
+}
+
+extern "C" int pgt_frame_to_u8(int32_t dtype, const void* x, int32_t ldx, int32_t H, int32_t W, uint8_t* y,
+                               pgt_stream_t stream) {
+    PGT_CHECK(x && y, "frame_to_u8: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long npix = (long)H * W;
+    const dim3 g = grid1d(npix * 3);
+    DT_DISPATCH(dtype, "frame_to_u8",
+                hipLaunchKernelGGL((frame_to_u8_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, npix, y),
+                hipLaunchKernelGGL((frame_to_u8_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, npix, y));
+}

@@ -1,0 +1,352 @@
+// Normalisation kernels (K6, K7, K11 of SURVEY.md §2.3): HBM-bound, 16-byte vector accesses,
+// every thread keeps a fixed channel chunk so per-channel coefficients live in registers.
+#include "common.h"
+#include "pgt_internal.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics, stage 1: per (image, pixel-chunk) partial sum / sum-of-squares per group.
+// Thread -> (pixel slot, 16-byte channel chunk); the chunk is fixed per thread, pixels strided.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NQ>
+__global__ __launch_bounds__(kT) void gn_partial_kernel(const T* __restrict__ x, int ldx, int HW, int C, int groups,
+                                                        int pix_per_blk, float* __restrict__ part) {
+    constexpr int CH = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C] sums, then [slots][C] sumsq
+    const int QC = C / CH;
+    const int PS = NQ > 1 ? 1 : kT / QC;
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int slot = NQ > 1 ? 0 : tid / QC;
+    const int q0 = NQ > 1 ? tid : tid % QC;
+    const bool active = NQ > 1 ? true : tid < PS * QC;
+    float s[NQ][CH], ss[NQ][CH];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s[j][e] = ss[j][e] = 0.f;
+    const int p_begin = blk * pix_per_blk;
+    const int p_end = min(HW, p_begin + pix_per_blk);
+    if (active) {
+        for (int p = p_begin + slot; p < p_end; p += PS) {
+            const T* row = x + ((long)n * HW + p) * ldx;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = q0 + j * kT;
+                if (q < QC) {
+                    float f[CH];
+                    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(row + q * CH), f);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) { s[j][e] += f[e]; ss[j][e] += f[e] * f[e]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = q0 + j * kT;
+            if (q < QC) {
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    sm[slot * C + q * CH + e] = s[j][e];
+                    sm[(PS + slot) * C + q * CH + e] = ss[j][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const int cpg = C / groups;
+        float a = 0.f, b = 0.f;
+        for (int sl = 0; sl < PS; ++sl)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += sm[sl * C + c]; b += sm[(PS + sl) * C + c]; }
+        float* o = part + (((long)n * gridDim.x + blk) * groups + tid) * 2;
+        o[0] = a;
+        o[1] = b;
+    }
+}
+
+// stage 2: fixed-order reduction of the partials in double, then per-(n,c) affine coefficients
+__global__ void gn_finalize_kernel(const float* __restrict__ part, int nblk, int HW, int C, int groups, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int n = blockIdx.x;
+    const int cpg = C / groups;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < nblk; ++k) {
+            const float* o = part + (((long)n * nblk + k) * groups + g) * 2;
+            a += (double)o[0];
+            b += (double)o[1];
+        }
+        const double cnt = (double)HW * cpg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * gamma[c];
+        scale[(long)n * C + c] = sc;
+        shift[(long)n * C + c] = beta[c] - s_mean[g] * sc;
+    }
+}
+
+// y = act(x*scale[n,c] + shift[n,c])
+template <typename T, int NQ>
+__global__ __launch_bounds__(kT) void affine_act_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                        int HW, int C, int pix_per_blk, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int act) {
+    constexpr int CH = Vec16<T>::N;
+    const int QC = C / CH;
+    const int PS = NQ > 1 ? 1 : kT / QC;
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int slot = NQ > 1 ? 0 : tid / QC;
+    const int q0 = NQ > 1 ? tid : tid % QC;
+    if (NQ == 1 && tid >= PS * QC) return;
+    float sc[NQ][CH], sh[NQ][CH];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q = q0 + j * kT;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            sc[j][e] = q < QC ? scale[(long)n * C + q * CH + e] : 0.f;
+            sh[j][e] = q < QC ? shift[(long)n * C + q * CH + e] : 0.f;
+        }
+    }
+    const int p_begin = blockIdx.x * pix_per_blk;
+    const int p_end = min(HW, p_begin + pix_per_blk);
+    for (int p = p_begin + slot; p < p_end; p += PS) {
+        const T* row = x + ((long)n * HW + p) * ldx;
+        T* orow = y + ((long)n * HW + p) * ldy;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = q0 + j * kT;
+            if (q < QC) {
+                float f[CH];
+                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(row + q * CH), f);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) f[e] = apply_act(f[e] * sc[j][e] + sh[j][e], act);
+                *reinterpret_cast<uint4*>(orow + q * CH) = Vec16<T>::pack(f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wavefront per row, C/64 contiguous elements per lane, two-pass in registers.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int EPL>
+__global__ __launch_bounds__(kT) void layernorm_kernel(const T* __restrict__ x, int ldx, int rows, int C,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, T* __restrict__ y, int ldy, const T* __restrict__ pos,
+                                                       int ldpos, T* __restrict__ y2, int ldy2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int c0 = lane * EPL;
+    float v[EPL];
+    const T* xr = x + (long)row * ldx + c0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = ldf(xr + e);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += v[e];
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { const float d = v[e] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+    T* yr = y + (long)row * ldy + c0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        v[e] = (v[e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+        stf(yr + e, v[e]);
+    }
+    if (y2) {
+        const T* pr = pos + (long)row * ldpos + c0;
+        T* y2r = y2 + (long)row * ldy2 + c0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) stf(y2r + e, v[e] + ldf(pr + e));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-(n,c) mean / unbiased variance over HW (AdaIN statistics; also global average pooling)
+// grid (C/64, N), block 256 = 4 pixel slots x 64 channels
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kT) void channel_stats_kernel(const T* __restrict__ x, int ldx, int HW, int C,
+                                                           float* __restrict__ mean, float* __restrict__ var) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slot = threadIdx.x >> 6;
+    const int n = blockIdx.y;
+    const bool ok = c < C;
+    float s = 0.f;
+    if (ok)
+        for (int p = slot; p < HW; p += 4) s += ldf(x + ((long)n * HW + p) * ldx + c);
+    sm[slot][threadIdx.x & 63] = s;
+    __syncthreads();
+    const float mu = (sm[0][threadIdx.x & 63] + sm[1][threadIdx.x & 63] + sm[2][threadIdx.x & 63] + sm[3][threadIdx.x & 63]) / (float)HW;
+    __syncthreads();
+    float q = 0.f;
+    if (ok && var)
+        for (int p = slot; p < HW; p += 4) { const float d = ldf(x + ((long)n * HW + p) * ldx + c) - mu; q += d * d; }
+    sm[slot][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (slot == 0 && ok) {
+        mean[(long)n * C + c] = mu;
+        if (var) var[(long)n * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)(HW > 1 ? HW - 1 : 1);
+    }
+}
+
+__global__ void adain_affine_kernel(const float* mc, const float* vc, const float* ms, const float* vs, float eps,
+                                    float* scale, float* shift, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sc = sqrtf(vs[i] + eps) / sqrtf(vc[i] + eps);
+    scale[i] = sc;
+    shift[i] = ms[i] - mc[i] * sc;
+}
+
+inline int gn_pix_per_block(int N, int HW, int QC) {
+    const int ps = QC >= kT ? 1 : kT / QC;
+    int target_blocks = 2048 / (N > 0 ? N : 1);
+    if (target_blocks < 1) target_blocks = 1;
+    int ppb = (HW + target_blocks - 1) / target_blocks;
+    const int min_ppb = ps * 8;
+    if (ppb < min_ppb) ppb = min_ppb;
+    return ppb;
+}
+
+}  // namespace
+
+extern "C" size_t pgt_groupnorm_workspace_bytes(int32_t N, int32_t HW, int32_t C, int32_t groups) {
+    // upper bound independent of dtype: smallest chunk count is C/8
+    const int ppb = gn_pix_per_block(N, HW, C / 8 > 0 ? C / 8 : 1);
+    const int ppb4 = gn_pix_per_block(N, HW, C / 4 > 0 ? C / 4 : 1);
+    const int nb = (HW + (ppb < ppb4 ? ppb : ppb4) - 1) / (ppb < ppb4 ? ppb : ppb4);
+    return (size_t)N * nb * groups * 2 * sizeof(float);
+}
+
+template <typename T>
+static int gn_affine_impl(const void* x, int ldx, int N, int HW, int C, int groups, float eps, const float* gamma,
+                          const float* beta, float* scale, float* shift, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int CH = Vec16<T>::N;
+    PGT_CHECK(C % CH == 0 && ldx % CH == 0, "groupnorm: C=%d, ldx=%d must be multiples of %d", C, ldx, CH);
+    PGT_CHECK(C % groups == 0 && groups <= 64, "groupnorm: C=%d not divisible by groups=%d (<=64)", C, groups);
+    const int QC = C / CH;
+    PGT_CHECK(QC <= 2 * kT, "groupnorm: C=%d too large", C);
+    const int ppb = gn_pix_per_block(N, HW, QC);
+    const int nb = (HW + ppb - 1) / ppb;
+    PGT_CHECK((size_t)N * nb * groups * 2 * sizeof(float) <= ws_bytes, "groupnorm: workspace too small");
+    const int ps = QC > kT ? 1 : kT / QC;
+    const size_t lds = (size_t)2 * ps * C * sizeof(float);
+    float* part = (float*)ws;
+    if (QC > kT)
+        hipLaunchKernelGGL((gn_partial_kernel<T, 2>), dim3(nb, N), dim3(kT), lds, st, (const T*)x, ldx, HW, C, groups, ppb, part);
+    else
+        hipLaunchKernelGGL((gn_partial_kernel<T, 1>), dim3(nb, N), dim3(kT), lds, st, (const T*)x, ldx, HW, C, groups, ppb, part);
+    PGT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, st, part, nb, HW, C, groups, eps, gamma, beta, scale, shift);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_groupnorm_affine(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
+                                    int32_t groups, float eps, const float* gamma, const float* beta, float* scale,
+                                    float* shift, void* workspace, size_t workspace_bytes, pgt_stream_t stream) {
+    PGT_CHECK(x && gamma && beta && scale && shift && workspace, "groupnorm: null argument");
+    PGT_CHECK(((uintptr_t)x & 15) == 0, "groupnorm: x must be 16-byte aligned");
+    if (dtype == PGT_F32) return gn_affine_impl<float>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream);
+    if (dtype == PGT_BF16) return gn_affine_impl<bf16_t>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream);
+    PGT_CHECK(false, "groupnorm: bad dtype %d", dtype);
+}
+
+template <typename T>
+static int affine_act_impl(const void* x, int ldx, void* y, int ldy, int N, int HW, int C, const float* scale,
+                           const float* shift, int act, hipStream_t st) {
+    constexpr int CH = Vec16<T>::N;
+    PGT_CHECK(C % CH == 0 && ldx % CH == 0 && ldy % CH == 0, "affine_act: C/ldx/ldy must be multiples of %d", CH);
+    const int QC = C / CH;
+    PGT_CHECK(QC <= 2 * kT, "affine_act: C=%d too large", C);
+    const int ppb = gn_pix_per_block(N, HW, QC);
+    const int nb = (HW + ppb - 1) / ppb;
+    if (QC > kT)
+        hipLaunchKernelGGL((affine_act_kernel<T, 2>), dim3(nb, N), dim3(kT), 0, st, (const T*)x, ldx, (T*)y, ldy, HW, C, ppb, scale, shift, act);
+    else
+        hipLaunchKernelGGL((affine_act_kernel<T, 1>), dim3(nb, N), dim3(kT), 0, st, (const T*)x, ldx, (T*)y, ldy, HW, C, ppb, scale, shift, act);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_affine_act(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N, int32_t HW,
+                              int32_t C, const float* scale, const float* shift, int32_t act, pgt_stream_t stream) {
+    PGT_CHECK(x && y && scale && shift, "affine_act: null argument");
+    PGT_CHECK((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "affine_act: x and y must be 16-byte aligned");
+    if (dtype == PGT_F32) return affine_act_impl<float>(x, ldx, y, ldy, N, HW, C, scale, shift, act, (hipStream_t)stream);
+    if (dtype == PGT_BF16) return affine_act_impl<bf16_t>(x, ldx, y, ldy, N, HW, C, scale, shift, act, (hipStream_t)stream);
+    PGT_CHECK(false, "affine_act: bad dtype %d", dtype);
+}
+
+template <typename T>
+static int layernorm_impl(const void* x, int ldx, int rows, int C, const float* gamma, const float* beta, float eps,
+                          void* y, int ldy, const void* pos, int ldpos, void* y2, int ldy2, hipStream_t st) {
+    const dim3 grid((rows + 3) / 4), blk(kT);
+#define LN_LAUNCH(EPL)                                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<T, EPL>), grid, blk, 0, st, (const T*)x, ldx, rows, C, gamma, beta, eps,  \
+                       (T*)y, ldy, (const T*)pos, ldpos, (T*)y2, ldy2)
+    switch (C) {
+        case 64: LN_LAUNCH(1); break;
+        case 128: LN_LAUNCH(2); break;
+        case 256: LN_LAUNCH(4); break;
+        case 512: LN_LAUNCH(8); break;
+        case 1024: LN_LAUNCH(16); break;
+        default: PGT_CHECK(false, "layernorm: C=%d unsupported (64,128,256,512,1024)", C);
+    }
+#undef LN_LAUNCH
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_layernorm(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t C, const float* gamma,
+                             const float* beta, float eps, void* y, int32_t ldy, const void* pos, int32_t ldpos,
+                             void* y2, int32_t ldy2, pgt_stream_t stream) {
+    PGT_CHECK(x && y && gamma && beta, "layernorm: null argument");
+    PGT_CHECK(!y2 || pos, "layernorm: y2 requested without pos");
+    if (dtype == PGT_F32) return layernorm_impl<float>(x, ldx, rows, C, gamma, beta, eps, y, ldy, pos, ldpos, y2, ldy2, (hipStream_t)stream);
+    if (dtype == PGT_BF16) return layernorm_impl<bf16_t>(x, ldx, rows, C, gamma, beta, eps, y, ldy, pos, ldpos, y2, ldy2, (hipStream_t)stream);
+    PGT_CHECK(false, "layernorm: bad dtype %d", dtype);
+}
+
+extern "C" int pgt_channel_stats(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
+                                 float* mean, float* var_unbiased, pgt_stream_t stream) {
+    PGT_CHECK(x && mean, "channel_stats: null argument");
+    const dim3 grid((C + 63) / 64, N), blk(kT);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PGT_F32)
+        hipLaunchKernelGGL((channel_stats_kernel<float>), grid, blk, 0, st, (const float*)x, ldx, HW, C, mean, var_unbiased);
+    else if (dtype == PGT_BF16)
+        hipLaunchKernelGGL((channel_stats_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, C, mean, var_unbiased);
+    else
+        PGT_CHECK(false, "channel_stats: bad dtype %d", dtype);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_adain_affine(const float* mean_c, const float* var_c, const float* mean_s, const float* var_s,
+                                float eps, float* scale, float* shift, int32_t n, pgt_stream_t stream) {
+    PGT_CHECK(mean_c && var_c && mean_s && var_s && scale && shift, "adain_affine: null argument");
+    hipLaunchKernelGGL(adain_affine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean_c, var_c,
+                       mean_s, var_s, eps, scale, shift, n);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,78 @@
+"""ctypes binding of libpgt_hip.so (the C-ABI declared in include/pgt_hip.h).
+
+The library is loaded lazily on first use and the product path FAILS LOUDLY when it is missing:
+there is no CPU or PyTorch fallback anywhere in `pgtformer_amd`.
+"""
+import ctypes as C
+import os
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpgt_hip.so")
+
+PGT_F32, PGT_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_LEAKY02, ACT_SIGMOID = range(6)
+EPI_PLAIN, EPI_SFT = 0, 1
+
+i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `pgt_conv_desc` (include/pgt_hip.h)."""
+    _fields_ = [(n, i32) for n in ("dtype", "N", "H", "W", "Cin", "ldx", "ups", "KH", "KW", "stride", "pad_t",
+                                   "pad_l", "Ho", "Wo", "Cout", "ldy", "act", "post_relu", "ldr", "epi",
+                                   "ld_dec", "ld_shift")] + [("sft_w", f32)] + \
+               [(n, i32) for n in ("out_f32", "force_bm", "force_bn")]
+
+
+# name -> argtypes (restype is int32 unless listed in _RESTYPES); must cover every symbol of pgt_hip.h
+SIGNATURES = {
+    "pgt_version": [],
+    "pgt_last_error": [],
+    "pgt_conv2d": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp],
+    "pgt_groupnorm_workspace_bytes": [i32, i32, i32, i32],
+    "pgt_groupnorm_affine": [i32, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp],
+    "pgt_affine_act": [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp],
+    "pgt_layernorm": [i32, vp, i32, i32, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, vp],
+    "pgt_channel_stats": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
+    "pgt_adain_affine": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
+    "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "pgt_mha": [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
+    "pgt_argmax_rows": [vp, i32, i32, i32, vp, vp],
+    "pgt_rq_argmin": [vp, i32, vp, vp, i32, i32, vp, vp],
+    "pgt_embed_rows": [i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp],
+    "pgt_row_sumsq": [i32, vp, i32, i32, i32, vp, vp],
+    "pgt_maxpool3x3s2": [i32, vp, i32, i32, i32, i32, vp, vp],
+    "pgt_gate_add": [i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, vp],
+    "pgt_resize_bilinear_ac": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
+    "pgt_copy2d": [i32, vp, i32, i32, vp, i32, i64, i32, vp],
+    "pgt_prep_input": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
+    "pgt_nhwc_to_nchw_f32": [i32, vp, i32, i32, i32, i32, i32, vp, vp],
+    "pgt_frame_to_u8": [i32, vp, i32, i32, i32, vp, vp],
+}
+_RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz}
+
+
+class PgtError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise PgtError(f"{LIB_PATH} is missing: build it with `python -m pgtformer_amd.build` "
+                           "(there is no fallback path)")
+        h = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, i32)
+        _LIB = h
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().pgt_last_error()
+        raise PgtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -210,7 +210,7 @@ def tdcrqvae3_manifest(cfg):
     depth = cfg["code_shape"][-1]
     ls, cs = cfg["latent_shape"], cfg["code_shape"]
     vq_dim = (ls[0] * ls[1]) // (cs[0] * cs[1]) * ls[2]
-    n_books = 1 if cfg.get("shared_codebook", False) else depth
+    n_books = depth  # a shared codebook is the same module listed `depth` times (duplicate keys)
     for i in range(n_books):
         q = f"quantizer.codebooks.{i}"
         m.add(q + ".weight", (n_embed + 1, vq_dim))

@@ -1,0 +1,223 @@
+"""Temporal-coherent transformer layers and residual conv blocks, HIP-backed.
+
+Host-side mirror of the symbols the reference path uses from modules/rstt_layers.py — same class
+names, constructor arguments and state-dict keys — whose forward() launches the gfx950 kernels via
+`pgtformer_amd.ops` instead of ATen.  Activations are channels-last: a (B,D,C,H,W) reference tensor is
+held here as (B*D, H, W, C); the (D,Wh,Ww) window partition / roll / reverse of the reference
+(rstt_layers.py:55-88, 307-327) never materialise: they are address arithmetic inside the attention
+kernel.
+
+torch.nn modules are used as PARAMETER CONTAINERS only (so checkpoints load unchanged); their
+forward() is never called.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_NONE, ACT_SILU
+
+
+class HipModule(nn.Module):
+    """Base: `prepare(device, dtype)` repacks this module's weights for the kernels (recursively)."""
+
+    def prepare(self, device, dtype):
+        prepare_tree(self, device, dtype)
+        return self
+
+    def _pack(self, device, dtype):
+        pass
+
+
+def prepare_tree(m, device, dtype):
+    """Walk a module tree (through plain nn containers too) and repack every HipModule."""
+    if isinstance(m, HipModule):
+        m.dev, m.dt = device, dtype
+        m._pack(device, dtype)
+    for child in m.children():
+        prepare_tree(child, device, dtype)
+
+
+def _f32(t, device):
+    return None if t is None else t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Conv2d(nn.Conv2d, HipModule):
+    """nn.Conv2d parameter container + implicit-GEMM launch. Weight (Cout,Cin,KH,KW) is repacked to
+    (Cout, KH*KW*Cin) K-major; `bn` folds an eval-mode BatchNorm2d; `cin_pad` zero-pads input channels
+    (3->8, 57->64) to the 16-byte gather granule."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, pad4=None, cin_pad=None):
+        nn.Conv2d.__init__(self, cin, cout, k, stride=stride, padding=padding, bias=bias)
+        self.pad4 = pad4 if pad4 is not None else (padding, padding, padding, padding)
+        self.cin_pad = cin_pad
+        self._bn_ref = ()  # (BatchNorm2d,) to fold; a tuple so it is not registered as a sub-module
+
+    def _pack(self, device, dtype):
+        w = self.weight.detach().float()
+        b = self.bias.detach().float() if self.bias is not None else None
+        if self._bn_ref:
+            bn = self._bn_ref[0]
+            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            w = w * s.view(-1, 1, 1, 1)
+            b0 = b if b is not None else torch.zeros_like(s)
+            b = (b0 - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+        cout, cin, kh, kw = w.shape
+        if self.cin_pad is not None and self.cin_pad > cin:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, self.cin_pad - cin))
+        self.pw = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(device=device, dtype=dtype)
+        self.pb = _f32(b, device)
+
+    def run(self, x, **kw):
+        return ops.conv2d(x, self.pw, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
+                          stride=self.stride[0], pad=self.pad4, **kw)
+
+
+class Linear(nn.Linear, HipModule):
+    def _pack(self, device, dtype):
+        self.pw = self.weight.detach().to(device=device, dtype=dtype).contiguous()
+        self.pb = _f32(self.bias, device)
+
+    def run(self, x, **kw):
+        return ops.linear(x, self.pw, self.pb, **kw)
+
+
+class GroupNorm(nn.GroupNorm, HipModule):
+    def _pack(self, device, dtype):
+        self.pg, self.pbeta = _f32(self.weight, device), _f32(self.bias, device)
+
+    def run(self, x, act=ACT_SILU):
+        return ops.groupnorm_act(x, self.pg, self.pbeta, act, self.num_groups, self.eps)
+
+
+class LayerNorm(nn.LayerNorm, HipModule):
+    def _pack(self, device, dtype):
+        self.pg, self.pbeta = _f32(self.weight, device), _f32(self.bias, device)
+
+    def run(self, x, pos=None):
+        return ops.layernorm(x, self.pg, self.pbeta, self.eps, pos)
+
+
+def Normalize(in_channels):
+    """GroupNorm(32, C, eps=1e-6) (reference: rstt_layers.py:754-755)."""
+    return GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def get_window_size(x_size, window_size, shift_size=None):
+    """Clamp window (and zero the shift) where the feature map is not larger than the window
+    (reference: rstt_layers.py:90-114)."""
+    use_w = list(window_size)
+    use_s = list(shift_size) if shift_size is not None else None
+    for i in range(len(x_size)):
+        if x_size[i] <= window_size[i]:
+            use_w[i] = x_size[i]
+            if use_s is not None:
+                use_s[i] = 0
+    return tuple(use_w) if use_s is None else (tuple(use_w), tuple(use_s))
+
+
+class TDResnetBlock(HipModule):
+    """GN-SiLU-conv3x3-GN-SiLU-conv3x3 + (identity | 1x1 nin_shortcut) (reference: rstt_layers.py:835-904).
+    x: (N,H,W,Cin) -> (N,H,W,Cout); the residual add is the second conv's epilogue."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        assert not conv_shortcut and temb_channels == 0, "not used on the PGTFormer path"
+        self.checkpointing = False
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = Conv2d(in_channels, out_channels, 3, padding=1)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = Conv2d(out_channels, out_channels, 3, padding=1)
+        if in_channels != out_channels:
+            self.nin_shortcut = Conv2d(in_channels, out_channels, 1)
+
+    def forward(self, x, temb=None):
+        h = self.conv1.run(self.norm1.run(x, ACT_SILU))
+        h = self.norm2.run(h, ACT_SILU)
+        sc = self.nin_shortcut.run(x) if self.in_channels != self.out_channels else x
+        return self.conv2.run(h, res=sc)
+
+
+class Mlp(HipModule):
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        self.fc1 = Linear(in_features, hidden_features or in_features)
+        self.fc2 = Linear(hidden_features or in_features, out_features or in_features)
+
+
+class WindowAttention3D(HipModule):
+    """Parameters of the (D,Wh,Ww)-window attention (reference: rstt_layers.py:134-193)."""
+
+    def __init__(self, dim, num_frames_q, num_frames_kv, window_size, num_heads, qkv_bias=True):
+        super().__init__()
+        assert num_frames_q == num_frames_kv, "self-attention only on the PGTFormer path"
+        self.dim, self.num_frames, self.window_size, self.num_heads = dim, num_frames_q, tuple(window_size), num_heads
+        d, wh, ww = num_frames_q, window_size[0], window_size[1]
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * d - 1) * (2 * wh - 1) * (2 * ww - 1), num_heads))
+        from ..weightgen import relative_position_index
+        self.register_buffer("relative_position_index", torch.from_numpy(relative_position_index(d, (wh, ww))))
+        self.q = Linear(dim, dim, bias=qkv_bias)
+        self.kv = Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj = Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+
+    def _pack(self, device, dtype):
+        # one fused (3C,C) projection [q | k | v]; dense per-head bias gathered once from the table
+        self.w_qkv = torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0).to(device=device, dtype=dtype).contiguous()
+        if self.q.bias is not None:
+            self.b_qkv = _f32(torch.cat([self.q.bias.detach(), self.kv.bias.detach()], 0), device)
+        else:
+            self.b_qkv = None
+        n = self.relative_position_index.shape[0]
+        tbl = self.relative_position_bias_table.detach().float().cpu()
+        idx = self.relative_position_index.cpu().reshape(-1)
+        self.bias_dense = tbl[idx].reshape(n, n, -1).permute(2, 0, 1).contiguous().to(device)
+
+
+class VSTSREncoderTransformerBlock(HipModule):
+    """LN -> window attention -> +shortcut -> LN -> MLP(GELU) -> +residual (reference: rstt_layers.py:236-338)."""
+
+    def __init__(self, dim, num_heads, num_frames=4, window_size=(8, 8), shift_size=(0, 0), mlp_ratio=4.0, qkv_bias=True):
+        super().__init__()
+        self.dim, self.num_heads, self.num_frames = dim, num_heads, num_frames
+        self.window_size, self.shift_size = tuple(window_size), tuple(shift_size)
+        self.norm1 = LayerNorm(dim)
+        self.attn = WindowAttention3D(dim, num_frames, num_frames, self.window_size, num_heads, qkv_bias)
+        self.norm2 = LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, xt, B, H, W):
+        """xt: (B*D*H*W, C) tokens in (b,d,y,x) order."""
+        C = self.dim
+        win, shift = get_window_size((H, W), self.window_size, self.shift_size)
+        ln = self.norm1.run(xt)
+        qkv = ops.linear(ln, self.attn.w_qkv, self.attn.b_qkv)
+        ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift)
+        x1 = self.attn.proj.run(ao, res=xt)
+        m = self.mlp.fc1.run(self.norm2.run(x1), act=ACT_GELU)
+        return self.mlp.fc2.run(m, res=x1)
+
+
+class EncoderLayer(HipModule):
+    """depth blocks alternating un-shifted / shifted windows (reference: rstt_layers.py:499-575)."""
+
+    def __init__(self, dim, depth, num_heads, num_frames, window_size=(8, 8), mlp_ratio=4.0, qkv_bias=True):
+        super().__init__()
+        self.window_size = tuple(window_size)
+        self.shift_size = tuple(i // 2 for i in window_size)
+        self.depth, self.num_frames, self.dim = depth, num_frames, dim
+        self.blocks = nn.ModuleList([
+            VSTSREncoderTransformerBlock(dim, num_heads, num_frames, self.window_size,
+                                         (0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio, qkv_bias)
+            for i in range(depth)])
+
+    def forward(self, x):
+        """x: (B*D, H, W, C) -> same."""
+        n, h, w, c = x.shape
+        assert h % self.window_size[0] == 0 or h <= self.window_size[0]
+        xt = x.reshape(n * h * w, c)
+        for blk in self.blocks:
+            xt = blk(xt, n // self.num_frames, h, w)
+        return xt.reshape(n, h, w, c)

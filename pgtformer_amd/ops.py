@@ -1,0 +1,299 @@
+"""Operator layer: thin Python wrappers that launch the HIP kernels of libpgt_hip.so on torch device
+tensors (torch is used for memory, streams and views only — all arithmetic happens in the kernels).
+
+Tensors are channels-last: images (N,H,W,C), token matrices (rows,C); the last dim must be contiguous
+and the pixel/row stride may exceed C (channel slices of a wider buffer are valid inputs/outputs).
+dtype torch.float32 selects the exact-f32 kernels, torch.bfloat16 the bf16-MFMA kernels.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+from .hip import (ACT_GELU, ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU,  # noqa: F401
+                  EPI_PLAIN, EPI_SFT, PGT_BF16, PGT_F32)
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return PGT_F32
+    if t.dtype == torch.bfloat16:
+        return PGT_BF16
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise hip.PgtError("pgtformer_amd ops run on the GPU only (tensor is on %s); no CPU fallback" % t.device)
+    return t
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(_dev(t).data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ld_img(x):
+    """pixel stride of an (N,H,W,C) view; validates that N,H,W are densely packed over that stride."""
+    n, h, w, c = x.shape
+    assert c == 1 or x.stride(3) == 1, "channel dim must be contiguous"
+    if w > 1:
+        ld = x.stride(2)
+    elif h > 1:
+        ld = x.stride(1)
+    elif n > 1:
+        ld = x.stride(0)
+    else:
+        ld = c
+    assert ld >= c, (x.shape, x.stride())
+    assert h == 1 or x.stride(1) == w * ld, f"rows not dense: {x.stride()} {tuple(x.shape)}"
+    assert n == 1 or x.stride(0) == h * w * ld, f"images not dense: {x.stride()} {tuple(x.shape)}"
+    return ld
+
+
+def _ld_rows(x):
+    assert x.dim() == 2 and (x.stride(1) == 1 or x.shape[1] == 1)
+    return x.stride(0) if x.shape[0] > 1 else max(x.shape[1], x.stride(0))
+
+
+def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
+           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0)):
+    """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
+    sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout)."""
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    assert w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
+    assert w.dtype == x.dtype and w.is_contiguous()
+    hv, wv = (h * 2, wd * 2) if ups else (h, wd)
+    ho = (hv + pad[0] + pad[1] - kh) // stride + 1
+    wo = (wv + pad[2] + pad[3] - kw) // stride + 1
+    if out is None:
+        out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    assert tuple(out.shape) == (n, ho, wo, cout), (out.shape, (n, ho, wo, cout))
+    d = hip.ConvDesc()
+    d.dtype = _dt(x)
+    d.N, d.H, d.W, d.Cin, d.ldx, d.ups = n, h, wd, cin, _ld_img(x), int(ups)
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l = kh, kw, stride, pad[0], pad[2]
+    d.Ho, d.Wo, d.Cout, d.ldy = ho, wo, cout, _ld_img(out)
+    d.act, d.post_relu = act, int(post_relu)
+    d.ldr = _ld_img(res) if res is not None else 0
+    d.out_f32 = int(out_f32)
+    d.force_bm, d.force_bn = tile
+    dec = shift = None
+    if sft is not None:
+        dec, shift, sw = sft
+        d.epi, d.ld_dec, d.ld_shift, d.sft_w = EPI_SFT, _ld_img(dec), _ld_img(shift), float(sw)
+        assert dec.dtype == x.dtype and shift.dtype == x.dtype
+    if res is not None:
+        assert res.dtype == x.dtype and tuple(res.shape) == tuple(out.shape)
+    hip.check(hip.lib().pgt_conv2d(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out),
+                                   _stream()), "pgt_conv2d")
+    return out
+
+
+def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False):
+    """x: (rows, Cin) -> (rows, Cout)."""
+    rows, cin = x.shape
+    x4 = x.as_strided((1, 1, rows, cin), (0, 0, _ld_rows(x), 1))
+    if out is None:
+        out = torch.empty((rows, w.shape[0]), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    o4 = out.as_strided((1, 1, rows, w.shape[0]), (0, 0, _ld_rows(out), 1))
+    r4 = None if res is None else res.as_strided((1, 1, rows, w.shape[0]), (0, 0, _ld_rows(res), 1))
+    conv2d(x4, w, bias, act=act, res=r4, out=o4, out_f32=out_f32)
+    return out
+
+
+def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6):
+    """GroupNorm statistics of x (N,H,W,C) folded with gamma/beta -> (scale, shift) fp32 (N,C)."""
+    n, h, w, c = x.shape
+    L = hip.lib()
+    nbytes = L.pgt_groupnorm_workspace_bytes(n, h * w, c, groups)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    shift = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    hip.check(L.pgt_groupnorm_affine(_dt(x), _p(x), _ld_img(x), n, h * w, c, groups, eps, _p(gamma), _p(beta),
+                                     _p(scale), _p(shift), _p(ws), nbytes, _stream()), "pgt_groupnorm_affine")
+    return scale, shift
+
+
+def affine_act(x, scale, shift, act=ACT_NONE, out=None):
+    """y = act(x*scale[n,c] + shift[n,c]); x (N,H,W,C)."""
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, h, w, c), device=x.device, dtype=x.dtype)
+    hip.check(hip.lib().pgt_affine_act(_dt(x), _p(x), _ld_img(x), _p(out), _ld_img(out), n, h * w, c, _p(scale),
+                                       _p(shift), act, _stream()), "pgt_affine_act")
+    return out
+
+
+def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6):
+    scale, shift = groupnorm_affine(x, gamma, beta, groups, eps)
+    return affine_act(x, scale, shift, act)
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pos=None):
+    """x (rows,C). Returns LN(x), or (LN(x), LN(x)+pos) when pos is given."""
+    rows, c = x.shape
+    y = torch.empty((rows, c), device=x.device, dtype=x.dtype)
+    y2 = torch.empty((rows, c), device=x.device, dtype=x.dtype) if pos is not None else None
+    hip.check(hip.lib().pgt_layernorm(_dt(x), _p(x), _ld_rows(x), rows, c, _p(gamma), _p(beta), eps, _p(y), c,
+                                      _p(pos), _ld_rows(pos) if pos is not None else 0, _p(y2), c, _stream()),
+              "pgt_layernorm")
+    return y if pos is None else (y, y2)
+
+
+def channel_stats(x, want_var=True):
+    """per-(n,c) mean and unbiased variance over pixels of x (N,H,W,C) -> fp32 (N,C)."""
+    n, h, w, c = x.shape
+    mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    var = torch.empty((n, c), dtype=torch.float32, device=x.device) if want_var else None
+    hip.check(hip.lib().pgt_channel_stats(_dt(x), _p(x), _ld_img(x), n, h * w, c, _p(mean), _p(var), _stream()),
+              "pgt_channel_stats")
+    return mean, var
+
+
+def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):
+    scale = torch.empty_like(mean_c)
+    shift = torch.empty_like(mean_c)
+    hip.check(hip.lib().pgt_adain_affine(_p(mean_c), _p(var_c), _p(mean_s), _p(var_s), eps, _p(scale), _p(shift),
+                                         mean_c.numel(), _stream()), "pgt_adain_affine")
+    return scale, shift
+
+
+def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift):
+    """qkv (B*T*H*W, 3C) -> (B*T*H*W, C)."""
+    rows = B * T * H * W
+    assert tuple(qkv.shape) == (rows, 3 * C_)
+    out = torch.empty((rows, C_), device=qkv.device, dtype=qkv.dtype)
+    hip.check(hip.lib().pgt_window_attention(_dt(qkv), _p(qkv), _ld_rows(qkv), _p(out), C_, _p(bias), B, T, H, W,
+                                             C_, heads, win[0], win[1], shift[0], shift[1], _stream()),
+              "pgt_window_attention")
+    return out
+
+
+def mha(q, k, v, B, L, heads, hd, scale):
+    """q,k,v (B*L, heads*hd) views -> (B*L, heads*hd)."""
+    out = torch.empty((B * L, heads * hd), device=q.device, dtype=q.dtype)
+    hip.check(hip.lib().pgt_mha(_dt(q), _p(q), _ld_rows(q), _p(k), _ld_rows(k), _p(v), _ld_rows(v), _p(out),
+                                heads * hd, B, L, heads, hd, scale, _stream()), "pgt_mha")
+    return out
+
+
+def argmax_rows(logits):
+    rows, k = logits.shape
+    assert logits.dtype == torch.float32
+    codes = torch.empty((rows,), dtype=torch.int32, device=logits.device)
+    hip.check(hip.lib().pgt_argmax_rows(_p(logits), _ld_rows(logits), rows, k, _p(codes), _stream()),
+              "pgt_argmax_rows")
+    return codes
+
+
+def rq_argmin(dot, xnorm, enorm):
+    rows, k = dot.shape
+    codes = torch.empty((rows,), dtype=torch.int32, device=dot.device)
+    hip.check(hip.lib().pgt_rq_argmin(_p(dot), _ld_rows(dot), _p(xnorm), _p(enorm), rows, k, _p(codes), _stream()),
+              "pgt_rq_argmin")
+    return codes
+
+
+def embed_rows(codebook, codes, dtype, out=None, accumulate=False, resid=None):
+    rows, d = codes.numel(), codebook.shape[1]
+    if out is None:
+        out = torch.empty((rows, d), device=codes.device, dtype=dtype)
+    hip.check(hip.lib().pgt_embed_rows(_dt(out), _p(codebook), d, _p(codes), rows, _p(out), _ld_rows(out),
+                                       int(accumulate), _p(resid), _ld_rows(resid) if resid is not None else 0,
+                                       _stream()), "pgt_embed_rows")
+    return out
+
+
+def row_sumsq(x):
+    rows, c = x.shape
+    out = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().pgt_row_sumsq(_dt(x), _p(x), _ld_rows(x), rows, c, _p(out), _stream()), "pgt_row_sumsq")
+    return out
+
+
+def maxpool3x3s2(x):
+    n, h, w, c = x.shape
+    assert x.is_contiguous()
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=x.device, dtype=x.dtype)
+    hip.check(hip.lib().pgt_maxpool3x3s2(_dt(x), _p(x), n, h, w, c, _p(out), _stream()), "pgt_maxpool3x3s2")
+    return out
+
+
+def gate_add(x, gate=None, addvec=None, addt=None, out=None):
+    """y = x*gate[n,c] + addvec[n,c] + addt; x (N,H,W,C), gate/addvec (N,C) of x.dtype."""
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, h, w, c), device=x.device, dtype=x.dtype)
+    for t in (gate, addvec):
+        assert t is None or (t.dtype == x.dtype and t.is_contiguous() and t.numel() == n * c)
+    hip.check(hip.lib().pgt_gate_add(_dt(x), _p(x), _ld_img(x), n, h * w, c, _p(gate), _p(addvec), _p(addt),
+                                     _ld_img(addt) if addt is not None else 0, _p(out), _ld_img(out), _stream()),
+              "pgt_gate_add")
+    return out
+
+
+def resize_bilinear_ac(x, ho, wo, out=None):
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty((n, ho, wo, c), device=x.device, dtype=x.dtype)
+    hip.check(hip.lib().pgt_resize_bilinear_ac(_dt(x), _p(x), _ld_img(x), n, h, w, c, _p(out), _ld_img(out), ho, wo,
+                                               _stream()), "pgt_resize_bilinear_ac")
+    return out
+
+
+def copy_into(src, dst):
+    """dst[...] = src with dtype conversion; both (..., C) views with the same leading shape, dense rows."""
+    c = src.shape[-1]
+    rows = src.numel() // c
+    lds = _ld_img(src) if src.dim() == 4 else _ld_rows(src)
+    ldd = _ld_img(dst) if dst.dim() == 4 else _ld_rows(dst)
+    assert dst.shape == src.shape
+    hip.check(hip.lib().pgt_copy2d(_dt(src), _p(src), lds, _dt(dst), _p(dst), ldd, rows, c, _stream()), "pgt_copy2d")
+    return dst
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    return copy_into(x, out)
+
+
+def prep_input(src, dtype, want_raw=True, want_norm=True):
+    """src: uint8 (N,H,W,3) or float32 (N,3,H,W) -> raw, norm as (N,H,W,8) channel-padded tensors."""
+    if src.dtype == torch.uint8:
+        n, h, w, _ = src.shape
+        kind = 0
+    else:
+        assert src.dtype == torch.float32
+        n, _, h, w = src.shape
+        kind = 1
+    assert src.is_contiguous()
+    raw = torch.empty((n, h, w, 8), device=src.device, dtype=dtype) if want_raw else None
+    norm = torch.empty((n, h, w, 8), device=src.device, dtype=dtype) if want_norm else None
+    ref = raw if raw is not None else norm
+    hip.check(hip.lib().pgt_prep_input(_dt(ref), _p(src), kind, n, h, w, _p(raw), _p(norm), _stream()),
+              "pgt_prep_input")
+    return raw, norm
+
+
+def nhwc_to_nchw_f32(x):
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    hip.check(hip.lib().pgt_nhwc_to_nchw_f32(_dt(x), _p(x), _ld_img(x), n, h, w, c, _p(out), _stream()),
+              "pgt_nhwc_to_nchw_f32")
+    return out
+
+
+def frame_to_u8(x):
+    """x (H,W,3) activation view -> uint8 (H,W,3): floor(clamp(x,0,1)*255)."""
+    h, w, c = x.shape
+    assert c == 3
+    out = torch.empty((h, w, 3), device=x.device, dtype=torch.uint8)
+    hip.check(hip.lib().pgt_frame_to_u8(_dt(x), _p(x), x.stride(1), h, w, _p(out), _stream()), "pgt_frame_to_u8")
+    return out

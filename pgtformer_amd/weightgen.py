@@ -69,6 +69,8 @@ def generate_tensor(name, shape, dtype, cfg, seed=0):
         return (0.2 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
     if name.startswith("quantizer.codebooks."):
         base = name.rsplit(".", 1)[0] + ".weight"
+        if cfg.get("shared_codebook", False):
+            base = "quantizer.codebooks.0.weight"
         if leaf == "cluster_size_ema":
             return np.zeros(shape, np.float32)
         gw = _rng(base, seed)

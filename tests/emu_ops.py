@@ -1,0 +1,234 @@
+"""TEST INFRASTRUCTURE: torch-CPU emulation of the operator contracts of `pgtformer_amd.ops`.
+
+Used only by tests: (a) on CPU, monkeypatched over `pgtformer_amd.ops` to check the HOST logic (module
+graph, weight repack, channels-last index math) of the product against the oracle without a GPU;
+(b) on the GPU box, as the per-operator expected value for the HIP kernels at arbitrary shapes.
+It is never imported by the package; the product has no CPU path.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_LEAKY02, ACT_SIGMOID = range(6)
+
+
+def _act(v, act):
+    if act == ACT_RELU:
+        return F.relu(v)
+    if act == ACT_GELU:
+        return F.gelu(v)
+    if act == ACT_SILU:
+        return F.silu(v)
+    if act == ACT_LEAKY02:
+        return F.leaky_relu(v, 0.2)
+    if act == ACT_SIGMOID:
+        return torch.sigmoid(v)
+    return v
+
+
+def _store(val, out, dtype):
+    if out is None:
+        return val.to(dtype).contiguous()
+    out.copy_(val.to(out.dtype))
+    return out
+
+
+def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
+           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0)):
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    assert w.shape[1] == kh * kw * cin and w.dtype == x.dtype
+    xi = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    xi = F.pad(xi, (pad[2], pad[3], pad[0], pad[1]))
+    wt = w.float().reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
+    y = F.conv2d(xi, wt, bias.float() if bias is not None else None, stride=stride).permute(0, 2, 3, 1)
+    y = _act(y, act)
+    if sft is not None:
+        dec, shift, sw = sft
+        y = dec.float() + sw * (dec.float() * y + shift.float())
+    else:
+        if res is not None:
+            y = y + res.float()
+        if post_relu:
+            y = F.relu(y)
+    return _store(y, out, torch.float32 if out_f32 else x.dtype)
+
+
+def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False):
+    y = _act(F.linear(x.float(), w.float(), bias.float() if bias is not None else None), act)
+    if res is not None:
+        y = y + res.float()
+    return _store(y, out, torch.float32 if out_f32 else x.dtype)
+
+
+def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6):
+    n, h, w, c = x.shape
+    xf = x.float().reshape(n, h * w, groups, c // groups)
+    mean = xf.mean(dim=(1, 3))
+    var = xf.var(dim=(1, 3), unbiased=False)
+    rstd = (var + eps).rsqrt()
+    rs = rstd.repeat_interleave(c // groups, 1)
+    mu = mean.repeat_interleave(c // groups, 1)
+    scale = rs * gamma
+    shift = beta - mu * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def affine_act(x, scale, shift, act=ACT_NONE, out=None):
+    n = x.shape[0]
+    y = _act(x.float() * scale.reshape(n, 1, 1, -1) + shift.reshape(n, 1, 1, -1), act)
+    return _store(y, out, x.dtype)
+
+
+def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6):
+    s, b = groupnorm_affine(x, gamma, beta, groups, eps)
+    return affine_act(x, s, b, act)
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pos=None):
+    y = F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps)
+    if pos is None:
+        return y.to(x.dtype)
+    return y.to(x.dtype), (y + pos.float()).to(x.dtype)
+
+
+def channel_stats(x, want_var=True):
+    n, h, w, c = x.shape
+    xf = x.float().reshape(n, h * w, c)
+    return xf.mean(1).contiguous(), (xf.var(1, unbiased=True).contiguous() if want_var else None)
+
+
+def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):
+    scale = (var_s + eps).sqrt() / (var_c + eps).sqrt()
+    return scale, mean_s - mean_c * scale
+
+
+def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift):
+    """Independent formulation: roll / partition with torch ops, dense mask from region labels."""
+    wh, ww = win
+    sh, sw = shift
+    hd = C_ // heads
+    x = qkv.float().reshape(B, T, H, W, 3 * C_)
+    if sh or sw:
+        x = torch.roll(x, shifts=(-sh, -sw), dims=(2, 3))
+    xw = x.reshape(B, T, H // wh, wh, W // ww, ww, 3 * C_).permute(0, 2, 4, 1, 3, 5, 6)
+    nW = (H // wh) * (W // ww)
+    N = T * wh * ww
+    xw = xw.reshape(B * nW, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = xw[0] * (hd ** -0.5), xw[1], xw[2]
+    attn = q @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if sh or sw:
+        img = torch.zeros(1, T, H, W, 1)
+        cnt = 0
+        for hs in (slice(0, -wh), slice(-wh, -sh), slice(-sh, None)):
+            for ws_ in (slice(0, -ww), slice(-ww, -sw), slice(-sw, None)):
+                img[:, :, hs, ws_, :] = cnt
+                cnt += 1
+        mw = img.reshape(1, T, H // wh, wh, W // ww, ww, 1).permute(0, 2, 4, 1, 3, 5, 6).reshape(nW, N)
+        am = mw.unsqueeze(1) - mw.unsqueeze(2)
+        am = torch.where(am != 0, torch.full_like(am, -100.0), torch.zeros_like(am))
+        attn = (attn.reshape(B, nW, heads, N, N) + am.unsqueeze(1).unsqueeze(0)).reshape(-1, heads, N, N)
+    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(B, H // wh, W // ww, T, wh, ww, C_)
+    o = o.permute(0, 3, 1, 4, 2, 5, 6).reshape(B, T, H, W, C_)
+    if sh or sw:
+        o = torch.roll(o, shifts=(sh, sw), dims=(2, 3))
+    return o.reshape(B * T * H * W, C_).to(qkv.dtype)
+
+
+def mha(q, k, v, B, L, heads, hd, scale):
+    def split(t):
+        return t.float().reshape(B, L, heads, hd).permute(0, 2, 1, 3)
+    attn = ((split(q) * scale) @ split(k).transpose(-2, -1)).softmax(-1)
+    return (attn @ split(v)).permute(0, 2, 1, 3).reshape(B * L, heads * hd).to(q.dtype)
+
+
+def argmax_rows(logits):
+    return logits.argmax(-1).to(torch.int32)
+
+
+def rq_argmin(dot, xnorm, enorm):
+    return ((xnorm.unsqueeze(1) + enorm.unsqueeze(0)) - 2.0 * dot).argmin(-1).to(torch.int32)
+
+
+def embed_rows(codebook, codes, dtype, out=None, accumulate=False, resid=None):
+    e = codebook[codes.long()]
+    if out is None:
+        out = torch.zeros((codes.numel(), codebook.shape[1]), dtype=dtype)
+        accumulate = False
+    out.copy_(((out.float() if accumulate else 0) + e).to(out.dtype))
+    if resid is not None:
+        resid.copy_((resid.float() - e).to(resid.dtype))
+    return out
+
+
+def row_sumsq(x):
+    return x.float().pow(2).sum(1)
+
+
+def maxpool3x3s2(x):
+    return F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).to(x.dtype).contiguous()
+
+
+def gate_add(x, gate=None, addvec=None, addt=None, out=None):
+    n, c = x.shape[0], x.shape[3]
+    y = x.float()
+    if gate is not None:
+        y = y * gate.float().reshape(n, 1, 1, c)
+    if addvec is not None:
+        y = y + addvec.float().reshape(n, 1, 1, c)
+    if addt is not None:
+        y = y + addt.float()
+    return _store(y, out, x.dtype)
+
+
+def resize_bilinear_ac(x, ho, wo, out=None):
+    y = F.interpolate(x.float().permute(0, 3, 1, 2), (ho, wo), mode="bilinear", align_corners=True)
+    return _store(y.permute(0, 2, 3, 1), out, x.dtype)
+
+
+def copy_into(src, dst):
+    dst.copy_(src.to(dst.dtype))
+    return dst
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else x.to(dtype)
+
+
+def prep_input(src, dtype, want_raw=True, want_norm=True):
+    if src.dtype == torch.uint8:
+        r = src.float() / 255.0
+    else:
+        r = src.permute(0, 2, 3, 1)
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    std = torch.tensor([0.229, 0.224, 0.225])
+    nn_ = (r - mean) / std
+    pad = lambda t: F.pad(t, (0, 5)).to(dtype).contiguous()  # noqa: E731
+    return (pad(r) if want_raw else None), (pad(nn_) if want_norm else None)
+
+
+def nhwc_to_nchw_f32(x):
+    return x.float().permute(0, 3, 1, 2).contiguous()
+
+
+def frame_to_u8(x):
+    return (x.float().clamp(0, 1) * 255).to(torch.uint8)
+
+
+ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "layernorm", "channel_stats",
+       "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
+       "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
+       "frame_to_u8"]
+
+
+def install(monkeypatch):
+    """Replace every operator of pgtformer_amd.ops by its CPU emulation (tests only)."""
+    import sys
+
+    import pgtformer_amd.ops as real
+    me = sys.modules[__name__]
+    for name in ALL:
+        monkeypatch.setattr(real, name, getattr(me, name))

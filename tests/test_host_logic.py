@@ -1,0 +1,92 @@
+"""Host logic of the product (module graph, weight repack, channels-last index math, precision plumbing)
+checked on CPU: `pgtformer_amd.ops` is monkeypatched with the torch-CPU operator emulation of
+tests/emu_ops.py (test infrastructure) and the result is compared with the reference-derived goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import emu_ops
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def cpu_model(cfg, full_sd):
+    from pgtformer_amd import PGTFormer
+
+    m = PGTFormer(**cfg)
+    missing = m.load_state_dict(full_sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m.prepare("cpu", "fp32")
+    return m
+
+
+def test_state_dict_is_reference_compatible(cfg, manifest):
+    from pgtformer_amd import PGTFormer
+
+    m = PGTFormer(**cfg)
+    sd = m.state_dict()
+    assert list(sd) == list(manifest)
+    for k, v in sd.items():
+        assert tuple(v.shape) == manifest[k][0], k
+        assert str(v.dtype).replace("torch.", "") == manifest[k][1], k
+    assert m.eval() is m
+
+
+def test_registry_surface(cfg):
+    from pgtformer_amd import ARCH_REGISTRY
+    from pgtformer_amd.registry import build_network
+    import pgtformer_amd.archs.pgtformer_arch  # noqa: F401  (registers)
+
+    assert "PGTFormer" in ARCH_REGISTRY and "TDCRQVAE3" in ARCH_REGISTRY
+    opt = dict(cfg)
+    opt["type"] = "PGTFormer"
+    net = build_network(opt)
+    assert type(net).__name__ == "PGTFormer"
+    with pytest.raises(KeyError):
+        ARCH_REGISTRY.get("NoSuchArch")
+
+
+def test_product_refuses_to_run_without_gpu(cpu_model, golden_window):
+    """No CPU fallback: un-patched ops must fail loudly on CPU tensors."""
+    from pgtformer_amd import hip
+
+    x, _, _ = golden_window
+    with pytest.raises((hip.PgtError, RuntimeError, OSError)):
+        cpu_model(x)
+
+
+@pytest.mark.slow
+def test_whole_model_host_logic_matches_reference(cpu_model, golden_window, monkeypatch):
+    emu_ops.install(monkeypatch)
+    g = np.load(os.path.join(GOLD, "full_golden.npz"))
+    x, win_u8, _ = golden_window
+    out, logits, lq = cpu_model(x, w=1.0)
+    assert out.shape == (3, 3, 512, 512) and out.dtype == torch.float32
+    assert logits.shape == (3, 32, 32, 1, 1024) and lq.shape == (3, 32, 32, 512)
+    codes = cpu_model.last_codes.reshape(3, 32, 32, 1).numpy().astype(np.int16)
+    agree = (codes == g["codes"]).mean()
+    assert agree == 1.0, f"code agreement {agree}"
+    assert np.abs(lq[:, 12:20, 12:20, :].numpy() - g["lq_feat_crop"]).max() < 2e-4
+    assert np.abs(logits[:, :2, :2].numpy() - g["logits_tok0"]).max() < 2e-3
+    crop = out[1, :, 192:320, 192:320].numpy()
+    err = np.abs(crop - g["out_mid_crop"]).max()
+    assert err < 5e-3, err
+    # uint8 ingest path gives the same result as the float path (x is win_u8/255)
+    out_u8 = cpu_model.restore_middle_u8(torch.from_numpy(win_u8), w=1.0)
+    want = (out[1].clamp(0, 1).permute(1, 2, 0) * 255).to(torch.uint8)
+    assert (out_u8.int() - want.int()).abs().max() <= 1
+
+
+@pytest.mark.slow
+def test_stage1_host_logic_matches_reference(cpu_model, golden_window, monkeypatch):
+    from pgtformer_amd.archs.tdcrqvae3_arch import TDCRQVAE3
+
+    emu_ops.install(monkeypatch)
+    g = np.load(os.path.join(GOLD, "full_golden.npz"))
+    x, _, _ = golden_window
+    out, _, codes = TDCRQVAE3.forward(cpu_model, x)
+    assert (codes.numpy().astype(np.int16) == g["stage1_codes"]).mean() == 1.0
+    assert np.abs(out[1, :, 192:320, 192:320].numpy() - g["stage1_out_mid_crop"]).max() < 5e-3
