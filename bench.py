@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""Headline benchmark: restored 512x512 frames/s of the PGTFormer forward path on MI355X.
+
+One "step" = one 3-frame-window forward = one restored frame (reference driver semantics,
+inference.py:12-19, 38-74).  Workload = BASELINE.json configs[1]: pgtformer-base, synthetic degraded
+512x512 clip, 3-frame window, bf16 activations (fp32 accumulate), random-init weights of the exact
+architecture (no checkpoint / network here).  The clip is resident in HBM as uint8 before the timed
+region; each step gathers its window on-device, replays the captured HIP graph of the whole forward
+(uint8 in -> uint8 restored middle frame out) and stores the frame.
+
+N>1: one process per GPU (torchrun), the clip is sharded by output-frame range, ranks exchange the
+1-frame halos with ONE all_gather (RCCL over xGMI) inside the timed region; weak scaling (each rank
+restores `steps` frames).  value = frames restored by all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the `roofline` (dominant kernel: the MFMA implicit-GEMM conv,
+measured live with events on the launch stream in a separate instrumented eager pass) and
+`cpu_baseline` (the CPU oracle = a port of the reference's fp32 eager path, timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "mixed": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "mixed", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def live_roofline(model, window, precision):
+    """Instrumented eager pass: every implicit-GEMM launch bracketed by events on its launch stream."""
+    from pgtformer_amd import ops
+    model.restore_middle_u8(window, w=1.0)      # warm
+    torch.cuda.synchronize()
+    recs = []
+    ops.PROFILE = recs
+    try:
+        model.restore_middle_u8(window, w=1.0)
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILE = None
+    t_ms = sum(r["events"][0].elapsed_time(r["events"][1]) for r in recs)
+    flops = sum(r["flops"] for r in recs)
+    byts = sum(r["bytes"] for r in recs)
+    n = len(recs)
+    achieved = flops / (t_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[precision]
+    top = sorted(recs, key=lambda r: -r["events"][0].elapsed_time(r["events"][1]))[:5]
+    return {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear)", "achieved": round(achieved, 2),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "launches_per_window": n, "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3),
+            "avg_launch_us": round(t_ms * 1e3 / n, 2), "algorithmic_gb_per_window": round(byts / 1e9, 3),
+            "igemm_ms_per_window": round(t_ms, 3),
+            "slowest_launches": [{"shape_NHWCinCoutKSU": list(r["shape"]),
+                                  "us": round(r["events"][0].elapsed_time(r["events"][1]) * 1e3, 1),
+                                  "tflops": round(r["flops"] / (r["events"][0].elapsed_time(r["events"][1]) * 1e-3) / 1e12, 1)}
+                                 for r in top]}
+
+
+def cpu_baseline(cfg, sd, window_u8):
+    from oracle import pgt_oracle as O      # reported CPU baseline only (never on the product path)
+    x = torch.from_numpy(window_u8.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    t0 = time.time()
+    O.pgtformer_forward(sd, cfg, x, w=1.0)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 window (3x512x512 in -> 1 restored frame), fp32 eager torch-CPU oracle, cold",
+            "seconds_per_window": round(dt, 2), "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from pgtformer_amd import PGTFormer, default_config, parallel
+    from pgtformer_amd.driver import WindowRunner
+    from pgtformer_amd.manifest import pgtformer_manifest
+    from pgtformer_amd.synth import make_clip
+    from pgtformer_amd.weightgen import generate_state_dict
+
+    cfg = default_config()
+    sd = generate_state_dict(pgtformer_manifest(cfg), cfg, seed=0)
+    model = PGTFormer(**cfg)
+    model.load_state_dict(sd, strict=True)
+    model.prepare(dev, args.precision)
+
+    # this rank's slice of the synthetic clip (weak scaling: `steps` frames per rank), resident in HBM
+    n_local = args.steps
+    lq_u8, _ = make_clip(min(n_local, 8), 512, seed=1234 + rank)
+    reps = (n_local + lq_u8.shape[0] - 1) // lq_u8.shape[0]
+    local = torch.from_numpy(np.concatenate([lq_u8] * reps, 0)[:n_local]).to(dev)
+    out = torch.empty_like(local)
+    runner = WindowRunner(model, 1.0, not args.no_graph, 512, 512)
+
+    def one_pass(n):
+        padded = parallel.padded_local_clip(local[:n] if n < n_local else local, rank, world)
+        for j in range(n):
+            out[j].copy_(runner.run(padded[j:j + 3]))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    one_pass(max(1, min(args.warmup, n_local)))
+    fence()
+    t0 = time.perf_counter()
+    one_pass(n_local)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    res = {"metric": "restored 512x512 frames/sec", "value": round(n_local * world / dt, 3), "unit": "frames/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / n_local * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": {"bf16": "bf16", "mixed": "bf16 (decoder) / f32 (code branch)", "fp32": "f32"}[args.precision],
+           "data": "synthetic",
+           "config": {"workload": "pgtformer-base, 3-frame 512x512 window -> 1 restored frame, synthetic degraded "
+                                  "VFHQ-shape clip, random-init weights (BASELINE.json configs[1])",
+                      "precision": args.precision, "frames_per_rank": n_local, "hip_graph": not args.no_graph,
+                      "parallelism": f"frame-range shard x{world}, 1 all_gather of boundary frames"}}
+    if rank == 0:
+        if not args.no_roofline:
+            res["roofline"] = live_roofline(model, local[:3].contiguous(), args.precision)
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, lq_u8[:3] if lq_u8.shape[0] >= 3 else np.repeat(lq_u8[:1], 3, 0))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,11 @@ from .hip import (ACT_GELU, ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SI
                   EPI_PLAIN, EPI_SFT, PGT_BF16, PGT_F32)
 
 
+# When set to a list, conv2d brackets each launch with events on the launch stream and appends
+# {"kernel", "flops", "bytes", "shape", "events"} records (bench.py's live roofline measurement).
+PROFILE = None
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return PGT_F32
@@ -89,8 +94,20 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         assert dec.dtype == x.dtype and shift.dtype == x.dtype
     if res is not None:
         assert res.dtype == x.dtype and tuple(res.shape) == tuple(out.shape)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     hip.check(hip.lib().pgt_conv2d(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out),
                                    _stream()), "pgt_conv2d")
+    if prof is not None:
+        e1.record()
+        m = n * ho * wo
+        es = x.element_size()
+        prof.append({"kernel": "igemm", "flops": 2.0 * m * cout * kh * kw * cin,
+                     "bytes": float(n * h * wd * cin * es + m * cout * out.element_size() + w.numel() * es
+                                    + (m * cout * es if res is not None else 0)),
+                     "shape": (n, h, wd, cin, cout, kh, stride, int(ups)), "events": (e0, e1)})
     return out
 
 

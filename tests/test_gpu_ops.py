@@ -1,0 +1,291 @@
+"""GPU parity tests, operator level: every HIP kernel (called through the C-ABI via pgtformer_amd.ops)
+against the torch-CPU operator emulation (tests/emu_ops.py) on the same seeded inputs, in f32 (exact
+MFMA, tight tolerance) and bf16 (bf16 MFMA, fp32 accumulate).  Each comparison is also logged to
+gpurun_out/parity_ops.json.
+
+Tolerances (written here, per the parity contract):
+  f32 : max|got-want| <= 2e-4 * max(1, max|want|)     (fp32 accumulation-order differences)
+  bf16: max|got-want| <= 4e-2 * max(1, max|want|)     (inputs/outputs rounded to bf16, 8-bit mantissa)
+  integer results (codes, u8 frames): bit-exact (u8: +-1 allowed only where noted)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import emu_ops as E
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+_LOG = []
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_log():
+    yield
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_ops.json", "w") as f:
+        json.dump(_LOG, f, indent=1)
+
+
+def ops():
+    import pgtformer_amd.ops as O
+    return O
+
+
+def rnd(shape, seed, dtype=torch.float32, scale=1.0):
+    g = np.random.default_rng(seed)
+    t = torch.from_numpy((scale * g.standard_normal(shape)).astype(np.float32))
+    return t.to(dtype)
+
+
+def check(name, got, want, dtype, tol_scale=1.0):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    ref = max(1.0, want.abs().max().item())
+    tol = TOL[dtype] * tol_scale * ref
+    _LOG.append({"name": name, "dtype": str(dtype), "max_abs_err": err, "ref_absmax": ref, "tol": tol,
+                 "ok": bool(err <= tol)})
+    assert np.isfinite(err) and err <= tol, f"{name}: max err {err:.3e} > tol {tol:.3e}"
+
+
+def g(t):
+    return None if t is None else t.to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [(0, 0), (64, 64), (64, 128), (128, 64), (128, 128)])
+def test_linear_asymmetric_all_tiles(dtype, tile):
+    """GEMM with ragged M, N, K and an asymmetric weight: catches operand/accumulator layout swaps."""
+    m, k, n = 200, 72, 150
+    x = rnd((m, k), 1, dtype)
+    w = rnd((n, k), 2, dtype, 0.2)
+    w[:, 0] += torch.arange(n, dtype=torch.float32).to(dtype) * 0.01   # asymmetric in n
+    b = rnd((n,), 3)
+    res = rnd((m, n), 4, dtype)
+    want = E.linear(x, w, b, act=E.ACT_GELU, res=res)
+    x4 = g(x).reshape(1, 1, m, k)
+    got = ops().conv2d(x4, g(w), g(b), act=E.ACT_GELU, res=g(res).reshape(1, 1, m, n), tile=tile)
+    check(f"linear_tile{tile}", got.reshape(m, n), want, dtype)
+
+
+CONV_CASES = [
+    # name, N,H,W,Cin,Cout,k,stride,pad4,ups
+    ("c3x3_s1", 2, 13, 11, 32, 48, 3, 1, (1, 1, 1, 1), False),
+    ("c3x3_s2_asym", 3, 16, 16, 64, 64, 3, 2, (0, 1, 0, 1), False),
+    ("c3x3_ups", 2, 6, 5, 128, 128, 3, 1, (1, 1, 1, 1), True),
+    ("c7x7_s2_cin8", 1, 32, 32, 8, 64, 7, 2, (3, 3, 3, 3), False),
+    ("c1x1_s2", 2, 12, 12, 64, 128, 1, 2, (0, 0, 0, 0), False),
+    ("c3x3_288_128", 1, 8, 8, 288, 128, 3, 1, (1, 1, 1, 1), False),
+    ("c3x3_cout3", 3, 20, 20, 64, 3, 3, 1, (1, 1, 1, 1), False),
+    ("c3x3_s2_p1", 2, 16, 16, 64, 128, 3, 2, (1, 1, 1, 1), False),
+    ("c3x3_big_m", 3, 64, 64, 64, 64, 3, 1, (1, 1, 1, 1), False),
+    ("c3x3_cin8", 3, 24, 24, 8, 64, 3, 1, (1, 1, 1, 1), False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(dtype, case):
+    name, n, h, w_, cin, cout, k, stride, pad4, ups = case
+    x = rnd((n, h, w_, cin), 10, dtype)
+    wt = rnd((cout, k * k * cin), 11, dtype, 1.0 / np.sqrt(k * k * cin))
+    b = rnd((cout,), 12, torch.float32, 0.1)
+    kw = dict(kh=k, kw=k, stride=stride, pad=pad4, ups=ups)
+    want = E.conv2d(x, wt, b, act=E.ACT_SILU, **kw)
+    got = ops().conv2d(g(x), g(wt), g(b), act=E.ACT_SILU, **kw)
+    check(name, got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_epilogues_and_views(dtype):
+    n, h, w_, c = 2, 10, 9, 64
+    x = rnd((n, h, w_, c), 20, dtype)
+    wt = rnd((c, 9 * c), 21, dtype, 0.04)
+    b = rnd((c,), 22)
+    res = rnd((n, h, w_, c), 23, dtype)
+    kw = dict(kh=3, kw=3, pad=(1, 1, 1, 1))
+    check("res_postrelu", ops().conv2d(g(x), g(wt), g(b), res=g(res), post_relu=True, **kw),
+          E.conv2d(x, wt, b, res=res, post_relu=True, **kw), dtype)
+    dec, shf = rnd((n, h, w_, c), 24, dtype), rnd((n, h, w_, c), 25, dtype)
+    check("sft", ops().conv2d(g(x), g(wt), g(b), sft=(g(dec), g(shf), 0.7), **kw),
+          E.conv2d(x, wt, b, sft=(dec, shf, 0.7), **kw), dtype)
+    check("out_f32", ops().conv2d(g(x), g(wt), g(b), out_f32=True, **kw), E.conv2d(x, wt, b, out_f32=True, **kw), dtype)
+    # channel-sliced input view and channel-sliced output view (concat buffers)
+    wide = rnd((n, h, w_, 2 * c), 26, dtype)
+    wide_d = g(wide)
+    outbuf = torch.zeros((n, h, w_, 3 * c), device=DEV, dtype=dtype)
+    ops().conv2d(wide_d[..., c:], g(wt), g(b), act=E.ACT_LEAKY02, out=outbuf[..., c:2 * c], **kw)
+    want = E.conv2d(wide[..., c:], wt, b, act=E.ACT_LEAKY02, **kw)
+    check("sliced_views", outbuf[..., c:2 * c], want, dtype)
+    assert outbuf[..., :c].abs().max().item() == 0 and outbuf[..., 2 * c:].abs().max().item() == 0
+    # 19-channel output slice at an odd offset (BiSeNet heads)
+    w19 = rnd((19, c), 27, dtype, 0.1)
+    cond = torch.zeros((n, h, w_, 64), device=DEV, dtype=dtype)
+    ops().conv2d(g(x), g(w19), None, out=cond[..., 19:38])
+    check("cout19_slice", cond[..., 19:38], E.conv2d(x, w19, None), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(3, 24, 24, 64), (2, 9, 7, 288), (1, 6, 6, 1056), (3, 16, 16, 512), (3, 5, 5, 544)])
+def test_groupnorm_silu(dtype, shape):
+    x = rnd(shape, 30, dtype) * 1.5 + 0.4
+    x = x.to(dtype)
+    gam, bet = 1 + 0.1 * rnd((shape[3],), 31), 0.1 * rnd((shape[3],), 32)
+    want = E.groupnorm_act(x, gam, bet)
+    got = ops().groupnorm_act(g(x), g(gam), g(bet))
+    check(f"gn_silu{shape}", got, want, dtype)
+    s_w, b_w = E.groupnorm_affine(x, gam, bet)
+    s_g, b_g = ops().groupnorm_affine(g(x), g(gam), g(bet))
+    check(f"gn_scale{shape}", s_g, s_w, torch.float32, 5.0)
+    check(f"gn_shift{shape}", b_g, b_w, torch.float32, 5.0)
+
+
+def test_groupnorm_is_deterministic():
+    x = g(rnd((3, 64, 64, 128), 33))
+    gam, bet = g(torch.ones(128)), g(torch.zeros(128))
+    a = ops().groupnorm_affine(x, gam, bet)
+    b = ops().groupnorm_affine(x, gam, bet)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c", [256, 512])
+def test_layernorm(dtype, c):
+    x = rnd((77, c), 40, dtype) * 2 + 0.3
+    x = x.to(dtype)
+    pos = rnd((77, c), 41, dtype)
+    gam, bet = 1 + 0.1 * rnd((c,), 42), 0.1 * rnd((c,), 43)
+    y_w, y2_w = E.layernorm(x, gam, bet, 1e-5, pos)
+    y_g, y2_g = ops().layernorm(g(x), g(gam), g(bet), 1e-5, g(pos))
+    check(f"ln{c}", y_g, y_w, dtype)
+    check(f"ln_pos{c}", y2_g, y2_w, dtype)
+    check(f"ln_nopos{c}", ops().layernorm(g(x), g(gam), g(bet)), E.layernorm(x, gam, bet), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adain_and_stats(dtype):
+    c_ = (rnd((3, 8, 8, 512), 50, dtype) * 0.3).to(dtype)
+    s_ = (rnd((3, 8, 8, 512), 51, torch.float32) * 2.0 + 0.3)
+    mc, vc = ops().channel_stats(g(c_))
+    mw, vw = E.channel_stats(c_)
+    check("stats_mean", mc, mw, torch.float32, 5.0)
+    check("stats_var", vc, vw, torch.float32, 5.0)
+    from pgtformer_amd.archs.codeformer_arch import adaptive_instance_normalization as adain
+    got = adain(g(c_), g(s_))
+    mm, vv = E.channel_stats(s_)
+    sc, sh = E.adain_affine(mw, vw, mm, vv)
+    check("adain", got, E.affine_act(c_, sc, sh), dtype)
+
+
+WA_CASES = [(1, 3, 8, 12, 256, (4, 4), (0, 0)), (1, 3, 8, 12, 256, (4, 4), (2, 2)), (2, 3, 8, 8, 512, (4, 4), (2, 2)),
+            (1, 3, 16, 16, 256, (4, 4), (2, 2)), (1, 3, 8, 8, 512, (4, 4), (0, 0))]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", WA_CASES)
+def test_window_attention(dtype, case):
+    b, t, h, w_, c, win, shift = case
+    heads = 8
+    n = t * win[0] * win[1]
+    qkv = rnd((b * t * h * w_, 3 * c), 60, dtype)
+    bias = rnd((heads, n, n), 61, torch.float32, 0.5)
+    want = E.window_attention(qkv, bias, b, t, h, w_, c, heads, win, shift)
+    got = ops().window_attention(g(qkv), g(bias), b, t, h, w_, c, heads, win, shift)
+    check(f"winattn{case}", got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("L", [192, 200])
+def test_mha(dtype, L):
+    b, heads, hd = 2, 8, 64
+    e = heads * hd
+    qk = rnd((b * L, 2 * e), 70, dtype)
+    v = rnd((b * L, e), 71, dtype)
+    qk[5, :64] *= 6.0   # a spiky query row: exercises the online-softmax rescale
+    want = E.mha(qk[:, :e], qk[:, e:], v, b, L, heads, hd, 0.125)
+    qk_d = g(qk)
+    got = ops().mha(qk_d[:, :e], qk_d[:, e:], g(v), b, L, heads, hd, 0.125)
+    check(f"mha{L}", got, want, dtype)
+
+
+def test_argmax_argmin_ties_and_embed():
+    logits = rnd((70, 1024), 80)
+    logits[3, 100] = logits[3, 900] = 50.0       # tie -> lowest index (torch rule)
+    logits[4, 1023] = 60.0
+    logits[5, 0] = 60.0
+    got = ops().argmax_rows(g(logits)).cpu()
+    assert torch.equal(got, logits.argmax(-1).to(torch.int32)) and got[3] == 100
+    book = rnd((1025, 512), 81)
+    book[77] = book[5]                              # duplicated code vector -> argmin must return 5
+    book[1024] = 0
+    x = rnd((64, 512), 82, torch.float32, 0.3)
+    x[9] = book[77] + 1e-3
+    for dtype in DTYPES:
+        xd = g(x.to(dtype))
+        bt = g(book[:-1].to(dtype))
+        dot = ops().linear(xd, bt, None, out_f32=True)
+        codes = ops().rq_argmin(dot, ops().row_sumsq(xd), g(book[:-1].pow(2).sum(1))).cpu()
+        want = E.rq_argmin(E.linear(x.to(dtype), book[:-1].to(dtype), None, out_f32=True),
+                           E.row_sumsq(x.to(dtype)), book[:-1].pow(2).sum(1))
+        agree = (codes == want).float().mean().item()
+        _LOG.append({"name": f"rq_argmin_{dtype}", "agree": agree})
+        assert codes[9] == 5
+        assert agree >= (1.0 if dtype == torch.float32 else 0.95)
+        out = ops().embed_rows(g(book), g(want), dtype)
+        check(f"embed_rows_{dtype}", out, book[want.long()], dtype)
+        resid = xd.clone()
+        ops().embed_rows(g(book), g(want), dtype, out=out, accumulate=True, resid=resid)
+        check(f"embed_acc_{dtype}", out, 2 * book[want.long()].to(dtype).float(), dtype)
+        check(f"embed_resid_{dtype}", resid, x.to(dtype).float() - book[want.long()], dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_glue_ops(dtype):
+    x = rnd((2, 17, 16, 64), 90, dtype)
+    check("maxpool", ops().maxpool3x3s2(g(x)), E.maxpool3x3s2(x), dtype)
+    gate, av = rnd((2, 64), 91, dtype), rnd((2, 64), 92, dtype)
+    at = rnd((2, 17, 16, 64), 93, dtype)
+    check("gate_add", ops().gate_add(g(x), gate=g(gate), addvec=g(av), addt=g(at)),
+          E.gate_add(x, gate=gate, addvec=av, addt=at), dtype)
+    y = rnd((2, 64, 64, 19), 94, dtype)
+    buf = torch.zeros((2, 32, 32, 64), device=DEV, dtype=dtype)
+    ops().resize_bilinear_ac(g(y), 32, 32, out=buf[..., 19:38])
+    check("bilinear", buf[..., 19:38], E.resize_bilinear_ac(y, 32, 32), dtype)
+    check("cast", ops().cast(g(x), torch.float32), x.float(), dtype)
+    check("nchw", ops().nhwc_to_nchw_f32(g(x)), E.nhwc_to_nchw_f32(x), dtype)
+
+
+def test_driver_edges():
+    gen = np.random.default_rng(5)
+    u8 = torch.from_numpy(gen.integers(0, 256, (3, 20, 24, 3), dtype=np.uint8))
+    for dtype in DTYPES:
+        raw, norm = ops().prep_input(g(u8), dtype)
+        rw, nw = E.prep_input(u8, dtype)
+        check("prep_raw_u8", raw, rw, dtype, 0.1 if dtype == torch.float32 else 1.0)
+        check("prep_norm_u8", norm, nw, dtype, 0.1 if dtype == torch.float32 else 1.0)
+        xf = (u8.float() / 255).permute(0, 3, 1, 2).contiguous()
+        raw2, _ = ops().prep_input(g(xf), dtype)
+        assert torch.equal(raw2, raw)
+    fr = torch.tensor([-0.2, 0.0, 0.5, 0.999, 1.0, 1.7, 0.25, 0.75]).repeat(6).reshape(4, 4, 3)
+    got = ops().frame_to_u8(g(fr)).cpu()
+    assert torch.equal(got, E.frame_to_u8(fr))
+
+
+def test_errors_are_reported_not_fatal():
+    from pgtformer_amd import hip
+    x = g(rnd((1, 4, 4, 12), 99))      # Cin=12 f32 is fine (multiple of 4); bf16 Cin=12 is not (multiple of 8)
+    w = g(rnd((8, 12), 98))
+    ops().conv2d(x, w)
+    with pytest.raises(hip.PgtError, match="Cin"):
+        ops().conv2d(x.to(torch.bfloat16), w.to(torch.bfloat16))
+    with pytest.raises(hip.PgtError):
+        ops().conv2d(torch.zeros(1, 4, 4, 12), torch.zeros(8, 12))   # CPU tensors: no fallback
