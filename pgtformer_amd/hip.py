@@ -63,6 +63,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise PgtError(f"{LIB_PATH} is missing: build it with `python -m pgtformer_amd.build` "
                            "(there is no fallback path)")
+        # torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's): import torch FIRST so this
+        # library binds to the HIP runtime instance that owns torch's device context and streams.
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)
