@@ -59,6 +59,7 @@ typedef struct pgt_conv_desc {
     float sft_w;
     int32_t out_f32;            /* 1: store y as fp32 even when dtype is bf16 (logits, distances) */
     int32_t force_bm, force_bn; /* 0 = heuristic; 64|128 pins the workgroup tile (tests, tuning)  */
+    int32_t scalar_epilogue;    /* 1: force the element-wise epilogue (A/B tests); 0 = 16-byte path when legal */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,

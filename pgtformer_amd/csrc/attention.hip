@@ -285,6 +285,8 @@ extern "C" int pgt_mha(int32_t dtype, const void* q, int32_t ldq, const void* k,
                        float scale, pgt_stream_t stream) {
     PGT_CHECK(q && k && v && out, "mha: null argument");
     PGT_CHECK(hd == 64 || hd == 32, "mha: head_dim=%d unsupported (32, 64)", hd);
+    if (dtype == PGT_BF16 && hd == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0)
+        return pgt_mha_mfma_bf16(q, ldq, k, ldk, v, ldv, out, ldo, B, L, heads, scale, (hipStream_t)stream);
     const dim3 grid((L + 63) / 64, heads, B), blk(256);
     hipStream_t st = (hipStream_t)stream;
 #define MHA_LAUNCH(TT, HD)                                                                                       \

@@ -1,0 +1,190 @@
+// Flash attention on MFMA for the code-prediction transformer (K8: L=3072, 8 heads, hd=64, bf16).
+//
+// Swapped formulation so that every per-query quantity lives in ONE lane:
+//   S^T = K . Q^T        (v_mfma_f32_32x32x16_bf16: A = K tile rows from LDS, B = Q^T held in registers)
+//   O^T += V^T . P^T     (A = V^T from a transposed LDS image, B = P^T built in registers from S^T)
+// In the 32x32 accumulator layout lane l owns column (l & 31) = one query, so the running max / sum and
+// the rescale factor are per-lane scalars and the only cross-lane traffic per tile is one lane<->lane+32
+// exchange of the tile maximum.  The P^T operand is formed directly from the S^T accumulator
+// registers: accumulator registers 8s..8s+7 of a 32-key block are exactly the 8 keys lane-half h
+// contributes to k-step s if the keys inside each 16-key group are taken in the order
+// {4h..4h+3, 8+4h..8+4h+3}; V^T fragments are read with the same key order (two ds_read_b64), so the
+// contraction is unchanged and P never round-trips through LDS.
+// Workgroup = 4 waves x 32 queries; K/V streamed in 64-key tiles, next tile prefetched into registers
+// while the current one is consumed.
+#include "common.h"
+#include "pgt_internal.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int BKV = 64;
+constexpr int KSTR = 144;   // K tile row stride in bytes (128 + 16 pad): conflict-free ds_read_b128
+constexpr int VSTR = 136;   // V^T row stride in bytes (64 keys * 2 + 8): conflict-free ds_read_b64
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k,
+                                                       int ldk, const uint16_t* __restrict__ v, int ldv,
+                                                       uint16_t* __restrict__ out, int ldo, int L, float c /* scale*log2(e) */) {
+    __shared__ __attribute__((aligned(16))) char smem[BKV * KSTR + HD * VSTR];
+    char* Ks = smem;
+    char* Vt = smem + BKV * KSTR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qi = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const long rowbase = (long)b * L;
+
+    // Q^T fragments (B operand of S^T): 4 k-steps of 16 head-dims, this half's 8 dims each
+    uint4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = make_uint4(0, 0, 0, 0);
+        if (qi < L) qf[s] = *reinterpret_cast<const uint4*>(q + (rowbase + qi) * ldq + head * HD + s * 16 + h * 8);
+    }
+    // staging roles
+    const int k_r0 = tid >> 3, k_cc = tid & 7;      // K: rows k_r0, k_r0+32; 16-byte chunk k_cc
+    const int v_kp = tid >> 3, v_c = tid & 7;       // V: key pair (2kp, 2kp+1), head-dim chunk 8c..8c+7
+    uint4 rk[2], rv[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kj = k0 + k_r0 + 32 * i;
+            rk[i] = make_uint4(0, 0, 0, 0);
+            if (kj < L) rk[i] = *reinterpret_cast<const uint4*>(k + (rowbase + kj) * ldk + head * HD + k_cc * 8);
+            const int vj = k0 + 2 * v_kp + i;
+            rv[i] = make_uint4(0, 0, 0, 0);
+            if (vj < L) rv[i] = *reinterpret_cast<const uint4*>(v + (rowbase + vj) * ldv + head * HD + v_c * 8);
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(Ks + (k_r0 + 32 * i) * KSTR + k_cc * 16) = rk[i];
+        // transpose V: dword = {V[2kp][d], V[2kp+1][d]} -> Vt[d][2kp..2kp+1]
+        const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
+        const uint32_t bb[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = (a[j] & 0xffffu) | (bb[j] << 16);
+            const uint32_t hi = (a[j] >> 16) | (bb[j] & 0xffff0000u);
+            *reinterpret_cast<uint32_t*>(Vt + (v_c * 8 + 2 * j) * VSTR + v_kp * 4) = lo;
+            *reinterpret_cast<uint32_t*>(Vt + (v_c * 8 + 2 * j + 1) * VSTR + v_kp * 4) = hi;
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    const int nt = (L + BKV - 1) / BKV;
+    gload(0);
+    sstore();
+    __syncthreads();
+    const char* k_rd = Ks + (lane & 31) * KSTR + h * 16;
+    const char* v_rd = Vt + (lane & 31) * VSTR + h * 8;
+    for (int t = 0; t < nt; ++t) {
+        const int k0 = t * BKV;
+        const bool more = t + 1 < nt;
+        if (more) gload(k0 + BKV);
+        // ---- S^T = K Q^T : 2 key blocks x 4 k-steps
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const uint4 a = *reinterpret_cast<const uint4*>(k_rd + kb * 32 * KSTR + st * 32);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                __builtin_bit_cast(bf16x8, qf[st]), s[kb], 0, 0, 0);
+            }
+        }
+        if (k0 + BKV > L) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= L) s[kb][e] = -INFINITY;
+        }
+        // ---- online softmax, per lane = per query
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float alpha = exp2f((m - mnew) * c);
+        const float mc = mnew * c;
+        float lsum = 0.f;
+        uint4 pf[2][2];   // P^T B-operands: [key block][k-step]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float p[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                p[e] = exp2f(s[kb][e] * c - mc);
+                lsum += p[e];
+            }
+            pf[kb][0] = make_uint4(pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7]));
+            pf[kb][1] = make_uint4(pack2(p[8], p[9]), pack2(p[10], p[11]), pack2(p[12], p[13]), pack2(p[14], p[15]));
+        }
+        l = l * alpha + lsum;
+        m = mnew;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        // ---- O^T += V^T P^T : 2 head-dim blocks x (2 key blocks x 2 k-steps)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* pa = v_rd + d * 32 * VSTR + (kb * 32 + s2 * 16) * 2;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(pa);        // keys 4h..4h+3 of the group
+                    const uint2 hi = *reinterpret_cast<const uint2*>(pa + 16);   // keys 8+4h..8+4h+3
+                    const uint4 a = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                   __builtin_bit_cast(bf16x8, pf[kb][s2]), o[d], 0, 0, 0);
+                }
+        __syncthreads();
+        if (more) {
+            sstore();
+            __syncthreads();
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (qi < L) {
+        const float inv = 1.0f / l;
+        uint16_t* orow = out + (rowbase + qi) * ldo + head * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * h;   // rows (e&3) + 8*(e>>2) + 4h of the accumulator
+                uint2 w;
+                w.x = pack2(o[d][4 * g4 + 0] * inv, o[d][4 * g4 + 1] * inv);
+                w.y = pack2(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + dd) = w;
+            }
+    }
+}
+
+}  // namespace
+
+int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
+                      int L, int heads, float scale, hipStream_t st) {
+    PGT_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "mha: row strides must be multiples of 8");
+    PGT_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "mha: misaligned pointer");
+    const dim3 grid((L + 127) / 128, heads, B);
+    hipLaunchKernelGGL(mha_mfma_kernel, grid, dim3(256), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
+                       (const uint16_t*)v, ldv, (uint16_t*)out, ldo, L, scale * 1.44269504088896340736f);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}

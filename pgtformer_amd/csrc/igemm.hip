@@ -41,6 +41,24 @@ template <> struct Mma<float> {
     }
 };
 
+// 8 consecutive elements <-> floats with 16-byte accesses
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* f) {
+    Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p), f);
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) {
+    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p);
+    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p + 4);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* f) {
+    *reinterpret_cast<uint4*>(p) = Vec16<bf16_t>::pack(f);
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) {
+    *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(f);
+    *reinterpret_cast<float4*>(p + 4) = *reinterpret_cast<const float4*>(f + 4);
+}
+
 struct ConvP {
     const char* x;
     const char* w;
@@ -50,7 +68,7 @@ struct ConvP {
     const char* shift;
     char* y;
     int N, H, W, Cin, ldx, ups, KH, KW, stride, pad_t, pad_l, Ho, Wo, Cout, ldy;
-    int act, post_relu, ldr, epi, ld_dec, ld_shift, out_f32;
+    int act, post_relu, ldr, epi, ld_dec, ld_shift, out_f32, vec_epi;
     float sft_w;
     int M, K, nbm, nbn;
 };
@@ -190,6 +208,65 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
     }
 
     // epilogue: bias, activation, residual, (post-ReLU | SFT modulate), store
+    if (p.vec_epi) {
+        // Vectorised path: act(acc + bias) is staged through LDS (fp32, two half-tile passes) so that every
+        // thread then handles 8 consecutive output channels of one pixel: 16-byte residual/dec/shift loads
+        // and 16-byte stores instead of 2-byte scattered ones.
+        constexpr int SROW = BN + 4;
+        float* stage = reinterpret_cast<float*>(smem);
+        static_assert((BM / 2) * SROW * 4 <= (BM + BN) * kRowStride, "stage buffer must fit the tile LDS");
+        const T* res = reinterpret_cast<const T*>(p.res);
+        const T* dec = reinterpret_cast<const T*>(p.dec);
+        const T* shf = reinterpret_cast<const T*>(p.shift);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wm == pass) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int cl = wn * (BN / 2) + j * 32 + (lane & 31);
+                    const int n = n0 + cl;
+                    const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int rl = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                            stage[rl * SROW + cl] = apply_act(acc[i][j][e] + bv, p.act);
+                        }
+                }
+            }
+            __syncthreads();
+            for (int cidx = tid; cidx < (BM / 2) * (BN / 8); cidx += kThreads) {
+                const int rl = cidx / (BN / 8), c8 = (cidx % (BN / 8)) * 8;
+                const int m = m0 + pass * (BM / 2) + rl, n = n0 + c8;
+                if (m >= p.M || n >= p.Cout) continue;
+                float v[8];
+                *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8);
+                *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8 + 4);
+                if (p.epi == 1) {
+                    float d[8], s[8];
+                    load8<T>(dec + (long)m * p.ld_dec + n, d);
+                    load8<T>(shf + (long)m * p.ld_shift + n, s);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + s[e]);
+                } else {
+                    if (res) {
+                        float r[8];
+                        load8<T>(res + (long)m * p.ldr + n, r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    }
+                    if (p.post_relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
+                }
+                if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n, v);
+                else store8<T>(reinterpret_cast<T*>(p.y) + (long)m * p.ldy + n, v);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     T* y = reinterpret_cast<T*>(p.y);
     const T* res = reinterpret_cast<const T*>(p.res);
     const T* dec = reinterpret_cast<const T*>(p.dec);
@@ -232,9 +309,16 @@ template <typename T, int BM, int BN> int launch(const ConvP& p0, hipStream_t st
 }
 
 template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm, int force_bn) {
-    int bn = p.Cout <= 64 ? 64 : 128;
-    long tiles128 = (long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
-    int bm = tiles128 >= 256 ? 128 : 64;
+    // Tile choice measured with tools/bench_igemm.py on MI355X (profiles/r1_igemm_shapes_v1.txt): this
+    // 2-barrier register-staged pipeline wants MANY resident workgroups per CU, so BM=64 wins almost
+    // everywhere; BN=128 only pays once K is deep and there are still >= 2 workgroups per CU; Cout<=64
+    // layers at 512x512 / 256x256 amortise their weight tile better with BM=128.
+    int bm = 64, bn = 64;
+    if (p.Cout <= 64) {
+        if (p.K >= 512 && p.M >= 65536) bm = 128;
+    } else if (p.K >= 1024 && (long)((p.M + 63) / 64) * ((p.Cout + 127) / 128) >= 512) {
+        bn = 128;
+    }
     if (force_bm) bm = force_bm;
     if (force_bn) bn = force_bn;
     if (bm == 128 && bn == 128) return launch<T, 128, 128>(p, st);
@@ -270,6 +354,10 @@ extern "C" int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, 
     p.M = d->N * d->Ho * d->Wo;
     p.K = d->KH * d->KW * d->Cin;
     p.nbm = p.nbn = 0;
+    // 16-byte epilogue accesses need 8-channel granularity and 16-byte aligned rows on every operand
+    auto al = [](const void* ptr, int ld) { return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && ld % 8 == 0); };
+    p.vec_epi = (d->Cout % 8 == 0) && al(y, d->ldy) && al(residual, d->ldr) &&
+                (d->epi == 0 || (al(sft_dec, d->ld_dec) && al(sft_shift, d->ld_shift))) && !d->scalar_epilogue;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == PGT_F32) return dispatch<float>(p, st, d->force_bm, d->force_bn);
     return dispatch<bf16_t>(p, st, d->force_bm, d->force_bn);

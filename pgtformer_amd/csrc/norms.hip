@@ -75,13 +75,22 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, int nblk, int
     __shared__ float s_mean[64], s_rstd[64];
     const int n = blockIdx.x;
     const int cpg = C / groups;
-    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+    // one wavefront per group: lanes stride the pixel-chunk partials, then a fixed-pattern butterfly in
+    // double (same order every run -> deterministic)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int g = wv; g < groups; g += nwv) {
         double a = 0.0, b = 0.0;
-        for (int k = 0; k < nblk; ++k) {
+        for (int k = lane; k < nblk; k += 64) {
             const float* o = part + (((long)n * nblk + k) * groups + g) * 2;
             a += (double)o[0];
             b += (double)o[1];
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if (lane != 0) continue;
         const double cnt = (double)HW * cpg;
         const double mean = a / cnt;
         double var = b / cnt - mean * mean;
@@ -256,7 +265,7 @@ static int gn_affine_impl(const void* x, int ldx, int N, int HW, int C, int grou
     else
         hipLaunchKernelGGL((gn_partial_kernel<T, 1>), dim3(nb, N), dim3(kT), lds, st, (const T*)x, ldx, HW, C, groups, ppb, part);
     PGT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, st, part, nb, HW, C, groups, eps, gamma, beta, scale, shift);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(1024), 0, st, part, nb, HW, C, groups, eps, gamma, beta, scale, shift);
     PGT_LAUNCH_CHECK();
     return 0;
 }

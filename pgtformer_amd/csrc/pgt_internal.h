@@ -1,3 +1,8 @@
 // Internal umbrella: public C-ABI + helpers shared by the translation units of libpgt_hip.so.
 #pragma once
+#include <hip/hip_runtime.h>
 #include "../../include/pgt_hip.h"
+
+// attention_mfma.hip: bf16 MFMA flash attention (hd = 64)
+int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
+                      int L, int heads, float scale, hipStream_t st);

@@ -65,7 +65,7 @@ def _ld_rows(x):
 
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
-           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0)):
+           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout)."""
     n, h, wd, cin = x.shape
@@ -87,6 +87,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.ldr = _ld_img(res) if res is not None else 0
     d.out_f32 = int(out_f32)
     d.force_bm, d.force_bn = tile
+    d.scalar_epilogue = int(scalar_epi)
     dec = shift = None
     if sft is not None:
         dec, shift, sw = sft

@@ -119,6 +119,12 @@ def test_conv_epilogues_and_views(dtype):
     check("sft", ops().conv2d(g(x), g(wt), g(b), sft=(g(dec), g(shf), 0.7), **kw),
           E.conv2d(x, wt, b, sft=(dec, shf, 0.7), **kw), dtype)
     check("out_f32", ops().conv2d(g(x), g(wt), g(b), out_f32=True, **kw), E.conv2d(x, wt, b, out_f32=True, **kw), dtype)
+    # the 16-byte (LDS-staged) epilogue and the element-wise one are the same arithmetic: bit-identical
+    for extra in (dict(res=g(res), post_relu=True), dict(sft=(g(dec), g(shf), 0.7)), dict(act=E.ACT_GELU)):
+        for tile in ((64, 64), (128, 128), (128, 64), (64, 128)):
+            a = ops().conv2d(g(x), g(wt), g(b), tile=tile, **extra, **kw)
+            bb = ops().conv2d(g(x), g(wt), g(b), tile=tile, scalar_epi=True, **extra, **kw)
+            assert torch.equal(a, bb), (tile, list(extra))
     # channel-sliced input view and channel-sliced output view (concat buffers)
     wide = rnd((n, h, w_, 2 * c), 26, dtype)
     wide_d = g(wide)
