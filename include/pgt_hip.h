@@ -60,11 +60,21 @@ typedef struct pgt_conv_desc {
     int32_t out_f32;            /* 1: store y as fp32 even when dtype is bf16 (logits, distances) */
     int32_t force_bm, force_bn; /* 0 = heuristic; 64|128 pins the workgroup tile (tests, tuning)  */
     int32_t scalar_epilogue;    /* 1: force the element-wise epilogue (A/B tests); 0 = 16-byte path when legal */
+    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0)     */
+    int32_t splitk;             /* 0 = auto (needs a workspace); 1 = never; 2..16 = that many K slices           */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
                const void* residual, const void* sft_dec, const void* sft_shift, void* y,
                pgt_stream_t stream);
+/* Same, with a caller-owned scratch buffer that enables split-K on deep-K / small-M layers (the 32x32
+ * feature maps): K slices accumulate fp32 partial tiles in `workspace`, a second kernel sums them in slice
+ * order (deterministic) and applies the epilogue.  pgt_conv2d_workspace_bytes() returns the size the layer
+ * would use (0: single pass, workspace may be NULL). */
+size_t pgt_conv2d_workspace_bytes(const pgt_conv_desc* d);
+int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
+                  const void* residual, const void* sft_dec, const void* sft_shift, void* y,
+                  void* workspace, size_t workspace_bytes, pgt_stream_t stream);
 
 /* ---- normalisation ---------------------------------------------------------------------------
  * GroupNorm(groups, eps) statistics -> per-(n,c) affine so that GN(x) = x*scale + shift

@@ -22,7 +22,9 @@ constexpr int BKV = 64;
 constexpr int KSTR = 144;   // K tile row stride in bytes (128 + 16 pad): conflict-free ds_read_b128
 constexpr int VSTR = 136;   // V^T row stride in bytes (64 keys * 2 + 8): conflict-free ds_read_b64
 
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf2(lo, hi); }   // v_cvt_pk_bf16_f32
+// raw v_exp_f32 (2^x): arguments here are <= 0 and results feed a bf16 operand, no range fix-up needed
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k,
                                                        int ldk, const uint16_t* __restrict__ v, int ldv,
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(m, mx);
-        const float alpha = exp2f((m - mnew) * c);
+        const float alpha = fast_exp2((m - mnew) * c);
         const float mc = mnew * c;
         float lsum = 0.f;
         uint4 pf[2][2];   // P^T B-operands: [key block][k-step]
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
             float p[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                p[e] = exp2f(s[kb][e] * c - mc);
+                p[e] = fast_exp2(s[kb][e] * c - mc);
                 lsum += p[e];
             }
             pf[kb][0] = make_uint4(pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7]));

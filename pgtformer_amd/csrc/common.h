@@ -12,12 +12,15 @@ struct bf16_t {
 };
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+// round-to-nearest-even fp32 -> bf16: the __bf16 casts lower to gfx950's v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {   // {lo, hi} packed, one instruction
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct ElemIO;
@@ -53,10 +56,7 @@ template <> struct Vec16<bf16_t> {
         f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
     }
     static __device__ __forceinline__ uint4 pack(const float* f) {
-        return make_uint4((uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16),
-                          (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
-                          (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16),
-                          (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+        return make_uint4(f2bf2(f[0], f[1]), f2bf2(f[2], f[3]), f2bf2(f[4], f[5]), f2bf2(f[6], f[7]));
     }
 };
 

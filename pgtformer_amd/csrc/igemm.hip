@@ -16,12 +16,18 @@
 // v_mfma_f32_32x32x2_f32 (parity mode); both accumulate in fp32.
 #include "common.h"
 #include "pgt_internal.h"
+#include "igemm_common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
+constexpr long kV2MinBlocks = 1L << 40;  // v2 (LDS-DMA) is opt-in (kernel=2): measured no faster than v1 on MI355X (profiles/r1_igemm_pmc.md)
+constexpr int kV2MinK = 256;
 constexpr int kRowBytes = 128;          // K bytes per tile row
-constexpr int kRowStride = kRowBytes + 16;  // padded LDS row stride
+constexpr int kRowStride = kRowBytes + 16;  // padded LDS rows (144 B): conflict-free ds_read_b128 / ds_write_b128.
+// (An unpadded XOR-swizzled image — swz128, used by igemm2 — fits 6 workgroups/CU but measured ~20 % slower in the
+// whole model: profiles/r1_v3 vs r1_v4 kernel stats.)
+__device__ __forceinline__ int lds_off(int row, int c) { return row * kRowStride + c * 16; }
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -41,39 +47,7 @@ template <> struct Mma<float> {
     }
 };
 
-// 8 consecutive elements <-> floats with 16-byte accesses
-template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* f) {
-    Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p), f);
-}
-template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) {
-    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p);
-    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p + 4);
-}
-template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* f) {
-    *reinterpret_cast<uint4*>(p) = Vec16<bf16_t>::pack(f);
-}
-template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) {
-    *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(f);
-    *reinterpret_cast<float4*>(p + 4) = *reinterpret_cast<const float4*>(f + 4);
-}
-
-struct ConvP {
-    const char* x;
-    const char* w;
-    const float* bias;
-    const char* res;
-    const char* dec;
-    const char* shift;
-    char* y;
-    int N, H, W, Cin, ldx, ups, KH, KW, stride, pad_t, pad_l, Ho, Wo, Cout, ldy;
-    int act, post_relu, ldr, epi, ld_dec, ld_shift, out_f32, vec_epi;
-    float sft_w;
-    int M, K, nbm, nbn;
-};
-
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool SK>   // SK: split-K slice kernel (compile-time so the common path keeps its registers)
 __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
     constexpr int ES = sizeof(T);
     constexpr int CH = 16 / ES;            // elements per 16-byte chunk
@@ -82,7 +56,9 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
     constexpr int BR = BN / 32;
     constexpr int MI = BM / 64;            // 32x32 MFMA tiles per wave along M
     constexpr int NI = BN / 64;
-    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * kRowStride];
+    constexpr int kTileBytes = (BM + BN) * kRowStride;
+    constexpr int kStageBytes = (BM / 2) * (BN + 4) * 4;   // fp32 epilogue staging (two half-tile passes)
+    __shared__ __attribute__((aligned(256))) char smem[kTileBytes > kStageBytes ? kTileBytes : kStageBytes];
     char* As = smem;
     char* Bs = smem + BM * kRowStride;
 
@@ -94,11 +70,15 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
     // XCD-aware tile order: the 8 XCDs each take a contiguous run of tiles (n fastest) so the
     // workgroups that share an A tile / a halo run on the same L2 (bijective for any grid size).
     const int nblk = p.nbm * p.nbn;
-    const int bid = blockIdx.x;
+    // split-K: workgroup = (K slice, output tile); slice s walks K tiles [s*kt_per_split, ...) and writes its
+    // raw fp32 partial tile to workspace slab s (summed in fixed order by splitk_epilogue_kernel).
+    const int split = SK ? (int)blockIdx.x / nblk : 0;
+    const int bid = (int)blockIdx.x - split * nblk;
     const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
     const int sw = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int m0 = (sw / p.nbn) * BM;
     const int n0 = (sw % p.nbn) * BN;
+    if (SK) p.y += (long)split * p.M * p.Cout * 4;
 
     const int cc = tid & 7;    // 16-byte chunk column of this thread within the 128-byte tile row
     const int r0 = tid >> 3;   // first tile row of this thread (then +32, +64, ...)
@@ -124,47 +104,70 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
         }
     }
     // K position of this thread's chunk: tap (ky,kx) and channel c, advanced incrementally
-    int kg = cc * CH;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = SK ? split * p.kt_per_split : 0;
+    const int nk = SK ? min(nk_all, kt0 + p.kt_per_split) : nk_all;   // one past the last K tile
+    int kg = kt0 * BK + cc * CH;
     int c = kg % p.Cin;
     int tap = kg / p.Cin;
     int ky = tap / p.KW, kx = tap % p.KW;
 
-    uint4 ra[AR], rb[BR];
-    auto gload = [&]() {
+    // Per-row gather state for the CURRENT filter tap, recomputed only when this thread's tap changes (every
+    // Cin/BK K tiles): byte offset of the source pixel (tensors are < 2 GiB), -1 = zero padding / out of range.
+    int a_offs[AR];
+    auto retap = [&]() {
         const bool kval = ky < p.KH;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            const bool ok = kval && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+            a_offs[i] = ok ? (pbase[i] + (iy >> p.ups) * p.W + (ix >> p.ups)) * p.ldx * ES : -1;
+        }
+    };
+    retap();
+    int b_offs[BR];   // byte offset of this thread's weight row (Cout*K*ES < 2 GiB), -1 = row >= Cout
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_offs[i] = n < p.Cout ? n * p.K * ES : -1;
+    }
+
+    uint4 ra[AR], rb[BR];
+    auto gload = [&]() {
+        const char* xa = p.x + c * ES;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (kval && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
-                const long pix = (long)pbase[i] + (long)(iy >> p.ups) * p.W + (ix >> p.ups);
-                v = *reinterpret_cast<const uint4*>(p.x + (pix * p.ldx + c) * ES);
-            }
+            if (a_offs[i] >= 0) v = *reinterpret_cast<const uint4*>(xa + a_offs[i]);
             ra[i] = v;
         }
+        const char* wb = p.w + (long)kg * ES;
+        const bool kin = kg < p.K;
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int n = n0 + r0 + 32 * i;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (n < p.Cout && kg < p.K) v = *reinterpret_cast<const uint4*>(p.w + ((long)n * p.K + kg) * ES);
+            if (kin && b_offs[i] >= 0) v = *reinterpret_cast<const uint4*>(wb + b_offs[i]);
             rb[i] = v;
         }
     };
     auto advance = [&]() {
         kg += BK;
         c += BK;
-        while (c >= p.Cin) {
-            c -= p.Cin;
-            if (++kx == p.KW) { kx = 0; ++ky; }
+        if (c >= p.Cin) {
+            do {
+                c -= p.Cin;
+                if (++kx == p.KW) { kx = 0; ++ky; }
+            } while (c >= p.Cin);
+            retap();
         }
     };
     auto sstore = [&]() {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<uint4*>(As + (r0 + 32 * i) * kRowStride + cc * 16) = ra[i];
+            *reinterpret_cast<uint4*>(As + lds_off(r0 + 32 * i, cc)) = ra[i];
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<uint4*>(Bs + (r0 + 32 * i) * kRowStride + cc * 16) = rb[i];
+            *reinterpret_cast<uint4*>(Bs + lds_off(r0 + 32 * i, cc)) = rb[i];
     };
 
     f32x16 acc[MI][NI];
@@ -175,14 +178,13 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
     gload();
     advance();
     sstore();
     __syncthreads();
     const char* a_rd = As + (wm * (BM / 2) + (lane & 31)) * kRowStride + (lane >> 5) * 16;
     const char* b_rd = Bs + (wn * (BN / 2) + (lane & 31)) * kRowStride + (lane >> 5) * 16;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) {
             gload();
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
         // and 16-byte stores instead of 2-byte scattered ones.
         constexpr int SROW = BN + 4;
         float* stage = reinterpret_cast<float*>(smem);
-        static_assert((BM / 2) * SROW * 4 <= (BM + BN) * kRowStride, "stage buffer must fit the tile LDS");
+        static_assert((BM / 2) * SROW * 4 <= (int)sizeof(smem), "stage buffer must fit the tile LDS");
         const T* res = reinterpret_cast<const T*>(p.res);
         const T* dec = reinterpret_cast<const T*>(p.dec);
         const T* shf = reinterpret_cast<const T*>(p.shift);
@@ -303,9 +305,67 @@ template <typename T, int BM, int BN> int launch(const ConvP& p0, hipStream_t st
     ConvP p = p0;
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(p.nbm * p.nbn), dim3(kThreads), 0, st, p);
+    if (p.splitk > 1) {
+        if constexpr (BM == 64 && BN == 64)
+            hipLaunchKernelGGL((igemm_kernel<T, BM, BN, true>), dim3(p.nbm * p.nbn * p.splitk), dim3(kThreads), 0, st, p);
+        else
+            PGT_CHECK(false, "split-K runs on 64x64 tiles only");
+    } else {
+        hipLaunchKernelGGL((igemm_kernel<T, BM, BN, false>), dim3(p.nbm * p.nbn), dim3(kThreads), 0, st, p);
+    }
     PGT_LAUNCH_CHECK();
     return 0;
+}
+
+// Sum the split-K slabs in slice order (deterministic) and apply the conv epilogue, 8 channels per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, const float* __restrict__ ws, int slices) {
+    const long nchunk = (long)p.M * (p.Cout / 8);
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nchunk) return;
+    const int m = (int)(i / (p.Cout / 8)), n = (int)(i % (p.Cout / 8)) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int s = 0; s < slices; ++s) {
+        float t[8];
+        load8<float>(ws + ((long)s * p.M + m) * p.Cout + n, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += t[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
+    if (p.epi == 1) {
+        float d[8], sh[8];
+        load8<T>(reinterpret_cast<const T*>(p.dec) + (long)m * p.ld_dec + n, d);
+        load8<T>(reinterpret_cast<const T*>(p.shift) + (long)m * p.ld_shift + n, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + sh[e]);
+    } else {
+        if (p.res) {
+            float rr[8];
+            load8<T>(reinterpret_cast<const T*>(p.res) + (long)m * p.ldr + n, rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        }
+        if (p.post_relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+    }
+    if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n, v);
+    else store8<T>(reinterpret_cast<T*>(p.y) + (long)m * p.ldy + n, v);
+}
+
+// Split-K policy: deep-K layers whose 64x64 tiling leaves most of the chip idle (32x32-resolution convs).
+inline int choose_splitk(long M, int Cout, int K, int bk) {
+    const long tiles = ((M + 63) / 64) * ((Cout + 63) / 64);
+    const int nk = (K + bk - 1) / bk;
+    if (tiles >= 512 || nk < 32) return 1;
+    int s = (int)((1536 + tiles - 1) / tiles);
+    if (s > 8) s = 8;
+    while (s > 1 && nk / s < 8) --s;
+    return s;
 }
 
 template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm, int force_bn) {
@@ -329,9 +389,25 @@ template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm,
 
 }  // namespace
 
-extern "C" int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
-                          const void* residual, const void* sft_dec, const void* sft_shift, void* y,
-                          pgt_stream_t stream) {
+// number of K slices pgt_conv2d_ws would use for this layer (1 = single pass)
+static int planned_splitk(const pgt_conv_desc* d) {
+    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0) return 1;
+    const long M = (long)d->N * d->Ho * d->Wo;
+    const int K = d->KH * d->KW * d->Cin;
+    const int bk = d->dtype == PGT_F32 ? 32 : 64;
+    if (d->splitk > 1) return d->splitk <= 16 && (K + bk - 1) / bk >= d->splitk ? d->splitk : 1;
+    return choose_splitk(M, d->Cout, K, bk);
+}
+
+extern "C" size_t pgt_conv2d_workspace_bytes(const pgt_conv_desc* d) {
+    if (!d) return 0;
+    const int s = planned_splitk(d);
+    return s > 1 ? (size_t)s * d->N * d->Ho * d->Wo * d->Cout * sizeof(float) : 0;
+}
+
+extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
+                             const void* residual, const void* sft_dec, const void* sft_shift, void* y,
+                             void* workspace, size_t workspace_bytes, pgt_stream_t stream) {
     PGT_CHECK(d && x && w && y, "pgt_conv2d: null argument");
     PGT_CHECK(d->dtype == PGT_F32 || d->dtype == PGT_BF16, "pgt_conv2d: bad dtype %d", d->dtype);
     const int es = d->dtype == PGT_F32 ? 4 : 2;
@@ -354,11 +430,54 @@ extern "C" int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, 
     p.M = d->N * d->Ho * d->Wo;
     p.K = d->KH * d->KW * d->Cin;
     p.nbm = p.nbn = 0;
+    p.splitk = 1;
+    p.kt_per_split = 0;
     // 16-byte epilogue accesses need 8-channel granularity and 16-byte aligned rows on every operand
     auto al = [](const void* ptr, int ld) { return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && ld % 8 == 0); };
     p.vec_epi = (d->Cout % 8 == 0) && al(y, d->ldy) && al(residual, d->ldr) &&
                 (d->epi == 0 || (al(sft_dec, d->ld_dec) && al(sft_shift, d->ld_shift))) && !d->scalar_epilogue;
     hipStream_t st = (hipStream_t)stream;
+
+    // ---- split-K: slices write fp32 partial tiles to the workspace, a second kernel sums + applies the epilogue
+    const int slices = (workspace && p.vec_epi) ? planned_splitk(d) : 1;
+    if (slices > 1) {
+        PGT_CHECK(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (size_t)slices * p.M * p.Cout * sizeof(float),
+                  "pgt_conv2d: split-K workspace too small or misaligned");
+        ConvP ps = p;
+        ps.bias = nullptr; ps.res = nullptr; ps.dec = nullptr; ps.shift = nullptr;
+        ps.act = 0; ps.post_relu = 0; ps.epi = 0; ps.out_f32 = 1; ps.vec_epi = 1;
+        ps.y = (char*)workspace; ps.ldy = p.Cout;
+        ps.splitk = slices;
+        const int bk = d->dtype == PGT_F32 ? 32 : 64;
+        const int nk = (p.K + bk - 1) / bk;
+        ps.kt_per_split = (nk + slices - 1) / slices;
+        int rc = d->dtype == PGT_F32 ? launch<float, 64, 64>(ps, st) : launch<bf16_t, 64, 64>(ps, st);
+        if (rc) return rc;
+        const long nchunk = (long)p.M * (p.Cout / 8);
+        const dim3 grid((unsigned)((nchunk + 255) / 256));
+        if (d->dtype == PGT_F32)
+            hipLaunchKernelGGL((splitk_epilogue_kernel<float>), grid, dim3(256), 0, st, p, (const float*)workspace, slices);
+        else
+            hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t>), grid, dim3(256), 0, st, p, (const float*)workspace, slices);
+        PGT_LAUNCH_CHECK();
+        return 0;
+    }
+
     if (d->dtype == PGT_F32) return dispatch<float>(p, st, d->force_bm, d->force_bn);
+    // v2 (LDS-DMA, 128-row tiles) is opt-in (kernel = 2); kernel: 0 auto, 1 v1, 2 v2
+    const bool v2_legal = d->Cin % 64 == 0 && p.vec_epi && ((uintptr_t)x & 15) == 0 && d->ldx % 8 == 0;
+    PGT_CHECK(d->kernel != 2 || v2_legal, "pgt_conv2d: kernel=2 needs bf16, Cin %% 64 == 0 and a 16-byte-legal epilogue");
+    if (v2_legal && d->kernel != 1) {
+        const int bn = (d->force_bn == 64 || (d->force_bn == 0 && d->Cout <= 64)) ? 64 : 128;
+        const long blocks = (long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
+        if (d->kernel == 2 || (d->kernel == 0 && d->force_bm == 0 && d->force_bn == 0 && blocks >= kV2MinBlocks && p.K >= kV2MinK))
+            return pgt_igemm2_launch(&p, bn, d->force_bm >= 2 && d->force_bm <= 4 ? d->force_bm : 3, st);
+    }
     return dispatch<bf16_t>(p, st, d->force_bm, d->force_bn);
+}
+
+extern "C" int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
+                          const void* residual, const void* sft_dec, const void* sft_shift, void* y,
+                          pgt_stream_t stream) {
+    return pgt_conv2d_ws(d, x, w, bias, residual, sft_dec, sft_shift, y, nullptr, 0, stream);
 }

@@ -152,19 +152,62 @@ __global__ __launch_bounds__(kT) void affine_act_kernel(const T* __restrict__ x,
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wavefront per row, C/64 contiguous elements per lane, two-pass in registers.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int EPL>
+// EPL contiguous elements of one row <-> floats; 8/16-byte vector accesses when VEC (caller checked alignment)
+template <typename T, int EPL, bool VEC> struct RowIO {
+    static __device__ __forceinline__ void ld(const T* p, float* v) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] = ldf(p + e);
+    }
+    static __device__ __forceinline__ void st(T* p, const float* v) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) stf(p + e, v[e]);
+    }
+};
+template <int EPL> struct RowIO<bf16_t, EPL, true> {   // EPL in {4, 8, 16}
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
+        if constexpr (EPL == 4) {
+            const uint2 q = *reinterpret_cast<const uint2*>(p);
+            v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+            v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL / 8; ++i) Vec16<bf16_t>::unpack(reinterpret_cast<const uint4*>(p)[i], v + 8 * i);
+        }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
+        if constexpr (EPL == 4) {
+            *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL / 8; ++i) reinterpret_cast<uint4*>(p)[i] = Vec16<bf16_t>::pack(v + 8 * i);
+        }
+    }
+};
+template <int EPL> struct RowIO<float, EPL, true> {    // EPL in {4, 8, 16}
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) *reinterpret_cast<float4*>(v + 4 * i) = reinterpret_cast<const float4*>(p)[i];
+    }
+    static __device__ __forceinline__ void st(float* p, const float* v) {
+#pragma unroll
+        for (int i = 0; i < EPL / 4; ++i) reinterpret_cast<float4*>(p)[i] = *reinterpret_cast<const float4*>(v + 4 * i);
+    }
+};
+
+template <typename T, int EPL, bool VEC>
 __global__ __launch_bounds__(kT) void layernorm_kernel(const T* __restrict__ x, int ldx, int rows, int C,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, T* __restrict__ y, int ldy, const T* __restrict__ pos,
                                                        int ldpos, T* __restrict__ y2, int ldy2) {
+    typedef RowIO<T, EPL, VEC> IO;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int c0 = lane * EPL;
-    float v[EPL];
-    const T* xr = x + (long)row * ldx + c0;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] = ldf(xr + e);
+    float v[EPL], gm[EPL], bt[EPL];
+    IO::ld(x + (long)row * ldx + c0, v);
+    RowIO<float, EPL, VEC>::ld(gamma + c0, gm);
+    RowIO<float, EPL, VEC>::ld(beta + c0, bt);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) s += v[e];
@@ -173,17 +216,15 @@ __global__ __launch_bounds__(kT) void layernorm_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { const float d = v[e] - mean; ss += d * d; }
     const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
-    T* yr = y + (long)row * ldy + c0;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        v[e] = (v[e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
-        stf(yr + e, v[e]);
-    }
+    for (int e = 0; e < EPL; ++e) v[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+    IO::st(y + (long)row * ldy + c0, v);
     if (y2) {
-        const T* pr = pos + (long)row * ldpos + c0;
-        T* y2r = y2 + (long)row * ldy2 + c0;
+        float pv[EPL];
+        IO::ld(pos + (long)row * ldpos + c0, pv);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) stf(y2r + e, v[e] + ldf(pr + e));
+        for (int e = 0; e < EPL; ++e) pv[e] += v[e];
+        IO::st(y2 + (long)row * ldy2 + c0, pv);
     }
 }
 
@@ -191,29 +232,55 @@ __global__ __launch_bounds__(kT) void layernorm_kernel(const T* __restrict__ x, 
 // per-(n,c) mean / unbiased variance over HW (AdaIN statistics; also global average pooling)
 // grid (C/64, N), block 256 = 4 pixel slots x 64 channels
 // ---------------------------------------------------------------------------------------------
+constexpr int kStatSlots = 16;   // pixel slots per workgroup (1024 threads = 16 slots x 64 channels)
 template <typename T>
-__global__ __launch_bounds__(kT) void channel_stats_kernel(const T* __restrict__ x, int ldx, int HW, int C,
-                                                           float* __restrict__ mean, float* __restrict__ var) {
-    __shared__ float sm[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+__global__ __launch_bounds__(kStatSlots * 64) void channel_stats_kernel(const T* __restrict__ x, int ldx, int HW, int C,
+                                                                        float* __restrict__ mean, float* __restrict__ var) {
+    __shared__ float sm[kStatSlots][64];
+    const int cl = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + cl;
     const int slot = threadIdx.x >> 6;
     const int n = blockIdx.y;
     const bool ok = c < C;
-    float s = 0.f;
-    if (ok)
-        for (int p = slot; p < HW; p += 4) s += ldf(x + ((long)n * HW + p) * ldx + c);
-    sm[slot][threadIdx.x & 63] = s;
+    const T* base = x + (long)n * HW * ldx + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains: loads stay in flight
+    if (ok) {
+        int p = slot;
+        for (; p + 3 * kStatSlots < HW; p += 4 * kStatSlots) {
+            s0 += ldf(base + (long)p * ldx);
+            s1 += ldf(base + (long)(p + kStatSlots) * ldx);
+            s2 += ldf(base + (long)(p + 2 * kStatSlots) * ldx);
+            s3 += ldf(base + (long)(p + 3 * kStatSlots) * ldx);
+        }
+        for (; p < HW; p += kStatSlots) s0 += ldf(base + (long)p * ldx);
+    }
+    sm[slot][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    const float mu = (sm[0][threadIdx.x & 63] + sm[1][threadIdx.x & 63] + sm[2][threadIdx.x & 63] + sm[3][threadIdx.x & 63]) / (float)HW;
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < kStatSlots; ++k) tot += sm[k][cl];
+    const float mu = tot / (float)HW;
     __syncthreads();
-    float q = 0.f;
-    if (ok && var)
-        for (int p = slot; p < HW; p += 4) { const float d = ldf(x + ((long)n * HW + p) * ldx + c) - mu; q += d * d; }
-    sm[slot][threadIdx.x & 63] = q;
+    float q0 = 0.f, q1 = 0.f;
+    if (ok && var) {
+        int p = slot;
+        for (; p + kStatSlots < HW; p += 2 * kStatSlots) {
+            const float d0 = ldf(base + (long)p * ldx) - mu, d1 = ldf(base + (long)(p + kStatSlots) * ldx) - mu;
+            q0 += d0 * d0;
+            q1 += d1 * d1;
+        }
+        for (; p < HW; p += kStatSlots) { const float d = ldf(base + (long)p * ldx) - mu; q0 += d * d; }
+    }
+    sm[slot][cl] = q0 + q1;
     __syncthreads();
     if (slot == 0 && ok) {
         mean[(long)n * C + c] = mu;
-        if (var) var[(long)n * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)(HW > 1 ? HW - 1 : 1);
+        if (var) {
+            float qt = 0.f;
+#pragma unroll
+            for (int k = 0; k < kStatSlots; ++k) qt += sm[k][cl];
+            var[(long)n * C + c] = qt / (float)(HW > 1 ? HW - 1 : 1);
+        }
     }
 }
 
@@ -310,9 +377,13 @@ template <typename T>
 static int layernorm_impl(const void* x, int ldx, int rows, int C, const float* gamma, const float* beta, float eps,
                           void* y, int ldy, const void* pos, int ldpos, void* y2, int ldy2, hipStream_t st) {
     const dim3 grid((rows + 3) / 4), blk(kT);
-#define LN_LAUNCH(EPL)                                                                                              \
-    hipLaunchKernelGGL((layernorm_kernel<T, EPL>), grid, blk, 0, st, (const T*)x, ldx, rows, C, gamma, beta, eps,  \
+    // 8/16-byte row accesses need 16-byte aligned rows on every tensor
+    auto al = [](const void* ptr, int ld) { return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && ld % 8 == 0); };
+    const bool vec = al(x, ldx) && al(y, ldy) && al(pos, ldpos) && al(y2, ldy2) && al(gamma, 8) && al(beta, 8);
+#define LN_LAUNCH2(EPL, VEC)                                                                                          \
+    hipLaunchKernelGGL((layernorm_kernel<T, EPL, VEC>), grid, blk, 0, st, (const T*)x, ldx, rows, C, gamma, beta, eps, \
                        (T*)y, ldy, (const T*)pos, ldpos, (T*)y2, ldy2)
+#define LN_LAUNCH(EPL) do { if (vec && EPL >= 4) LN_LAUNCH2(EPL, (EPL >= 4)); else LN_LAUNCH2(EPL, false); } while (0)
     switch (C) {
         case 64: LN_LAUNCH(1); break;
         case 128: LN_LAUNCH(2); break;
@@ -322,6 +393,7 @@ static int layernorm_impl(const void* x, int ldx, int rows, int C, const float* 
         default: PGT_CHECK(false, "layernorm: C=%d unsupported (64,128,256,512,1024)", C);
     }
 #undef LN_LAUNCH
+#undef LN_LAUNCH2
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -339,7 +411,7 @@ extern "C" int pgt_layernorm(int32_t dtype, const void* x, int32_t ldx, int32_t 
 extern "C" int pgt_channel_stats(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
                                  float* mean, float* var_unbiased, pgt_stream_t stream) {
     PGT_CHECK(x && mean, "channel_stats: null argument");
-    const dim3 grid((C + 63) / 64, N), blk(kT);
+    const dim3 grid((C + 63) / 64, N), blk(kStatSlots * 64);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PGT_F32)
         hipLaunchKernelGGL((channel_stats_kernel<float>), grid, blk, 0, st, (const float*)x, ldx, HW, C, mean, var_unbiased);

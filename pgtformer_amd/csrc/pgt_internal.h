@@ -6,3 +6,6 @@
 // attention_mfma.hip: bf16 MFMA flash attention (hd = 64)
 int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
                       int L, int heads, float scale, hipStream_t st);
+
+// igemm2.hip: LDS-DMA implicit GEMM (bf16, Cin % 64 == 0, 16-byte epilogue legal). `conv_p` is a ConvP.
+int pgt_igemm2_launch(const void* conv_p, int bn, int stages, hipStream_t st);

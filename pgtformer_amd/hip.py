@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "N", "H", "W", "Cin", "ldx", "ups", "KH", "KW", "stride", "pad_t",
                                    "pad_l", "Ho", "Wo", "Cout", "ldy", "act", "post_relu", "ldr", "epi",
                                    "ld_dec", "ld_shift")] + [("sft_w", f32)] + \
-               [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue")]
+               [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue", "kernel", "splitk")]
 
 
 # name -> argtypes (restype is int32 unless listed in _RESTYPES); must cover every symbol of pgt_hip.h
@@ -29,6 +29,8 @@ SIGNATURES = {
     "pgt_version": [],
     "pgt_last_error": [],
     "pgt_conv2d": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp],
+    "pgt_conv2d_workspace_bytes": [C.POINTER(ConvDesc)],
+    "pgt_conv2d_ws": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
     "pgt_groupnorm_workspace_bytes": [i32, i32, i32, i32],
     "pgt_groupnorm_affine": [i32, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp],
     "pgt_affine_act": [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp],
@@ -49,7 +51,8 @@ SIGNATURES = {
     "pgt_nhwc_to_nchw_f32": [i32, vp, i32, i32, i32, i32, i32, vp, vp],
     "pgt_frame_to_u8": [i32, vp, i32, i32, i32, vp, vp],
 }
-_RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz}
+_RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz,
+             "pgt_conv2d_workspace_bytes": sz}
 
 
 class PgtError(RuntimeError):

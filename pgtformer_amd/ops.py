@@ -65,7 +65,7 @@ def _ld_rows(x):
 
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
-           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False):
+           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout)."""
     n, h, wd, cin = x.shape
@@ -88,6 +88,8 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.out_f32 = int(out_f32)
     d.force_bm, d.force_bn = tile
     d.scalar_epilogue = int(scalar_epi)
+    d.kernel = int(kernel)
+    d.splitk = int(splitk)
     dec = shift = None
     if sft is not None:
         dec, shift, sw = sft
@@ -99,8 +101,11 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    hip.check(hip.lib().pgt_conv2d(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out),
-                                   _stream()), "pgt_conv2d")
+    L = hip.lib()
+    ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None   # split-K scratch
+    hip.check(L.pgt_conv2d_ws(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out), _p(ws),
+                              ws_bytes, _stream()), "pgt_conv2d")
     if prof is not None:
         e1.record()
         m = n * ho * wo

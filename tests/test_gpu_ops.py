@@ -105,6 +105,64 @@ def test_conv2d(dtype, case):
     check(name, got, want, dtype)
 
 
+V2_CASES = [
+    ("v2_c3x3", 2, 20, 24, 64, 128, 3, 1, (1, 1, 1, 1), False),
+    ("v2_c3x3_s2_asym", 3, 16, 16, 128, 64, 3, 2, (0, 1, 0, 1), False),
+    ("v2_c3x3_ups", 2, 9, 7, 192, 200, 3, 1, (1, 1, 1, 1), True),
+    ("v2_lin_ragged_m", 1, 1, 333, 256, 72, 1, 1, (0, 0, 0, 0), False),
+    ("v2_c1x1_s2", 2, 12, 12, 64, 136, 1, 2, (0, 0, 0, 0), False),
+]
+
+
+@pytest.mark.parametrize("bn", [64, 128])
+@pytest.mark.parametrize("case", V2_CASES, ids=[c[0] for c in V2_CASES])
+def test_conv2d_lds_dma_kernel(case, bn):
+    """igemm2 (global_load_lds + XOR-swizzled LDS + double buffering) against the emulation, incl. all epilogues."""
+    name, n, h, w_, cin, cout, k, stride, pad4, ups = case
+    dtype = torch.bfloat16
+    x = rnd((n, h, w_, cin), 110, dtype)
+    wt = rnd((cout, k * k * cin), 111, dtype, 1.0 / np.sqrt(k * k * cin))
+    wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
+    b = rnd((cout,), 112, torch.float32, 0.1)
+    kw = dict(kh=k, kw=k, stride=stride, pad=pad4, ups=ups)
+    want = E.conv2d(x, wt, b, act=E.ACT_SILU, **kw)
+    res = rnd(tuple(want.shape), 113, dtype)
+    got = ops().conv2d(g(x), g(wt), g(b), act=E.ACT_SILU, kernel=2, tile=(2, bn), **kw)
+    check(f"{name}_bn{bn}", got, want, dtype)
+    got = ops().conv2d(g(x), g(wt), g(b), res=g(res), post_relu=True, kernel=2, tile=(3, bn), **kw)
+    check(f"{name}_bn{bn}_res", got, E.conv2d(x, wt, b, res=res, post_relu=True, **kw), dtype)
+    v1 = ops().conv2d(g(x), g(wt), g(b), res=g(res), post_relu=True, kernel=1, **kw)
+    check(f"{name}_bn{bn}_v1_vs_v2", got, v1, dtype, 0.2)
+    dec, shf = rnd(tuple(want.shape), 114, dtype), rnd(tuple(want.shape), 115, dtype)
+    got = ops().conv2d(g(x), g(wt), g(b), sft=(g(dec), g(shf), 0.6), out_f32=False, kernel=2, tile=(4, bn), **kw)
+    check(f"{name}_bn{bn}_sft", got, E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_split_k(dtype):
+    """Deep-K / small-M layers run as K slices + a fixed-order reduction: same result as the single pass,
+    deterministic, with every epilogue."""
+    n, h, w_, cin, cout = 3, 16, 16, 256, 72
+    x = rnd((n, h, w_, cin), 120, dtype)
+    wt = rnd((cout, 9 * cin), 121, dtype, 1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 122, torch.float32, 0.1)
+    res = rnd((n, h, w_, cout), 123, dtype)
+    kw = dict(kh=3, kw=3, pad=(1, 1, 1, 1))
+    want = E.conv2d(x, wt, b, act=E.ACT_SILU, res=res, **kw)
+    one = ops().conv2d(g(x), g(wt), g(b), act=E.ACT_SILU, res=g(res), splitk=1, **kw)
+    check("splitk_ref", one, want, dtype)
+    for s in (2, 3, 5, 0):   # 0 = library heuristic (this shape splits)
+        got = ops().conv2d(g(x), g(wt), g(b), act=E.ACT_SILU, res=g(res), splitk=s, **kw)
+        check(f"splitk{s}", got, want, dtype)
+        again = ops().conv2d(g(x), g(wt), g(b), act=E.ACT_SILU, res=g(res), splitk=s, **kw)
+        assert torch.equal(got, again)
+    dec, shf = rnd((n, h, w_, cout), 124, dtype), rnd((n, h, w_, cout), 125, dtype)
+    check("splitk_sft", ops().conv2d(g(x), g(wt), g(b), sft=(g(dec), g(shf), 0.5), splitk=4, **kw),
+          E.conv2d(x, wt, b, sft=(dec, shf, 0.5), **kw), dtype)
+    check("splitk_f32out", ops().conv2d(g(x), g(wt), None, out_f32=True, splitk=4, **kw),
+          E.conv2d(x, wt, None, out_f32=True, **kw), dtype)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_epilogues_and_views(dtype):
     n, h, w_, c = 2, 10, 9, 64

@@ -77,6 +77,14 @@ def main():
             ts = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res, tile=(bm, bn), scalar_epi=True), args.iters)
             best = min(best, tv, ts)
             cells.append(f"{tv:9.1f}/{ts:9.1f}".rjust(24))
+        v2 = ""
+        if dt == torch.bfloat16 and cin % 64 == 0 and cout % 8 == 0:
+            for bn in (64, 128):
+                for nst in (2, 3, 4):   # for kernel=2 the BM slot of `tile` carries the LDS stage count
+                    t2 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res, kernel=2, tile=(nst, bn)), args.iters)
+                    best = min(best, t2)
+                    v2 += f" v2/{bn}s{nst}={t2:6.1f}"
+        cells.append(v2)
         ta = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res), args.iters)
         total_best += best * cnt
         total_auto += ta * cnt
