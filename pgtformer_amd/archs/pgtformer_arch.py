@@ -370,6 +370,14 @@ class PGTFormer(TDCRQVAE3):
     @torch.no_grad()
     def restore_middle_u8(self, window_u8, w=1.0):
         """Driver fast path (reference: inference.py:12-19): uint8 (3,H,W,3) window -> restored middle
-        frame as uint8 (H,W,3) with floor(clamp(x,0,1)*255), without leaving the device."""
+        frame as uint8 (H,W,3) with floor(clamp(x,0,1)*255), without leaving the device.
+        B windows stacked on the frame axis, (B*3,H,W,3), give (B,H,W,3): B independent windows per forward
+        (the reference accepts only B=1, modules/rstt_layers.py:904; here B>1 == B separate calls)."""
         out, _, _ = self.forward_nhwc(window_u8, w=w)
-        return ops.frame_to_u8(out[self.t // 2])
+        b = out.shape[0] // self.t
+        if b == 1:
+            return ops.frame_to_u8(out[self.t // 2])
+        res = torch.empty((b,) + tuple(out.shape[1:3]) + (3,), device=out.device, dtype=torch.uint8)
+        for i in range(b):
+            ops.frame_to_u8(out[i * self.t + self.t // 2], out=res[i])
+        return res

@@ -18,13 +18,15 @@ from . import parallel
 
 
 class WindowRunner:
-    """Runs the model on 3-frame uint8 windows; optional HIP-graph replay (static shapes)."""
+    """Runs the model on uint8 windows, `batch` independent 3-frame windows per forward; optional HIP-graph
+    replay (static shapes)."""
 
-    def __init__(self, model, w=1.0, use_graph=True, height=512, width=512):
+    def __init__(self, model, w=1.0, use_graph=True, height=512, width=512, batch=1):
         self.model, self.w = model, w
         self.dev = model.dev
         self.t = model.t
-        self.static_in = torch.zeros((self.t, height, width, 3), dtype=torch.uint8, device=self.dev)
+        self.batch = batch
+        self.static_in = torch.zeros((batch * self.t, height, width, 3), dtype=torch.uint8, device=self.dev)
         self.graph = None
         self.static_out = None
         if use_graph:
@@ -42,14 +44,27 @@ class WindowRunner:
         with torch.cuda.graph(self.graph):
             self.static_out = self.model.restore_middle_u8(self.static_in, w=self.w)
 
-    def run(self, window_u8):
-        """window_u8: (3,H,W,3) uint8 device tensor -> restored middle frame (H,W,3) uint8 (device).
-        The returned tensor is overwritten by the next call when graphs are on."""
+    def run(self, windows_u8):
+        """windows_u8: (batch*3,H,W,3) uint8 device tensor (batch windows back to back) -> restored middle
+        frames (batch,H,W,3) uint8 ((H,W,3) when batch == 1).  Overwritten by the next call when graphs are on."""
         if self.graph is None:
-            return self.model.restore_middle_u8(window_u8, w=self.w)
-        self.static_in.copy_(window_u8, non_blocking=True)
+            return self.model.restore_middle_u8(windows_u8, w=self.w)
+        self.static_in.copy_(windows_u8, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+    def run_clip(self, padded, out):
+        """padded: (n+2,H,W,3) u8 = [prev halo, n frames, next halo]; fills out (n,H,W,3) with the restored
+        frames, `batch` windows per forward (the tail batch is padded with repeats of the last window)."""
+        n, b, t = out.shape[0], self.batch, self.t
+        offs = torch.arange(t, device=padded.device)
+        for j in range(0, n, b):
+            idx = torch.arange(j, j + b, device=padded.device).clamp_(max=n - 1)
+            wins = padded[(idx[:, None] + offs[None, :]).reshape(-1)]        # (b*3,H,W,3) gather of u8 frames
+            res = self.run(wins)
+            k = min(b, n - j)
+            out[j:j + k].copy_(res.reshape(b, *res.shape[-3:])[:k])
+        return out
 
 
 def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True):
@@ -58,9 +73,7 @@ def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True):
     local = frames_u8.to(runner.dev, non_blocking=True)
     n_local = local.shape[0]
     padded = parallel.padded_local_clip(local, rank, world, group)   # one all_gather of boundary frames
-    out = torch.empty_like(local)
-    for j in range(n_local):
-        out[j].copy_(runner.run(padded[j:j + 3]))
+    out = runner.run_clip(padded, torch.empty_like(local))
     if world > 1 and gather:
         n_total = torch.tensor([n_local], device=runner.dev)
         torch.distributed.all_reduce(n_total, group=group)
@@ -127,10 +140,11 @@ def main(argv=None):
     ap.add_argument("--fps", type=int, default=30)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "mixed", "fp32"])
     ap.add_argument("--weights", default=None)
+    ap.add_argument("--batch", type=int, default=4, help="independent windows per forward")
     args = ap.parse_args(argv)
     frames = read_frames(args.input_video, args.size, args.size)
     model = load_architecture(args.precision, args.weights)
-    runner = WindowRunner(model, 1.0, True, args.size, args.size)
+    runner = WindowRunner(model, 1.0, True, args.size, args.size, batch=args.batch)
     out = restore_clip(runner, torch.from_numpy(np.ascontiguousarray(frames)))
     write_frames(args.output_video, out.cpu().numpy(), args.fps)
 

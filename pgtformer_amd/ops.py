@@ -313,10 +313,12 @@ def nhwc_to_nchw_f32(x):
     return out
 
 
-def frame_to_u8(x):
+def frame_to_u8(x, out=None):
     """x (H,W,3) activation view -> uint8 (H,W,3): floor(clamp(x,0,1)*255)."""
     h, w, c = x.shape
     assert c == 3
-    out = torch.empty((h, w, 3), device=x.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((h, w, 3), device=x.device, dtype=torch.uint8)
+    assert out.is_contiguous() and tuple(out.shape) == (h, w, 3)
     hip.check(hip.lib().pgt_frame_to_u8(_dt(x), _p(x), x.stride(1), h, w, _p(out), _stream()), "pgt_frame_to_u8")
     return out

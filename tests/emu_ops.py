@@ -214,8 +214,12 @@ def nhwc_to_nchw_f32(x):
     return x.float().permute(0, 3, 1, 2).contiguous()
 
 
-def frame_to_u8(x):
-    return (x.float().clamp(0, 1) * 255).to(torch.uint8)
+def frame_to_u8(x, out=None):
+    r = (x.float().clamp(0, 1) * 255).to(torch.uint8)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
 
 
 ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "layernorm", "channel_stats",

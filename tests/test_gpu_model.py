@@ -203,3 +203,28 @@ def test_stage1_rqvae_matches_reference(models, golden_window):
     assert agree >= 0.999
     if agree == 1.0:
         assert err < 2e-2
+
+
+def test_batched_windows_equal_separate_forwards(models):
+    """B windows per forward == B separate forwards (the reference only accepts B=1, rstt_layers.py:904):
+    f32 to accumulation-order round-off; and the clip runner (batch 2, ragged tail, replicate-padded halos)
+    reproduces the per-window driver policy."""
+    from pgtformer_amd.driver import WindowRunner
+    from pgtformer_amd import parallel
+    from pgtformer_amd.synth import make_clip
+
+    m = models["fp32"]
+    lq, _ = make_clip(3, 512, seed=77)
+    clip = torch.from_numpy(lq).to(DEV)
+    padded = parallel.padded_local_clip(clip, 0, 1)          # [f0, f0, f1, f2, f2]
+    wins = [padded[j:j + 3] for j in range(3)]
+    sep = [m.forward_nhwc(w, w=1.0)[0].float() for w in wins]
+    both = m.forward_nhwc(torch.cat(wins[:2], 0).contiguous(), w=1.0)[0].float()
+    err = max((both[:3] - sep[0]).abs().max().item(), (both[3:] - sep[1]).abs().max().item())
+    _LOG["batch2_vs_separate_f32"] = {"max_abs_err": err}
+    assert err < 2e-3
+    runner = WindowRunner(m, 1.0, use_graph=False, batch=2)
+    out = runner.run_clip(padded, torch.empty_like(clip))
+    for j in range(3):
+        want = (sep[j][1].clamp(0, 1) * 255).to(torch.uint8)
+        assert (out[j].int() - want.int()).abs().max().item() <= 1, j
