@@ -259,7 +259,13 @@ extern "C" int pgt_window_attention(int32_t dtype, const void* qkv, int32_t ldqk
     const int N = T * wh * ww;
     const int hd = C / heads;
     PGT_CHECK(C % heads == 0 && (hd == 32 || hd == 64), "window_attention: head_dim=%d unsupported (32, 64)", hd);
-    PGT_CHECK(N <= 64, "window_attention: %d tokens per window unsupported in this build (<= 64)", N);
+    if (dtype == PGT_BF16) {
+        const int rc = pgt_window_attn_mfma_bf16(qkv, ldqkv, out, ldo, bias, B, T, H, W, C, heads, wh, ww, sh, sw,
+                                                 (hipStream_t)stream);
+        if (rc <= 0) return rc;   // 0 = launched, < 0 = error, 1 = shape not covered by the MFMA kernel
+    }
+    PGT_CHECK(N <= 64, "window_attention: %d tokens per window needs the bf16 MFMA kernel (N %% 48 == 0, <= 192); "
+              "the generic kernel covers N <= 64", N);
     const int grid = B * (H / wh) * (W / ww) * heads;
     hipStream_t st = (hipStream_t)stream;
     const int nmax = N <= 48 ? 48 : 64;

@@ -9,3 +9,7 @@ int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void
 
 // igemm2.hip: LDS-DMA implicit GEMM (bf16, Cin % 64 == 0, 16-byte epilogue legal). `conv_p` is a ConvP.
 int pgt_igemm2_launch(const void* conv_p, int bn, int stages, hipStream_t st);
+
+// window_attn_mfma.hip: bf16 MFMA window attention; returns 1 if the shape is not covered (fall back)
+int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int T, int H,
+                              int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st);

@@ -1,0 +1,197 @@
+// (T,Wh,Ww)-window attention on MFMA (K5 of SURVEY.md §2.3; reference: modules/rstt_layers.py:195-234 with
+// window_partition/reverse :55-88, torch.roll :307-327 and the shift mask :552-568; the same kernel covers the
+// Video-Swin parametrisation of modules/swin.py:85-167 — e.g. 3x8x8 windows, N = 192 tokens, C = 512).
+//
+// One workgroup per (window, head); one wavefront per 48 queries (N = 48 -> 1 wave, N = 192 -> 4 waves).
+// Swapped formulation on 16x16 tiles so that a query lives in ONE lane column:
+//   S^T[key, q]  = K . Q^T        v_mfma_f32_16x16x32_bf16, both operands are 16-byte row gathers straight
+//                                 from the (rolled, partitioned) token rows in HBM — no LDS, no copies
+//   O^T[d, q]   += V^T . P^T      v_mfma_f32_16x16x16_bf16: the 4 accumulator registers of an S^T tile
+//                                 (keys 4g..4g+3 of lane group g) ARE the P^T operand after exp/convert;
+//                                 V^T comes from an LDS image transposed while staging
+// Roll / partition / reverse are address arithmetic (tok[]), the relative-position bias is a dense
+// (heads,N,N) fp32 table read as float4, the 9-region mask is two region-id compares.  Online softmax over
+// 48-key groups (one cross-lane-group max per group), exp2 domain.
+#include "common.h"
+#include "pgt_internal.h"
+
+namespace {
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_t* __restrict__ qkv, int ldqkv,
+                                                                   uint16_t* __restrict__ out, int ldo,
+                                                                   const float* __restrict__ bias, int T_, int H, int W,
+                                                                   int C, int heads, int wh, int ww, int sh, int sw) {
+    constexpr int N = 48 * NW;
+    constexpr int VSTR = N * 2 + 8;   // V^T row stride in bytes (keys contiguous, 8-byte pad)
+    constexpr int KS = HD / 32;       // k-steps of the S^T MFMA
+    constexpr int DT = HD / 16;       // 16-wide head-dim tiles of O^T
+    constexpr float LOG2E = 1.44269504088896340736f;
+    __shared__ __attribute__((aligned(16))) char vt[HD * VSTR];
+    __shared__ int tok[N];
+    __shared__ int reg[N];
+
+    const int tid = threadIdx.x;
+    const int nwx = W / ww, nwy = H / wh;
+    int bid = blockIdx.x;
+    const int head = bid % heads; bid /= heads;
+    const int wx = bid % nwx; bid /= nwx;
+    const int wy = bid % nwy;
+    const int b = bid / nwy;
+    const bool shifted = (sh > 0) || (sw > 0);
+
+    for (int i = tid; i < N; i += 64 * NW) {
+        const int s = i % ww;
+        const int r = (i / ww) % wh;
+        const int d = i / (ww * wh);
+        const int ys = wy * wh + r, xs = wx * ww + s;             // coordinates in the rolled frame
+        const int y = (ys + sh) % H, x = (xs + sw) % W;           // source pixel (roll by -shift)
+        tok[i] = ((b * T_ + d) * H + y) * W + x;
+        const int rh = ys < H - wh ? 0 : (ys < H - sh ? 1 : 2);   // img_mask regions (rstt_layers.py:552-563)
+        const int rw = xs < W - ww ? 0 : (xs < W - sw ? 1 : 2);
+        reg[i] = rh * 3 + rw;
+    }
+    __syncthreads();
+    // ---- V^T image: work item = (key pair, 8-channel chunk); dword = {V[2kp][d], V[2kp+1][d]}
+    for (int it = tid; it < (N / 2) * (HD / 8); it += 64 * NW) {
+        const int kp = it / (HD / 8), c = it % (HD / 8);
+        const uint4 v0 = *reinterpret_cast<const uint4*>(qkv + (long)tok[2 * kp] * ldqkv + 2 * C + head * HD + c * 8);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(qkv + (long)tok[2 * kp + 1] * ldqkv + 2 * C + head * HD + c * 8);
+        const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w};
+        const uint32_t bb[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint32_t*>(vt + (c * 8 + 2 * j) * VSTR + kp * 4) = (a[j] & 0xffffu) | (bb[j] << 16);
+            *reinterpret_cast<uint32_t*>(vt + (c * 8 + 2 * j + 1) * VSTR + kp * 4) = (a[j] >> 16) | (bb[j] & 0xffff0000u);
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, col = lane & 15;
+    const float scale = rsqrtf((float)HD);
+    // Q^T fragments of this wave's 3 query tiles
+    uint4 qf[3][KS];
+    int qidx[3], rq[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+        qidx[qt] = wave * 48 + qt * 16 + col;
+        rq[qt] = reg[qidx[qt]];
+        const uint16_t* qrow = qkv + (long)tok[qidx[qt]] * ldqkv + head * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = *reinterpret_cast<const uint4*>(qrow + ks * 32);
+    }
+    float m[3], l[3];
+    f32x4 o[3][DT];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+        m[qt] = -INFINITY;
+        l[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int kg = 0; kg < NW; ++kg) {   // groups of 48 keys
+        uint4 kf[3][KS];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const uint16_t* krow = qkv + (long)tok[kg * 48 + kt * 16 + col] * ldqkv + C + head * HD + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[kt][ks] = *reinterpret_cast<const uint4*>(krow + ks * 32);
+        }
+        int rk[3][4];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rk[kt][r] = reg[kg * 48 + kt * 16 + 4 * g + r];
+#pragma unroll
+        for (int qt = 0; qt < 3; ++qt) {
+            f32x4 s[3];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[kt][ks]),
+                                                                    __builtin_bit_cast(bf16x8, qf[qt][ks]), s[kt], 0, 0, 0);
+                const float4 bv = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + kg * 48 + kt * 16 + 4 * g);
+                const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[kt][r] * scale + bvv[r];
+                    if (shifted && rk[kt][r] != rq[qt]) v += -100.0f;
+                    v *= LOG2E;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m[qt], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
+            m[qt] = mnew;
+            float lsum = 0.f;
+            uint2 pf[3];
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                float p[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(s[kt][r] - mnew);
+                    lsum += p[r];
+                }
+                pf[kt] = make_uint2(f2bf2(p[0], p[1]), f2bf2(p[2], p[3]));
+            }
+            l[qt] = l[qt] * alpha + lsum;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const uint2 a = *reinterpret_cast<const uint2*>(vt + (dt * 16 + col) * VSTR + (kg * 48 + kt * 16 + 4 * g) * 2);
+                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, a),
+                                                                          __builtin_bit_cast(short4v, pf[kt]), o[qt][dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+        float lt = l[qt];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const float inv = 1.0f / lt;
+        uint16_t* orow = out + (long)tok[qidx[qt]] * ldo + head * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            uint2 w2 = make_uint2(f2bf2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), f2bf2(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
+            *reinterpret_cast<uint2*>(orow + dt * 16) = w2;
+        }
+    }
+}
+
+}  // namespace
+
+// bf16; N = T*wh*ww in {48, 96, 144, 192}; hd in {32, 64}.  Returns 1 when the shape is not covered (caller falls back).
+int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int T, int H,
+                              int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st) {
+    const int N = T * wh * ww, hd = C / heads;
+    if (N % 48 != 0 || N > 192 || (hd != 32 && hd != 64)) return 1;
+    if (ldqkv % 8 != 0 || ldo % 4 != 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7) || ((uintptr_t)bias & 15)) return 1;
+    const int grid = B * (H / wh) * (W / ww) * heads;
+    const int nw = N / 48;
+#define WAM(HD_, NW_)                                                                                             \
+    hipLaunchKernelGGL((window_attn_mfma_kernel<HD_, NW_>), dim3(grid), dim3(64 * NW_), 0, st, (const uint16_t*)qkv, \
+                       ldqkv, (uint16_t*)out, ldo, bias, T, H, W, C, heads, wh, ww, sh, sw)
+    if (hd == 32) {
+        switch (nw) { case 1: WAM(32, 1); break; case 2: WAM(32, 2); break; case 3: WAM(32, 3); break; default: WAM(32, 4); }
+    } else {
+        switch (nw) { case 1: WAM(64, 1); break; case 2: WAM(64, 2); break; case 3: WAM(64, 3); break; default: WAM(64, 4); }
+    }
+#undef WAM
+    PGT_LAUNCH_CHECK();
+    return 0;
+}

@@ -353,3 +353,29 @@ def test_errors_are_reported_not_fatal():
         ops().conv2d(x.to(torch.bfloat16), w.to(torch.bfloat16))
     with pytest.raises(hip.PgtError):
         ops().conv2d(torch.zeros(1, 4, 4, 12), torch.zeros(8, 12))   # CPU tensors: no fallback
+
+
+SWIN_CASES = [(1, 3, 16, 16, 512, (8, 8), (0, 0)), (1, 3, 16, 24, 512, (8, 8), (4, 4)), (2, 3, 8, 16, 256, (8, 8), (4, 4)),
+              (1, 6, 8, 8, 256, (4, 4), (2, 2))]
+
+
+@pytest.mark.parametrize("case", SWIN_CASES)
+def test_window_attention_large_windows_bf16(case):
+    """BASELINE config 5 point: 3x8x8 windows (N = 192 tokens, C = 512) and other N % 48 == 0 shapes run on the
+    MFMA kernel (modules/swin.py parametrisation of the same attention)."""
+    b, t, h, w_, c, win, shift = case
+    heads, dtype = 8, torch.bfloat16
+    n = t * win[0] * win[1]
+    qkv = rnd((b * t * h * w_, 3 * c), 160, dtype)
+    bias = rnd((heads, n, n), 161, torch.float32, 0.5)
+    want = E.window_attention(qkv, bias, b, t, h, w_, c, heads, win, shift)
+    got = ops().window_attention(g(qkv), g(bias), b, t, h, w_, c, heads, win, shift)
+    check(f"winattn_large{case}", got, want, dtype)
+
+
+def test_window_attention_f32_rejects_large_windows():
+    from pgtformer_amd import hip
+    qkv = g(rnd((3 * 8 * 8, 3 * 256), 170))
+    bias = g(rnd((8, 192, 192), 171))
+    with pytest.raises(hip.PgtError, match="tokens per window"):
+        ops().window_attention(qkv, bias, 1, 3, 8, 8, 256, 8, (8, 8), (0, 0))
