@@ -66,8 +66,17 @@ def live_roofline(model, window, precision, nwin):
     achieved = flops / (t_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
     top = sorted(recs, key=lambda r: -r["events"][0].elapsed_time(r["events"][1]))[:5]
+    # HBM traffic of the same kernel from separate rocprofv3 --pmc passes (tools/pmc_traffic.py), if the committed
+    # measurement matches this configuration; bytes per launch, read side corrected x2 for gfx950 (see the file)
+    traffic, tsrc = None, None
+    tp = os.path.join(REPO, "profiles", "r1_igemm_traffic_pmc.json")
+    if os.path.exists(tp):
+        tj = json.load(open(tp))
+        if tj.get("windows_per_forward") == nwin and tj.get("precision") == precision:
+            traffic, tsrc = round(tj["hbm_bytes_per_launch"] / 1e9, 4), "profiles/r1_igemm_traffic_pmc.json (GB per launch)"
     return {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear)", "achieved": round(achieved, 2),
-            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+            "algorithmic_gb_per_launch": round(byts / n / 1e9, 4),
             "windows_per_forward": nwin, "launches_per_forward": n,
             "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3), "avg_launch_us": round(t_ms * 1e3 / n, 2),
             "algorithmic_gb_per_window": round(byts / nwin / 1e9, 3), "igemm_ms_per_window": round(t_ms / nwin, 3),

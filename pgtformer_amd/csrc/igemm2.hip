@@ -33,7 +33,7 @@ __device__ __forceinline__ int swz(int row, int c) {
     return sr * 256 + (((((row & 1) << 3) | c) ^ (sr & 15)) << 4);
 }
 
-template <int BN, int NST>
+template <int BN, int NST, bool FAST>   // FAST: stride 1, no up-sampling, KH*KW <= 32 -> scalar tap offset + row bitmask
 __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
     constexpr int NI = BN / 64;             // 32-wide MFMA tiles per wave along N
     constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
@@ -76,6 +76,23 @@ __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
             a_pix[i] = 0;
         }
     }
+    // FAST gather state: byte offset of the tap-(0,0) source pixel (+ this lane's chunk) and a bit per filter
+    // tap telling whether that tap is inside the image for this row; per K tile the address is then
+    // x + a_base[i] + (uniform tap/channel offset), one add and one select per DMA.
+    int a_base[QA];
+    unsigned a_mask[QA];
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < QA; ++i) {
+            a_base[i] = (int)(((a_pix[i] + (long)a_iy0[i] * p.W + a_ix0[i]) * p.ldx + a_c8[i]) * 2);
+            unsigned mk = 0;
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int iy = a_iy0[i] + t / p.KW, ix = a_ix0[i] + t % p.KW;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mk |= 1u << t;
+            }
+            a_mask[i] = mk;
+        }
+    }
     const char* b_src[QB];
 #pragma unroll
     for (int i = 0; i < QB; ++i) {
@@ -89,13 +106,23 @@ __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
     auto issue = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE;
         char* sb = sa + TILE_A;
+        if (FAST) {
+            const int tap = ky * p.KW + kx;
+            const int s_off = ((ky * p.W + kx) * p.ldx + c0) * 2;   // wave-uniform
 #pragma unroll
-        for (int i = 0; i < QA; ++i) {
-            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-            const char* src = zero;
-            if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv)
-                src = p.x + ((a_pix[i] + (long)(iy >> p.ups) * p.W + (ix >> p.ups)) * p.ldx + c0 + a_c8[i]) * 2;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+            for (int i = 0; i < QA; ++i) {
+                const char* src = ((a_mask[i] >> tap) & 1u) ? p.x + (long)(a_base[i] + s_off) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < QA; ++i) {
+                const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                const char* src = zero;
+                if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv)
+                    src = p.x + ((a_pix[i] + (long)(iy >> p.ups) * p.W + (ix >> p.ups)) * p.ldx + c0 + a_c8[i]) * 2;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < QB; ++i) {
@@ -222,18 +249,24 @@ __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
 
 }  // namespace
 
-template <int BN, int NST> static int launch2(const ConvP& p, hipStream_t st) {
+template <int BN, int NST, bool FAST> static int launch3(const ConvP& p, hipStream_t st) {
     constexpr int bytes = NST * (BM + BN) * 128;
     static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per kernel)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BN, NST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BN, NST, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { pgt_set_error("igemm2: cannot reserve %d B of LDS: %s", bytes, hipGetErrorString(e)); return -12; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm2_kernel<BN, NST>), dim3(p.nbm * p.nbn), dim3(kThreads), bytes, st, p);
+    hipLaunchKernelGGL((igemm2_kernel<BN, NST, FAST>), dim3(p.nbm * p.nbn), dim3(kThreads), bytes, st, p);
     PGT_LAUNCH_CHECK();
     return 0;
+}
+template <int BN, int NST> static int launch2(const ConvP& p, hipStream_t st) {
+    // FAST needs 32-bit byte offsets (tensor < 2 GiB) and a <= 32-tap filter
+    const bool fast = p.stride == 1 && p.ups == 0 && p.KH * p.KW <= 32 &&
+                      (long)p.N * p.H * p.W * p.ldx * 2 < (1L << 31);
+    return fast ? launch3<BN, NST, true>(p, st) : launch3<BN, NST, false>(p, st);
 }
 
 // bf16 only.  bn: 64 | 128; stages: 2 | 3 | 4 (LDS = stages * (128 + bn) * 128 bytes).

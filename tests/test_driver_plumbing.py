@@ -1,0 +1,63 @@
+"""Driver plumbing (BASELINE config 1 geometry: 119 frames of 512x512 rgb24; here a small frame size) on CPU:
+raw rgb24 file I/O, the reference window policy (first/last frame replicated, inference.py:38-74), batching of
+windows with a ragged tail, and output order.  A stub stands in for the model (the real one needs the GPU)."""
+import numpy as np
+import torch
+
+from oracle import pgt_oracle as O
+from pgtformer_amd import driver, parallel
+
+
+class StubModel:
+    """restore_middle_u8(windows) -> for each window: middle frame + (first frame idx encoded) so order is checkable."""
+    t = 3
+    dev = torch.device("cpu")
+
+    def __init__(self):
+        self.seen = []
+
+    def restore_middle_u8(self, win, w=1.0):
+        b = win.shape[0] // 3
+        self.seen += [tuple(int(win[i * 3 + k, 0, 0, 0]) for k in range(3)) for i in range(b)]
+        mid = win.reshape(b, 3, *win.shape[1:])[:, 1]
+        out = (mid.to(torch.int16) + 100).clamp(max=255).to(torch.uint8)
+        return out[0] if b == 1 else out
+
+
+def _clip(n, h=8, w=6):
+    return (torch.arange(n, dtype=torch.uint8).reshape(n, 1, 1, 1).expand(n, h, w, 3)).contiguous()
+
+
+def test_rgb24_roundtrip_and_window_policy(tmp_path):
+    n = 119                                     # the demo clip's frame count
+    clip = _clip(n)
+    path = tmp_path / "in.rgb"
+    clip.numpy().tofile(path)
+    frames = driver.read_frames(str(path), 6, 8)
+    assert frames.shape == (n, 8, 6, 3) and frames.dtype == np.uint8
+    for batch in (1, 4):                        # 119 = 29*4 + 3 -> ragged tail batch
+        model = StubModel()
+        runner = driver.WindowRunner(model, 1.0, use_graph=False, height=8, width=6, batch=batch)
+        out = driver.restore_clip(runner, torch.from_numpy(np.ascontiguousarray(frames)))
+        assert out.shape == (n, 8, 6, 3)
+        assert out[:, 0, 0, 0].tolist() == [i + 100 for i in range(n)]
+        triples = O.window_triples(n)
+        assert model.seen[:n] == triples if batch == 1 else set(triples) <= set(model.seen)
+    driver.write_frames(str(tmp_path / "out.rgb"), out.numpy())
+    back = np.fromfile(tmp_path / "out.rgb", np.uint8).reshape(n, 8, 6, 3)
+    assert np.array_equal(back, out.numpy())
+
+
+def test_single_and_two_frame_clips():
+    for n in (1, 2, 3):
+        model = StubModel()
+        runner = driver.WindowRunner(model, 1.0, use_graph=False, height=8, width=6, batch=2)
+        out = driver.restore_clip(runner, _clip(n))
+        assert out[:, 0, 0, 0].tolist() == [i + 100 for i in range(n)]
+        assert set(O.window_triples(n)) <= set(model.seen)
+
+
+def test_padded_clip_layout():
+    clip = _clip(5)
+    padded = parallel.padded_local_clip(clip, 0, 1)
+    assert padded[:, 0, 0, 0].tolist() == [0, 0, 1, 2, 3, 4, 4]

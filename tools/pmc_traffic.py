@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Aggregate HBM traffic of the implicit-GEMM kernel from two rocprofv3 --pmc passes (rocpd sqlite output):
+
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/fetch -o r -- python bench.py --steps 2 --warmup 1 --no-graph ...
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/write -o r -- python bench.py --steps 2 --warmup 1 --no-graph ...
+  python tools/pmc_traffic.py out/fetch/r_results.db out/write/r_results.db profiles/r1_igemm_traffic_pmc.json
+
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+counts 128-byte requests as 64 B for wide (16 B/lane) coalesced reads, so the read side is doubled.
+"""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(db, counter, like):
+    c = sqlite3.connect(db)
+    rows = c.execute("select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? "
+                     "and kernel_name like ? group by kernel_name", (counter, like)).fetchall()
+    tot = sum(r[1] for r in rows)
+    n = sum(r[2] for r in rows)
+    return tot, n
+
+
+def main(fetch_db, write_db, out):
+    f_kib, nf = per_kernel(fetch_db, "FETCH_SIZE", "%igemm_kernel%")
+    w_kib, nw = per_kernel(write_db, "WRITE_SIZE", "%igemm_kernel%")
+    res = {"kernel": "igemm_kernel", "launches": nf,
+           "fetch_bytes_per_launch_raw": f_kib * 1024 / max(nf, 1),
+           "fetch_bytes_per_launch_corrected_x2": 2 * f_kib * 1024 / max(nf, 1),
+           "write_bytes_per_launch": w_kib * 1024 / max(nw, 1),
+           "hbm_bytes_per_launch": (2 * f_kib * 1024) / max(nf, 1) + w_kib * 1024 / max(nw, 1),
+           "note": "read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE under-count for 16 B/lane streams); "
+                   "Infinity-Cache hits are included in these L2 fabric counters"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
