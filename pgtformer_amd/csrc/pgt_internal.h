@@ -13,3 +13,6 @@ int pgt_igemm2_launch(const void* conv_p, int bn, int stages, hipStream_t st);
 // window_attn_mfma.hip: bf16 MFMA window attention; returns 1 if the shape is not covered (fall back)
 int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int T, int H,
                               int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st);
+
+// igemm3.hip: large-tile LDS-DMA implicit GEMM (bf16, stride 1, no up-sampling, Cin % 64 == 0); 1 = combination not built
+int pgt_igemm3_launch(const void* conv_p, int bm, int bn, int stages, hipStream_t st);

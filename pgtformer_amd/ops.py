@@ -65,7 +65,7 @@ def _ld_rows(x):
 
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
-           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0):
+           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout)."""
     n, h, wd, cin = x.shape
@@ -90,6 +90,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.scalar_epilogue = int(scalar_epi)
     d.kernel = int(kernel)
     d.splitk = int(splitk)
+    d.stages = int(stages)
     dec = shift = None
     if sft is not None:
         dec, shift, sw = sft

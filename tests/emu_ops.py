@@ -35,7 +35,7 @@ def _store(val, out, dtype):
 
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
-           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0):
+           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0):
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     assert w.shape[1] == kh * kw * cin and w.dtype == x.dtype

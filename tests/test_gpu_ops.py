@@ -379,3 +379,32 @@ def test_window_attention_f32_rejects_large_windows():
     bias = g(rnd((8, 192, 192), 171))
     with pytest.raises(hip.PgtError, match="tokens per window"):
         ops().window_attention(qkv, bias, 1, 3, 8, 8, 256, 8, (8, 8), (0, 0))
+
+
+V3_SHAPES = [("v3_c3x3", 2, 20, 24, 64, 128, 3), ("v3_lin_ragged", 1, 1, 333, 256, 72, 1), ("v3_c3x3_wide", 3, 16, 16, 128, 264, 3)]
+V3_TILES = [(256, 128, 2), (256, 128, 3), (256, 256, 2), (128, 256, 2), (128, 256, 3)]
+
+
+@pytest.mark.parametrize("tile", V3_TILES)
+@pytest.mark.parametrize("shape", V3_SHAPES, ids=[s[0] for s in V3_SHAPES])
+def test_conv2d_large_tile_kernel(shape, tile):
+    """igemm3 (256-row / 256-column workgroup tiles, 8-16 waves, LDS-DMA) against the emulation and v1."""
+    name, n, h, w_, cin, cout, k = shape
+    bm, bn, nst = tile
+    dtype = torch.bfloat16
+    x = rnd((n, h, w_, cin), 210, dtype)
+    wt = rnd((cout, k * k * cin), 211, dtype, 1.0 / np.sqrt(k * k * cin))
+    wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
+    b = rnd((cout,), 212, torch.float32, 0.1)
+    kw = dict(kh=k, kw=k, pad=(k // 2,) * 4)
+    v3 = dict(kernel=3, tile=(bm, bn), stages=nst)
+    want = E.conv2d(x, wt, b, act=E.ACT_SILU, **kw)
+    check(f"{name}_{tile}", ops().conv2d(g(x), g(wt), g(b), act=E.ACT_SILU, **v3, **kw), want, dtype)
+    res = rnd(tuple(want.shape), 213, dtype)
+    got = ops().conv2d(g(x), g(wt), g(b), res=g(res), post_relu=True, **v3, **kw)
+    check(f"{name}_{tile}_res", got, E.conv2d(x, wt, b, res=res, post_relu=True, **kw), dtype)
+    v1 = ops().conv2d(g(x), g(wt), g(b), res=g(res), post_relu=True, kernel=1, **kw)
+    check(f"{name}_{tile}_v1", got, v1, dtype, 0.2)
+    dec, shf = rnd(tuple(want.shape), 214, dtype), rnd(tuple(want.shape), 215, dtype)
+    check(f"{name}_{tile}_sft", ops().conv2d(g(x), g(wt), g(b), sft=(g(dec), g(shf), 0.6), **v3, **kw),
+          E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)

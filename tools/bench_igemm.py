@@ -56,12 +56,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="multiply the frame count N (windows per forward)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = "cuda"
     total_best = total_auto = 0.0
     print(f"{'shape':24s} {'GFLOP':>7s} | " + " ".join(f"{bm}x{bn:<3d}(vec/scalar us)".rjust(24) for bm, bn in TILES) + " | auto us  TF/s")
     for name, n, h, w, cin, cout, k, stride, ups, cnt in SHAPES:
+        if n > 1:
+            n *= args.batch
+        else:
+            w *= args.batch
         x = torch.randn((n, h, w, cin), device=dev).to(dt)
         wt = (torch.randn((cout, k * k * cin), device=dev) / (k * k * cin) ** 0.5).to(dt)
         b = torch.randn((cout,), device=dev)
@@ -85,6 +90,13 @@ def main():
                     best = min(best, t2)
                     v2 += f" v2/{bn}s{nst}={t2:6.1f}"
         cells.append(v2)
+        v3 = ""
+        if dt == torch.bfloat16 and cin % 64 == 0 and cout % 8 == 0 and stride == 1 and not ups:
+            for bm, bn, nst in ((256, 128, 2), (256, 128, 3), (256, 256, 2), (128, 256, 2), (128, 256, 3)):
+                t3 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=3, tile=(bm, bn), stages=nst), args.iters)
+                best = min(best, t3)
+                v3 += f" v3/{bm}x{bn}s{nst}={t3:6.1f}"
+        cells.append(v3)
         ta = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res), args.iters)
         total_best += best * cnt
         total_auto += ta * cnt
