@@ -73,6 +73,35 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// Same on 8 values with the (uniform) switch OUTSIDE the element loop: a per-element switch in a fully unrolled
+// accumulator epilogue multiplies the code size by the number of cases (I-cache misses dominate the epilogue).
+__device__ __forceinline__ void apply_act8(float* v, int act) {
+    switch (act) {
+        case ACT_NONE: break;
+        case ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            break;
+        case ACT_GELU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+            break;
+        case ACT_SILU:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.f + expf(-v[e]));
+            break;
+        case ACT_LEAKY02:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+            break;
+        case ACT_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 1.f / (1.f + expf(-v[e]));
+            break;
+        default: break;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

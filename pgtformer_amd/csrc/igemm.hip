@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const int rl = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                            stage[rl * SROW + cl] = apply_act(acc[i][j][e] + bv, p.act);
+                            stage[rl * SROW + cl] = acc[i][j][e] + bv;
                         }
                 }
             }
@@ -244,6 +244,7 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
                 float v[8];
                 *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8);
                 *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8 + 4);
+                apply_act8(v, p.act);
                 if (p.epi == 1) {
                     float d[8], s[8];
                     load8<T>(dec + (long)m * p.ld_dec + n, d);
@@ -475,7 +476,9 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     // least twice (profiles/r1_igemm_shapes_v7.txt: 256->256 3x3 @ 12x128x128 363 -> 300 us)
     if (d->kernel == 0 && v3_legal && d->force_bm == 0 && d->force_bn == 0 && d->Cout % 256 == 0 && p.K >= 1024 &&
         (long)((p.M + 255) / 256) * (d->Cout / 256) >= 512)
-        return pgt_igemm3_launch(&p, 256, 256, 2, st);
+        return pgt_igemm4_launch(&p, st);
+    PGT_CHECK(d->kernel != 4 || v3_legal, "pgt_conv2d: kernel=4 needs bf16, stride 1, no up-sampling, Cin %% 64 == 0");
+    if (d->kernel == 4) return pgt_igemm4_launch(&p, st);
     if (d->kernel == 3) {
         const int rc = pgt_igemm3_launch(&p, d->force_bm ? d->force_bm : 256, d->force_bn ? d->force_bn : 128,
                                          d->stages ? d->stages : 3, st);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
     constexpr int QB = BN / 32;
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // NST * STAGE bytes
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int nblk = p.nbm * p.nbn;
     const int bid = blockIdx.x;
@@ -104,15 +104,15 @@ __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
     int ky = 0, kx = 0, c0 = 0;   // filter tap and first input channel of the current K tile (uniform)
 
     auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE;
-        char* sb = sa + TILE_A;
+        const unsigned sa = lds_addr(smem) + stage * STAGE;
+        const unsigned sb = sa + TILE_A;
         if (FAST) {
             const int tap = ky * p.KW + kx;
             const int s_off = ((ky * p.W + kx) * p.ldx + c0) * 2;   // wave-uniform
 #pragma unroll
             for (int i = 0; i < QA; ++i) {
                 const char* src = ((a_mask[i] >> tap) & 1u) ? p.x + (long)(a_base[i] + s_off) : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+                glds16(src, sa + (wave + 4 * i) * 1024);
             }
         } else {
 #pragma unroll
@@ -121,13 +121,13 @@ __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
                 const char* src = zero;
                 if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv)
                     src = p.x + ((a_pix[i] + (long)(iy >> p.ups) * p.W + (ix >> p.ups)) * p.ldx + c0 + a_c8[i]) * 2;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+                glds16(src, sa + (wave + 4 * i) * 1024);
             }
         }
 #pragma unroll
         for (int i = 0; i < QB; ++i) {
             const char* src = b_src[i] ? b_src[i] + (long)kt * 128 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (wave + 4 * i) * 1024), 16, 0, 0);
+            glds16(src, sb + (wave + 4 * i) * 1024);
         }
         c0 += 64;
         if (c0 == p.Cin) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int rl = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        stage[rl * SROW + cl] = apply_act(acc[i][j][e] + bv, p.act);
+                        stage[rl * SROW + cl] = acc[i][j][e] + bv;
                     }
             }
         }
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(kThreads) void igemm2_kernel(ConvP p) {
             float v[8];
             *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8);
             *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8 + 4);
+            apply_act8(v, p.act);
             if (p.epi == 1) {
                 float d[8], s[8];
                 load8<bf16_t>(dec + (long)m * p.ld_dec + n, d);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm3_kernel(Conv
     static_assert(QA >= 1 && QB >= 1 && (BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "tile/wave mismatch");
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // NST * STAGE bytes
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int nblk = p.nbm * p.nbn;
     const int bid = blockIdx.x;
@@ -79,19 +79,19 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm3_kernel(Conv
     int ky = 0, kx = 0, c0 = 0;   // filter tap and first input channel of the next K tile to issue (uniform)
 
     auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE;
-        char* sb = sa + TILE_A;
+        const unsigned sa = lds_addr(smem) + stage * STAGE;
+        const unsigned sb = sa + TILE_A;
         const int tap = ky * p.KW + kx;
         const int s_off = ((ky * p.W + kx) * p.ldx + c0) * 2;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < QA; ++i) {
             const char* src = ((a_mask[i] >> tap) & 1u) ? p.x + (long)(a_base[i] + s_off) : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (wave + NWAVES * i) * 1024), 16, 0, 0);
+            glds16(src, sa + (wave + NWAVES * i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < QB; ++i) {
             const char* src = b_src[i] ? b_src[i] + (long)kt * 128 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (wave + NWAVES * i) * 1024), 16, 0, 0);
+            glds16(src, sb + (wave + NWAVES * i) * 1024);
         }
         c0 += 64;
         if (c0 == p.Cin) {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm3_kernel(Conv
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int rl = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        stage[rl * SROW + cl] = apply_act(acc[i][j][e] + bv, p.act);
+                        stage[rl * SROW + cl] = acc[i][j][e] + bv;
                     }
             }
         }
@@ -184,6 +184,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void igemm3_kernel(Conv
             float v[8];
             *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8);
             *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8 + 4);
+            apply_act8(v, p.act);
             if (p.epi == 1) {
                 float d[8], s[8];
                 load8<bf16_t>(dec + (long)m * p.ld_dec + n, d);

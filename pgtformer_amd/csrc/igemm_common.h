@@ -43,6 +43,36 @@ struct ConvP {
 
 
 namespace {
+// LDS-DMA of 16 bytes per lane (1 KiB per wave) as ONE opaque statement: dst = wave-uniform LDS byte address (lane l
+// lands at dst + 16 l), src = the lane's global pointer.  Issued through inline asm on purpose: hipcc does not model
+// the transfer, so it neither drains it (s_waitcnt vmcnt(0)) ahead of the next ds_read nor at barriers; completion is
+// the caller's counted `s_waitcnt vmcnt(N)` followed by a workgroup barrier.  M0 is saved/restored inside the string.
+__device__ __forceinline__ void glds16(const void* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+// The same through a buffer descriptor: source = rsrc.base + voff (per lane) + soff (wave-uniform); a lane whose
+// voff is outside [0, num_records) transfers zeros (used for padding and ragged edges).
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long b = (unsigned long)base;
+    v4i r;
+    r.x = (int)(unsigned)b;
+    r.y = (int)(unsigned)((b >> 32) & 0xffffu);   // stride 0: raw buffer, range-checked in bytes
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void bufdma16(unsigned voff, v4i rsrc, int soff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+
 // Byte offset of (row, 16-byte chunk c) inside an UNPADDED tile of 128-byte rows, XOR-swizzled so that
 // ds_read_b128 fragment reads (32 rows, same chunk) and 16-byte staging writes are bank-conflict free:
 // a 256-byte super row holds two tile rows (16 slots); slot' = slot ^ (superrow & 15).

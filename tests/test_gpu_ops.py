@@ -408,3 +408,35 @@ def test_conv2d_large_tile_kernel(shape, tile):
     dec, shf = rnd(tuple(want.shape), 214, dtype), rnd(tuple(want.shape), 215, dtype)
     check(f"{name}_{tile}_sft", ops().conv2d(g(x), g(wt), g(b), sft=(g(dec), g(shf), 0.6), **v3, **kw),
           E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)
+
+
+V4_SHAPES = V3_SHAPES + [("v4_1tile_k64", 1, 8, 8, 64, 64, 1), ("v4_odd_ktiles", 1, 24, 40, 192, 320, 3),
+                         ("v4_big", 4, 64, 64, 256, 256, 3)]
+
+
+@pytest.mark.parametrize("shape", V4_SHAPES, ids=[s[0] for s in V4_SHAPES])
+def test_conv2d_phased_kernel(shape):
+    """igemm4 (256x256 tile, 8 waves, phase-interleaved LDS-DMA schedule) against the emulation and v1, plus a
+    repeat-run screen: the hand-placed vmcnt/barrier schedule must give bit-identical results on every launch."""
+    name, n, h, w_, cin, cout, k = shape
+    dtype = torch.bfloat16
+    x = rnd((n, h, w_, cin), 310, dtype)
+    wt = rnd((cout, k * k * cin), 311, dtype, 1.0 / np.sqrt(k * k * cin))
+    wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
+    b = rnd((cout,), 312, torch.float32, 0.1)
+    kw = dict(kh=k, kw=k, pad=(k // 2,) * 4)
+    gx, gw, gb = g(x), g(wt), g(b)
+    want = E.conv2d(x, wt, b, act=E.ACT_SILU, **kw)
+    check(f"{name}_v4", ops().conv2d(gx, gw, gb, act=E.ACT_SILU, kernel=4, **kw), want, dtype)
+    res = rnd(tuple(want.shape), 313, dtype)
+    gres = g(res)
+    got = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=4, **kw)
+    check(f"{name}_v4_res", got, E.conv2d(x, wt, b, res=res, post_relu=True, **kw), dtype)
+    v1 = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=1, **kw)
+    check(f"{name}_v4_v1", got, v1, dtype, 0.2)
+    for _ in range(20):
+        again = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=4, **kw)
+        assert torch.equal(again, got), f"{name}: igemm4 is not run-to-run deterministic"
+    dec, shf = rnd(tuple(want.shape), 314, dtype), rnd(tuple(want.shape), 315, dtype)
+    check(f"{name}_v4_sft", ops().conv2d(gx, gw, gb, sft=(g(dec), g(shf), 0.6), kernel=4, **kw),
+          E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)

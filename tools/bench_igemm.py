@@ -56,6 +56,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--quick", action="store_true")
     ap.add_argument("--batch", type=int, default=1, help="multiply the frame count N (windows per forward)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -78,6 +79,8 @@ def main():
         cells = []
         best = 1e30
         for bm, bn in TILES:
+            if args.quick and (bm, bn) == (128, 128):
+                continue
             tv = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res, tile=(bm, bn)), args.iters)
             ts = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res, tile=(bm, bn), scalar_epi=True), args.iters)
             best = min(best, tv, ts)
@@ -92,10 +95,13 @@ def main():
         cells.append(v2)
         v3 = ""
         if dt == torch.bfloat16 and cin % 64 == 0 and cout % 8 == 0 and stride == 1 and not ups:
-            for bm, bn, nst in ((256, 128, 2), (256, 128, 3), (256, 256, 2), (128, 256, 2), (128, 256, 3)):
+            for bm, bn, nst in ((256, 256, 2),):
                 t3 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=3, tile=(bm, bn), stages=nst), args.iters)
                 best = min(best, t3)
                 v3 += f" v3/{bm}x{bn}s{nst}={t3:6.1f}"
+            t4 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=4), args.iters)
+            best = min(best, t4)
+            v3 += f" v4={t4:6.1f}"
         cells.append(v3)
         ta = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res), args.iters)
         total_best += best * cnt
