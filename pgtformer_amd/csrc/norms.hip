@@ -31,16 +31,32 @@ __global__ __launch_bounds__(kT) void gn_partial_kernel(const T* __restrict__ x,
     const int p_begin = blk * pix_per_blk;
     const int p_end = min(HW, p_begin + pix_per_blk);
     if (active) {
-        for (int p = p_begin + slot; p < p_end; p += PS) {
-            const T* row = x + ((long)n * HW + p) * ldx;
+        // kU pixels per trip, all loads issued before the first add: one 16-byte load in flight per thread cannot
+        // cover the HBM latency (2.6 TB/s measured); accumulation order per thread is unchanged (ascending pixels).
+        constexpr int kU = 4;
+        for (int p = p_begin + slot; p < p_end; p += kU * PS) {
+            uint4 v[kU][NQ];
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const int q = q0 + j * kT;
-                if (q < QC) {
-                    float f[CH];
-                    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(row + q * CH), f);
+            for (int u = 0; u < kU; ++u) {
+                const int pu = p + u * PS;
+                const T* row = x + ((long)n * HW + (pu < p_end ? pu : p)) * ldx;
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) { s[j][e] += f[e]; ss[j][e] += f[e] * f[e]; }
+                for (int j = 0; j < NQ; ++j) {
+                    const int q = q0 + j * kT;
+                    v[u][j] = q < QC ? *reinterpret_cast<const uint4*>(row + q * CH) : make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (p + u * PS >= p_end) break;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    if (q0 + j * kT < QC) {
+                        float f[CH];
+                        Vec16<T>::unpack(v[u][j], f);
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) { s[j][e] += f[e]; ss[j][e] += f[e] * f[e]; }
+                    }
                 }
             }
         }
@@ -107,6 +123,50 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, int nblk, int
     }
 }
 
+// Activation of CH values with the (uniform) switch outside the element loop.  bf16 tensors take the hardware
+// exp2 / rcp forms of SiLU and sigmoid (relative error ~1e-6, far below the bf16 rounding of the result: this kernel
+// is otherwise VALU-bound on the IEEE division); fp32 tensors keep the exact expf / division of the parity path.
+template <typename T, int CH> __device__ __forceinline__ void act_vec(float* f, int act) {
+    if constexpr (sizeof(T) == 2) {
+        if (act == ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+                f[e] = f[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f[e]));
+            return;
+        }
+        if (act == ACT_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+                f[e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f[e]));
+            return;
+        }
+    }
+    switch (act) {
+        case ACT_NONE: break;
+        case ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] = apply_act(f[e], ACT_RELU);
+            break;
+        case ACT_GELU:
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] = apply_act(f[e], ACT_GELU);
+            break;
+        case ACT_SILU:
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] = apply_act(f[e], ACT_SILU);
+            break;
+        case ACT_LEAKY02:
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] = apply_act(f[e], ACT_LEAKY02);
+            break;
+        case ACT_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] = apply_act(f[e], ACT_SIGMOID);
+            break;
+        default: break;
+    }
+}
+
 // y = act(x*scale[n,c] + shift[n,c])
 template <typename T, int NQ>
 __global__ __launch_bounds__(kT) void affine_act_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
@@ -132,18 +192,35 @@ __global__ __launch_bounds__(kT) void affine_act_kernel(const T* __restrict__ x,
     }
     const int p_begin = blockIdx.x * pix_per_blk;
     const int p_end = min(HW, p_begin + pix_per_blk);
-    for (int p = p_begin + slot; p < p_end; p += PS) {
-        const T* row = x + ((long)n * HW + p) * ldx;
-        T* orow = y + ((long)n * HW + p) * ldy;
+    constexpr int kU = 4;   // pixels per trip, loads first (see gn_partial_kernel)
+    for (int p = p_begin + slot; p < p_end; p += kU * PS) {
+        uint4 v[kU][NQ];
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int q = q0 + j * kT;
-            if (q < QC) {
-                float f[CH];
-                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(row + q * CH), f);
+        for (int u = 0; u < kU; ++u) {
+            const int pu = p + u * PS;
+            const T* row = x + ((long)n * HW + (pu < p_end ? pu : p)) * ldx;
 #pragma unroll
-                for (int e = 0; e < CH; ++e) f[e] = apply_act(f[e] * sc[j][e] + sh[j][e], act);
-                *reinterpret_cast<uint4*>(orow + q * CH) = Vec16<T>::pack(f);
+            for (int j = 0; j < NQ; ++j) {
+                const int q = q0 + j * kT;
+                v[u][j] = q < QC ? *reinterpret_cast<const uint4*>(row + q * CH) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int pu = p + u * PS;
+            if (pu >= p_end) break;
+            T* orow = y + ((long)n * HW + pu) * ldy;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = q0 + j * kT;
+                if (q < QC) {
+                    float f[CH];
+                    Vec16<T>::unpack(v[u][j], f);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) f[e] = f[e] * sc[j][e] + sh[j][e];
+                    act_vec<T, CH>(f, act);
+                    *reinterpret_cast<uint4*>(orow + q * CH) = Vec16<T>::pack(f);
+                }
             }
         }
     }

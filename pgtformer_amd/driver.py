@@ -8,6 +8,7 @@ CLI:  python -m pgtformer_amd.driver -i in.{rgb|mp4} -o out.{rgb|mp4} [--size 51
       (mp4 needs an `ffmpeg` binary on PATH; .rgb is raw rgb24, W*H*3 bytes per frame)
 """
 import argparse
+import os
 import shutil
 import subprocess
 
@@ -30,6 +31,9 @@ class WindowRunner:
         self.graph = None
         self.static_out = None
         if use_graph:
+            if os.environ.get("PGT_AUTOTUNE", "1") != "0" and self.dev.type == "cuda":
+                from . import ops   # per-shape kernel selection during the eager warm-up passes (bf16 launches only)
+                ops.enable_autotune()
             self._capture()
 
     def _capture(self):

@@ -64,6 +64,41 @@ def _ld_rows(x):
     return x.stride(0) if x.shape[0] > 1 else max(x.shape[1], x.stride(0))
 
 
+# Per-shape kernel selection ("find" mode): with enable_autotune() every new bf16 conv/linear signature is timed once
+# (outside graph capture) over the built kernel/tile variants and the fastest one is cached; the library's static
+# heuristic stays one of the candidates, so tuning never loses to it.  fp32 (parity) launches are never tuned.
+AUTOTUNE = None
+_TUNE_CANDIDATES = ((0, (0, 0), 0), (1, (64, 64), 0), (1, (64, 128), 0), (1, (128, 64), 0), (1, (128, 128), 0),
+                    (3, (256, 256), 2), (4, (0, 0), 0))
+
+
+def enable_autotune(flag=True):
+    global AUTOTUNE
+    AUTOTUNE = ({} if AUTOTUNE is None else AUTOTUNE) if flag else None
+
+
+def _tune_conv(d, args, device, iters=4):
+    L = hip.lib()
+    best, best_t = _TUNE_CANDIDATES[0], None
+    for cand in _TUNE_CANDIDATES:
+        d.kernel, (d.force_bm, d.force_bn), d.stages = cand
+        ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device) if ws_bytes else None
+        call = lambda: L.pgt_conv2d_ws(C.byref(d), *args, _p(ws), ws_bytes, _stream())  # noqa: E731
+        if call() != 0:
+            continue   # variant not legal for this shape
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call()
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if best_t is None or t < best_t * (0.97 if cand[0] else 1.0):
+            best, best_t = cand, t
+    return best
+
+
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
@@ -103,6 +138,14 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     L = hip.lib()
+    if (AUTOTUNE is not None and kernel == 0 and tile == (0, 0) and splitk == 0 and not scalar_epi
+            and x.dtype == torch.bfloat16):
+        key = (n, h, wd, cin, d.ldx, d.ups, kh, kw, stride, tuple(pad), cout, d.ldy, act, d.post_relu, d.ldr, d.epi,
+               d.ld_dec, d.ld_shift, d.out_f32, bias is None)
+        cfg = AUTOTUNE.get(key)
+        if cfg is None and not torch.cuda.is_current_stream_capturing():
+            cfg = AUTOTUNE[key] = _tune_conv(d, (_p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out)), x.device)
+        d.kernel, (d.force_bm, d.force_bn), d.stages = cfg if cfg is not None else (0, (0, 0), 0)
     ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None   # split-K scratch
     hip.check(L.pgt_conv2d_ws(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out), _p(ws),
