@@ -66,6 +66,17 @@ def live_roofline(model, window, precision, nwin):
     achieved = flops / (t_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
     top = sorted(recs, key=lambda r: -r["events"][0].elapsed_time(r["events"][1]))[:5]
+    if os.environ.get("PGT_DUMP_SHAPES"):   # per-shape table of the instrumented pass (tuning aid)
+        agg = {}
+        for r in recs:
+            a = agg.setdefault((r["shape"], r.get("cfg")), [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += r["events"][0].elapsed_time(r["events"][1]) * 1e3
+            a[2] += r["flops"]
+        with open(os.environ["PGT_DUMP_SHAPES"], "w") as f:
+            f.write("shape(N,H,W,Cin,Cout,k,stride,ups) cfg(kernel,bm,bn) launches total_us avg_us TFLOP/s\n")
+            for (shape, cfg), (cnt, us, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{shape} {cfg} {cnt} {us:.1f} {us / cnt:.1f} {fl / us / 1e6:.1f}\n")
     # HBM traffic of the same kernel from separate rocprofv3 --pmc passes (tools/pmc_traffic.py), if the committed
     # measurement matches this configuration; bytes per launch, read side corrected x2 for gfx950 (see the file)
     traffic, tsrc = None, None

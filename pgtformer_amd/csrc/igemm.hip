@@ -476,9 +476,16 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     // least twice (profiles/r1_igemm_shapes_v7.txt: 256->256 3x3 @ 12x128x128 363 -> 300 us)
     if (d->kernel == 0 && v3_legal && d->force_bm == 0 && d->force_bn == 0 && d->Cout % 256 == 0 && p.K >= 1024 &&
         (long)((p.M + 255) / 256) * (d->Cout / 256) >= 512)
-        return pgt_igemm4_launch(&p, st);
-    PGT_CHECK(d->kernel != 4 || v3_legal, "pgt_conv2d: kernel=4 needs bf16, stride 1, no up-sampling, Cin %% 64 == 0");
-    if (d->kernel == 4) return pgt_igemm4_launch(&p, st);
+        return pgt_igemm4_launch(&p, 256, st);
+    // v4 (phase-interleaved 8-wave schedule; 256x256 or 512x128 tiles): any stride, nearest-2x up-sampling allowed
+    const bool v4_legal = v2_legal && d->KH * d->KW <= 30 && (long)d->N * d->H * d->W * d->ldx * 2 < (1L << 31) &&
+                          (long)d->Cout * p.K * 2 < (1L << 31);
+    PGT_CHECK(d->kernel != 4 || v4_legal, "pgt_conv2d: kernel=4 needs bf16, Cin %% 64 == 0, <= 30 taps, tensors < 2 GiB");
+    if (d->kernel == 4) {
+        const int rc = pgt_igemm4_launch(&p, d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256), st);
+        PGT_CHECK(rc != 1, "pgt_conv2d: kernel=4 has no %d-column tile (128, 256)", d->force_bn);
+        return rc;
+    }
     if (d->kernel == 3) {
         const int rc = pgt_igemm3_launch(&p, d->force_bm ? d->force_bm : 256, d->force_bn ? d->force_bn : 128,
                                          d->stages ? d->stages : 3, st);

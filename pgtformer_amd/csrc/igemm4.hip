@@ -1,37 +1,45 @@
-// Implicit-GEMM conv / linear, 256x256 tile, 8 waves, phase-interleaved schedule (bf16, gfx950).
+// Implicit-GEMM conv / linear with the phase-interleaved 8-wave schedule (bf16, gfx950).
+// Workgroup tiles 256x256 (waves 2 x 4) and 512x128 (waves 4 x 2); every wave owns 128 x 64 outputs.
 //
 // Why another kernel: igemm.hip / igemm2.hip / igemm3.hip all run "wait for the K tile -> barrier -> read fragments ->
 // MFMA" once per K tile, so the matrix pipes idle while fragments are read and while the barrier collects the waves
 // (MFMA busy 25-35 %, profiles/r1_igemm_pmc.md).  This kernel follows the CDNA4 guide's 8-phase structure instead:
 //
-//   * 8 waves as 2 (M) x 4 (N); each wave owns 128 x 64 outputs = 4 x 2 accumulators of 32x32 (128 acc registers).
+//   * 8 waves as WR (M) x WC (N); each wave owns 128 x 64 outputs = 4 x 2 accumulators of 32x32 (128 acc registers).
 //   * one K tile (64 deep) is consumed in FOUR phases, one 64 x 32 quadrant of the wave tile each (8 MFMAs):
 //     (A0,B0) (A0,B1) (A1,B1) (A1,B0) - fragment reads per phase 12 / 4 / 8 / 0.
-//   * the two wave rows run one barrier apart (wave row 1 executes one extra s_barrier up front, wave row 0 one at the
-//     end): while one row multiplies, the other one reads its fragments and issues DMA - each SIMD holds one wave of
-//     each row, so its matrix pipe always has a wave in the MFMA segment.
-//   * global -> LDS by LDS-DMA (glds16, inline asm so that hipcc does not drain it) in UNITS of 16 KiB = the rows that
-//     one phase reads: A0 = rows {0..63, 128..191}, A1 = the other rows, B0 = columns {64c..64c+31}, B1 the rest.
-//     Unit s = 4 kt + {A0,B0,B1,A1} is issued in phase g = s - 6 and first read in phase 4 kt + {0,0,1,2}:
-//       WAR  the previous occupant of the same LDS bytes (K tile kt-2) was last read >= 2 phases before the issue, so
-//            both wave rows have retired those reads and passed a barrier;
-//       RAW  after issuing, every wave waits vmcnt(8) (= at most the 4 newest units in flight) BEFORE the phase's first
-//            barrier, which retires every unit read in the NEXT phase - by either wave row.
-//     So four units (64 KiB) are always in flight and nothing is ever waited for within 4 phases of its issue.
+//   * waves 4-7 run one barrier behind waves 0-3 (they execute one extra s_barrier up front, waves 0-3 one at the
+//     end): while one half multiplies, the other one reads its fragments and issues DMA - each SIMD holds one wave of
+//     each half, so its matrix pipe always has a wave in the MFMA segment.
+//   * global -> LDS by LDS-DMA through buffer descriptors (bufdma16: inline asm, so hipcc does not drain it) in UNITS
+//     = the rows one phase reads: A0 = rows {128g .. 128g+63}, A1 = the other rows, B0 = columns {64c .. 64c+31}, B1
+//     the rest.  K tile kt's units are issued in phases 4kt-6 (A0), 4kt-5 (B0), 4kt-4 (B1), 4kt-3 (A1) - for the
+//     512-row tile half of each A unit moves to the neighbouring B phase (3-2-2-3 instead of 1-4-4-1 DMAs per
+//     phase) - and first read in phases 4kt + {0, 0, 1, 2}:
+//       WAR  the bytes a unit overwrites (K tile kt-2) were last read >= 2 phases before the issue, so both wave
+//            halves have retired those reads and passed a barrier;
+//       RAW  after its issues every phase waits vmcnt(NV), NV = the wave's DMA count of any 4 consecutive phases,
+//            BEFORE its first barrier: that retires everything issued >= 4 phases earlier, i.e. every unit read in
+//            the NEXT phase - by either half.
+//     So a full K tile (64-80 KiB) is always in flight and nothing is waited for within 4 phases of its issue.
+//   * padding taps, rows >= M and columns >= Cout use an out-of-range buffer offset (the DMA then writes zeros); the
+//     per-lane source offset of the current filter tap is recomputed when the tap changes (every Cin/64 K tiles),
+//     which also covers strided and nearest-2x up-sampled inputs; the K-tile channel offset is the scalar soffset.
 //
-// Swizzle (swz128) and epilogue as igemm3.hip; stride 1, no up-sampling, Cin % 64 == 0.
+// Swizzle (swz128) and epilogue as igemm3.hip.  Preconditions: bf16, Cin % 64 == 0, KH*KW <= 30, tensors < 2 GiB.
 #include "common.h"
 #include "pgt_internal.h"
 #include "igemm_common.h"
 
 // Probe hooks (tools/igemm4_probe.hip compiles this file with -DPGT_PROBE=<bits>; the library build has none):
-//   1 no DMA in the main loop   2 no fragment reads   4 no s_setprio   8 no wave-row stagger   16 no epilogue
-//   32 time stamps (s_memtime) of wave 0 into g_pgt_probe_ts[block][4]: start, loop start, loop end, end
+//   1 no DMA in the main loop   2 no fragment reads   4 no s_setprio   8 no wave stagger   16 no epilogue
+//   32 time stamps (s_memtime) of wave 0 into g_pgt_probe_ts[block][8]: start, loop start, loop end, end,
+//      addresses ready (before the first DMA), prologue DMA issued
 #ifndef PGT_PROBE
 #define PGT_PROBE 0
 #endif
 #if PGT_PROBE & 32
-__device__ unsigned long long g_pgt_probe_ts[4096][4];
+__device__ unsigned long long g_pgt_probe_ts[4096][8];
 #define PGT_STAMP(i) do { if (tid == 0) g_pgt_probe_ts[blockIdx.x & 4095][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PGT_STAMP(i) do {} while (0)
@@ -39,104 +47,168 @@ __device__ unsigned long long g_pgt_probe_ts[4096][4];
 
 namespace {
 
-constexpr int TILE4 = 256 * 128;        // bytes of one operand tile (256 rows of 64 bf16)
-constexpr int STAGE4 = 2 * TILE4;       // A tile + B tile
-
 #define PGT_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PGT_BARRIER() do { PGT_FENCE(); __builtin_amdgcn_s_barrier(); PGT_FENCE(); } while (0)
+#define PGT_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// dynamic LDS: two K-tile stages, or the fp32 epilogue stage of WR*64 rows if that is larger
+constexpr int lds_bytes4(int wr, int wc) {
+    const int stages = 2 * (wr * 128 + wc * 64) * 128, epi = wr * 64 * (wc * 64 + 4) * 4;
+    return stages > epi ? stages : epi;
+}
+
+template <int WR, int WC, bool UPS>
 __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 * STAGE4 bytes
+    static_assert(WR * WC == 8, "8 waves");
+    constexpr int BM = WR * 128, BN = WC * 64;
+    constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;   // bytes; K tile = 64 bf16 = 128 B
+    constexpr int PA = WR, PB = WC / 2;          // DMA pieces (8 rows x 128 B) per wave in one A / B unit
+    constexpr int NV = 2 * (PA + PB);            // pieces issued in any 4 consecutive phases = allowed in flight
+    constexpr int SA = PA > 2 ? PA / 2 : 0;      // A pieces moved to the neighbouring B phase (evens out 4-2-... issue)
+    constexpr int kLds = lds_bytes4(WR, WC);
+    static_assert(PB >= 1 && 2 * STAGE <= kLds && kLds <= 160 * 1024, "tile");
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // kLds bytes
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WC, wc = wave % WC;
+    const int late = wave >> 2;   // waves 4-7 share SIMDs with 0-3 and run one barrier behind them
     const int nblk = p.nbm * p.nbn;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
     const int sw = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (sw / p.nbn) * 256;
-    const int n0 = (sw % p.nbn) * 256;
+    const int m0 = (sw / p.nbn) * BM;
+    const int n0 = (sw % p.nbn) * BN;
     const unsigned lds0 = lds_addr(smem);
     PGT_STAMP(0);
 
-    // ---- DMA roles.  A piece (h, g): tile rows g*128 + h*64 + wave*8 .. +7.  B piece (h, g): j = wave + 8g,
-    //      tile columns (j>>2)*64 + h*32 + (j&3)*8 .. +7.  Lane l lands in slot (l & 15) of super row r0/2 + (l >> 4)
-    //      and therefore fetches the inverse-swizzled (row, chunk).
-    //      Sources are addressed through buffer descriptors: voffset = the lane's pixel / weight-row byte offset (or
-    //      kOob for padding taps, rows >= M, columns >= Cout: an out-of-range buffer load returns zeros), soffset =
-    //      the wave-uniform tap / channel / K-tile offset.  The A descriptor's base is moved back by the top-left
-    //      padding so that voffset is the UNPADDED pixel address (never negative).
-    constexpr unsigned kOob = 0x80000000u;
-    const long x_back = ((long)p.pad_t * p.W + p.pad_l) * p.ldx * 2;
-    const v4i rsrc_x = make_rsrc(p.x - x_back, (unsigned)((long)p.N * p.H * p.W * p.ldx * 2 + x_back));
+    // ---- DMA roles.  A piece (h, g): tile rows g*128 + h*64 + wave*8 .. +7 (g < WR).  B piece (h, g): j = wave + 8g
+    //      (g < PB), tile columns (j>>2)*64 + h*32 + (j&3)*8 .. +7.  Lane l lands in slot (l & 15) of super row
+    //      r0/2 + (l >> 4) and therefore fetches the inverse-swizzled (row, chunk).
+    //      a_pix = byte offset of the input pixel under filter tap (0,0) (may be "negative" for padding: only used
+    //      when the tap is valid), a_mask = valid-tap bits (+ the output pixel's y/x parity in bits 30/31 for UPS).
+    const v4i rsrc_x = make_rsrc(p.x, (unsigned)((long)p.N * p.H * p.W * p.ldx * 2));
     const v4i rsrc_w = make_rsrc(p.w, (unsigned)((long)p.Cout * p.K * 2));
-    unsigned a_pix[2][2], a_mask[2][2], a_sel[2][2], b_off[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            {
-                const int r0 = g * 128 + h * 64 + wave * 8;
-                const int sr = (r0 >> 1) + (lane >> 4);
-                const int slot = (lane & 15) ^ (sr & 15);
-                const int m = m0 + 2 * sr + (slot >> 3);
-                const int c8 = (slot & 7) * 8;
-                unsigned mk = 0, pix = 0;
-                if (m < p.M) {
-                    const int ox = m % p.Wo;
-                    const int t = m / p.Wo;
-                    const int oy = t % p.Ho;
-                    pix = (unsigned)(((((long)(t / p.Ho) * p.H + oy) * p.W + ox) * p.ldx + c8) * 2);
-                    int tt = 0;
-                    for (int fy = 0; fy < p.KH; ++fy)
-                        for (int fx = 0; fx < p.KW; ++fx, ++tt) {
-                            const int iy = oy - p.pad_t + fy, ix = ox - p.pad_l + fx;
-                            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mk |= 1u << tt;
-                        }
-                }
-                a_pix[h][g] = pix;
-                a_mask[h][g] = mk;
-                a_sel[h][g] = (mk & 1u) ? pix : kOob;
-            }
-            {
-                const int j = wave + 8 * g;
-                const int cc = (j >> 2) * 64 + h * 32 + (j & 3) * 8;
-                const int sr = (cc >> 1) + (lane >> 4);
-                const int slot = (lane & 15) ^ (sr & 15);
-                const int n = n0 + 2 * sr + (slot >> 3);
-                b_off[h][g] = n < p.Cout ? (unsigned)((n * p.K + (slot & 7) * 8) * 2) : kOob;
-            }
-        }
+    const int Hv = UPS ? 2 * p.H : p.H, Wv = UPS ? 2 * p.W : p.W;   // virtual (up-sampled) input size
+    const bool pointwise = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0;
+    int a_pix[2][PA];
+    unsigned a_mask[2][PA], a_sel[2][PA], b_off[2][PB];
+    int ky = 0, kx = 0, c0 = 0;   // filter tap / first channel of the K tile whose A units are issued next (uniform)
 
-    // issue state: filter tap / first channel of the K tile whose A units are issued next (wave-uniform)
-    int ky = 0, kx = 0, c0 = 0, s_off = 0;
-    auto issue_a = [&](int h, int buf) {
+    auto setup_b = [&](int h) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
-            bufdma16(a_sel[h][g], rsrc_x, s_off, lds0 + buf * STAGE4 + (g * 128 + h * 64 + wave * 8) * 128);
+        for (int g = 0; g < PB; ++g) {
+            const int j = wave + 8 * g;
+            const int cc = (j >> 2) * 64 + h * 32 + (j & 3) * 8;
+            const int sr = (cc >> 1) + (lane >> 4);
+            const int slot = (lane & 15) ^ (sr & 15);
+            const int n = n0 + 2 * sr + (slot >> 3);
+            b_off[h][g] = n < p.Cout ? (unsigned)((n * p.K + (slot & 7) * 8) * 2) : kOob;
+        }
+    };
+    auto setup_a = [&](int h) {   // 32-bit arithmetic throughout: every tensor is < 2 GiB
+#pragma unroll
+        for (int g = 0; g < PA; ++g) {
+            const int r0 = g * 128 + h * 64 + wave * 8;
+            const int sr = (r0 >> 1) + (lane >> 4);
+            const int slot = (lane & 15) ^ (sr & 15);
+            const int m = m0 + 2 * sr + (slot >> 3);
+            const int c8 = (slot & 7) * 8;
+            unsigned mk = 0;
+            int pix = 0;
+            if (m < p.M) {
+                if (!UPS && pointwise) {   // 1x1, stride 1, no padding: the output row IS the input pixel
+                    pix = (m * p.ldx + c8) * 2;
+                    mk = 1u;
+                } else {
+                    int ox, oy, img;
+                    if (p.wo_shift >= 0) {   // power-of-two feature maps: no integer division
+                        ox = m & (p.Wo - 1);
+                        const int t = m >> p.wo_shift;
+                        oy = t & (p.Ho - 1);
+                        img = t >> p.ho_shift;
+                    } else {
+                        ox = m % p.Wo;
+                        const int t = m / p.Wo;
+                        oy = t % p.Ho;
+                        img = t / p.Ho;
+                    }
+                    const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;   // virtual coordinates
+                    if (UPS) {
+                        pix = (((img * p.H + (oy >> 1)) * p.W + (ox >> 1)) * p.ldx + c8) * 2;
+                        mk = ((unsigned)(oy & 1) << 30) | ((unsigned)(ox & 1) << 31);
+                    } else {
+                        pix = (((img * p.H + iy0) * p.W + ix0) * p.ldx + c8) * 2;
+                    }
+                    unsigned xb = 0;   // valid columns of one filter row, replicated for every valid filter row
+                    for (int fx = 0; fx < p.KW; ++fx) xb |= ((unsigned)(ix0 + fx) < (unsigned)Wv ? 1u : 0u) << fx;
+                    for (int fy = 0; fy < p.KH; ++fy)
+                        if ((unsigned)(iy0 + fy) < (unsigned)Hv) mk |= xb << (fy * p.KW);
+                }
+            }
+            a_pix[h][g] = pix;
+            a_mask[h][g] = mk;
+        }
+    };
+    auto select_tap = [&](int h) {   // per-lane source offset of tap (ky, kx), or kOob
+        const int tap = ky * p.KW + kx;
+#pragma unroll
+        for (int g = 0; g < PA; ++g) {
+            int off;
+            if (UPS) {   // source pixel = floor(virtual / 2): the step depends on the output pixel's parity
+                const int dy = ((int)((a_mask[h][g] >> 30) & 1u) - p.pad_t + ky) >> 1;
+                const int dx = ((int)(a_mask[h][g] >> 31) - p.pad_l + kx) >> 1;
+                off = (dy * p.W + dx) * p.ldx * 2;
+            } else {
+                off = (ky * p.W + kx) * p.ldx * 2;
+            }
+            a_sel[h][g] = ((a_mask[h][g] >> tap) & 1u) ? (unsigned)(a_pix[h][g] + off) : kOob;
+        }
+    };
+    // DMA of pieces [g0, g1) of A unit h / of B unit h into stage `buf`
+    auto issue_a = [&](int h, int buf, int g0, int g1) {
+#pragma unroll
+        for (int g = 0; g < PA; ++g)
+            if (g >= g0 && g < g1)
+                bufdma16(a_sel[h][g], rsrc_x, c0 * 2, lds0 + buf * STAGE + (g * 128 + h * 64 + wave * 8) * 128);
     };
     auto advance = [&]() {
         c0 += 64;
-        s_off += 128;
         if (c0 == p.Cin) {
             c0 = 0;
             if (++kx == p.KW) { kx = 0; ++ky; }
-            const int tap = ky * p.KW + kx;
-            s_off = (ky * p.W + kx) * p.ldx * 2;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int g = 0; g < 2; ++g) a_sel[h][g] = ((a_mask[h][g] >> tap) & 1u) ? a_pix[h][g] : kOob;
+            select_tap(0);
+            select_tap(1);
         }
     };
     auto issue_b = [&](int h, int buf, int kt) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < PB; ++g) {
             const int j = wave + 8 * g;
-            bufdma16(b_off[h][g], rsrc_w, kt * 128, lds0 + buf * STAGE4 + TILE4 + ((j >> 2) * 64 + h * 32 + (j & 3) * 8) * 128);
+            bufdma16(b_off[h][g], rsrc_w, kt * 128, lds0 + buf * STAGE + TILE_A + ((j >> 2) * 64 + h * 32 + (j & 3) * 8) * 128);
         }
     };
+
+    // ---- prologue: K tile 0 (B0 B1 A0 A1) and the first two units of K tile 1 (A0 B0); each DMA leaves as soon as
+    //      its addresses exist, so the first (cold) transfers overlap the remaining address arithmetic.
+    const int nk = p.K / 64;
+    setup_b(0);
+    issue_b(0, 0, 0);
+    setup_b(1);
+    issue_b(1, 0, 0);
+    setup_a(0);
+    select_tap(0);
+    issue_a(0, 0, 0, PA);
+    setup_a(1);
+    select_tap(1);
+    issue_a(1, 0, 0, PA);
+    PGT_STAMP(4);
+    advance();
+    if (nk > 1) {
+        issue_a(0, 1, 0, PA);
+        issue_b(0, 1, 1);
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -153,25 +225,15 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         a_rd[ks] = swz128(wr * 128 + (lane & 31), 2 * ks + hh);
-        b_rd[ks] = TILE4 + swz128(wc * 64 + (lane & 31), 2 * ks + hh);
+        b_rd[ks] = TILE_A + swz128(wc * 64 + (lane & 31), 2 * ks + hh);
     }
 
-    const int nk = p.K / 64;
-    // ---- prologue: units 0..5 = K tile 0 (A0 B0 B1 A1) and K tile 1 (A0 B0)
-    issue_a(0, 0);
-    issue_b(0, 0, 0);
-    issue_b(1, 0, 0);
-    issue_a(1, 0);
-    advance();
-    if (nk > 1) {
-        issue_a(0, 1);
-        issue_b(0, 1, 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    }
+    // A0 and B0 of K tile 0 must have landed: everything issued after A0 may stay in flight
+    if (nk > 1) PGT_VMWAIT(2 * PA + PB);
+    else PGT_VMWAIT(PA);
+    PGT_STAMP(5);
     PGT_BARRIER();
-    if (!(PGT_PROBE & 8) && wr == 1) PGT_BARRIER();   // wave row 1 runs one barrier behind wave row 0
+    if (!(PGT_PROBE & 8) && late) PGT_BARRIER();
 
     uint4 fa[2][4], fb0[4], fb1[4];
 #if PGT_PROBE & 2
@@ -181,7 +243,7 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
 
 #define PGT_PHASE(Q, BUF, KT)                                                                                          \
     {                                                                                                                  \
-        const char* st_ = smem + (BUF) * STAGE4;                                                                       \
+        const char* st_ = smem + (BUF) * STAGE;                                                                        \
         if (PGT_PROBE & 2) {                                                                                           \
         } else if ((Q) == 0) {                                                                                         \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) fb0[ks] = *reinterpret_cast<const uint4*>(st_ + b_rd[ks]); \
@@ -198,13 +260,13 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
         }                                                                                                              \
         asm volatile("" ::: "memory");                                                                                 \
         if (!(PGT_PROBE & 1) && (KT) + ((Q) < 2 ? 1 : 2) < nk) {                                                       \
-            if ((Q) == 0) issue_b(1, (BUF) ^ 1, (KT) + 1);                                                             \
-            else if ((Q) == 1) { issue_a(1, (BUF) ^ 1); advance(); }                                                   \
-            else if ((Q) == 2) issue_a(0, (BUF));                                                                      \
-            else issue_b(0, (BUF), (KT) + 2);                                                                          \
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                           \
+            if ((Q) == 0) { issue_b(1, (BUF) ^ 1, (KT) + 1); issue_a(1, (BUF) ^ 1, 0, SA); }                           \
+            else if ((Q) == 1) { issue_a(1, (BUF) ^ 1, SA, PA); advance(); }                                           \
+            else if ((Q) == 2) issue_a(0, (BUF), 0, PA - SA);                                                          \
+            else { issue_a(0, (BUF), PA - SA, PA); issue_b(0, (BUF), (KT) + 2); }                                      \
+            PGT_VMWAIT(NV);                                                                                            \
         } else {                                                                                                       \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+            PGT_VMWAIT(0);                                                                                             \
         }                                                                                                              \
         PGT_BARRIER();                                                                                                 \
         if (!(PGT_PROBE & 4)) __builtin_amdgcn_s_setprio(1);                                                           \
@@ -231,8 +293,8 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
         }
     }
 #undef PGT_PHASE
-    if (!(PGT_PROBE & 8) && wr == 0) PGT_BARRIER();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(PGT_PROBE & 8) && !late) PGT_BARRIER();
+    PGT_VMWAIT(0);
     __syncthreads();
     PGT_STAMP(2);
 #if PGT_PROBE & 16
@@ -241,50 +303,84 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     return;
 #endif
 
-    // ---- epilogue: 4 passes of 64 rows (wave row wr, half ih); act(acc + bias) staged in LDS as fp32, then 8 channels
-    //      of one pixel per thread with 16-byte residual / dec / shift loads and stores.
-    constexpr int SROW = 256 + 4;
+    // ---- epilogue in two passes (ih = 0, 1): every wave stages its 64 x 64 half (acc + bias, fp32) in LDS, then each
+    //      thread finishes CPT chunks of 8 channels of one pixel: activation, residual / SFT, 16-byte store.  The
+    //      residual (dec, shift) chunks of a pass are requested before its staging writes so that their latency
+    //      overlaps the LDS round trip.
+    constexpr int SROW = BN + 4, SROWS = WR * 64, CPT = SROWS * (BN / 8) / 512;
+    static_assert(SROWS * SROW * 4 <= kLds && SROWS * (BN / 8) % 512 == 0, "epilogue stage must fit");
     float* stage = reinterpret_cast<float*>(smem);
-    static_assert(64 * SROW * 4 <= 2 * STAGE4, "epilogue stage must fit");
     const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
     const bf16_t* dec = reinterpret_cast<const bf16_t*>(p.dec);
     const bf16_t* shf = reinterpret_cast<const bf16_t*>(p.shift);
+    float bv[2];
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        if (wr == (pass >> 1)) {
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + (lane & 31);
+        bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int cl = wc * 64 + j * 32 + (lane & 31);
-                const int n = n0 + cl;
-                const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        uint4 pre0[CPT], pre1[CPT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rl = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        stage[rl * SROW + cl] = acc[(pass & 1) * 2 + i][j][e] + bv;
-                    }
+        for (int c = 0; c < CPT; ++c) {
+            const int cidx = tid + 512 * c;
+            const int rl = cidx / (BN / 8), n = n0 + (cidx % (BN / 8)) * 8;
+            const int m = m0 + (rl >> 6) * 128 + pass * 64 + (rl & 63);
+            pre0[c] = pre1[c] = make_uint4(0, 0, 0, 0);
+            if (m < p.M && n < p.Cout) {
+                if (p.epi == 1) {
+                    pre0[c] = *reinterpret_cast<const uint4*>(dec + (long)m * p.ld_dec + n);
+                    pre1[c] = *reinterpret_cast<const uint4*>(shf + (long)m * p.ld_shift + n);
+                } else if (res) {
+                    pre0[c] = *reinterpret_cast<const uint4*>(res + (long)m * p.ldr + n);
+                }
             }
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cl = wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    stage[rl * SROW + cl] = acc[pass * 2 + i][j][e] + bv[j];
+                }
+        }
         __syncthreads();
-        for (int cidx = tid; cidx < 64 * 32; cidx += 512) {
-            const int rl = cidx >> 5, c8 = (cidx & 31) * 8;
-            const int m = m0 + pass * 64 + rl, n = n0 + c8;
+        if (p.act != ACT_NONE) {   // in place on the thread's own chunks, in a ROLLED loop: one copy of the switch
+#pragma unroll 1
+            for (int c = 0; c < CPT; ++c) {
+                const int cidx = tid + 512 * c;
+                float* sp = stage + (cidx / (BN / 8)) * SROW + (cidx % (BN / 8)) * 8;
+                float v[8];
+                *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(sp);
+                *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(sp + 4);
+                apply_act8(v, p.act);
+                *reinterpret_cast<float4*>(sp) = *reinterpret_cast<const float4*>(v);
+                *reinterpret_cast<float4*>(sp + 4) = *reinterpret_cast<const float4*>(v + 4);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int cidx = tid + 512 * c;
+            const int rl = cidx / (BN / 8), c8 = (cidx % (BN / 8)) * 8;
+            const int m = m0 + (rl >> 6) * 128 + pass * 64 + (rl & 63), n = n0 + c8;
             if (m >= p.M || n >= p.Cout) continue;
             float v[8];
             *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8);
             *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8 + 4);
-            apply_act8(v, p.act);
             if (p.epi == 1) {
-                float d[8], s[8];
-                load8<bf16_t>(dec + (long)m * p.ld_dec + n, d);
-                load8<bf16_t>(shf + (long)m * p.ld_shift + n, s);
+                float d[8], sh[8];
+                Vec16<bf16_t>::unpack(pre0[c], d);
+                Vec16<bf16_t>::unpack(pre1[c], sh);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + s[e]);
+                for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + sh[e]);
             } else {
                 if (res) {
                     float r[8];
-                    load8<bf16_t>(res + (long)m * p.ldr + n, r);
+                    Vec16<bf16_t>::unpack(pre0[c], r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r[e];
                 }
@@ -296,27 +392,38 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
             if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n, v);
             else store8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + n, v);
         }
-        __syncthreads();
+        if (pass == 0) __syncthreads();
     }
     PGT_STAMP(3);
 }
 
-}  // namespace
-
-// bf16, stride 1, no up-sampling, Cin % 64 == 0, KH*KW <= 32, tensor < 2 GiB, 16-byte-legal epilogue (caller checks).
-int pgt_igemm4_launch(const void* pv, hipStream_t st) {
-    ConvP p = *reinterpret_cast<const ConvP*>(pv);
-    p.nbm = (p.M + 255) / 256;
-    p.nbn = (p.Cout + 255) / 256;
-    constexpr int bytes = 2 * STAGE4;
+template <int WR, int WC, bool UPS> int launch4(const ConvP& p0, hipStream_t st) {
+    ConvP p = p0;
+    constexpr int BM = WR * 128, BN = WC * 64, bytes = lds_bytes4(WR, WC);
+    const bool pow2 = (p.Wo & (p.Wo - 1)) == 0 && (p.Ho & (p.Ho - 1)) == 0;
+    p.wo_shift = pow2 ? __builtin_ctz(p.Wo) : -1;
+    p.ho_shift = pow2 ? __builtin_ctz(p.Ho) : -1;
+    p.nbm = (p.M + BM - 1) / BM;
+    p.nbn = (p.Cout + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { pgt_set_error("igemm4: cannot reserve %d B of LDS: %s", bytes, hipGetErrorString(e)); return -12; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(igemm4_kernel, dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
+    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
     PGT_LAUNCH_CHECK();
     return 0;
+}
+
+}  // namespace
+
+// bf16, Cin % 64 == 0, KH*KW <= 30, tensors < 2 GiB, 16-byte-legal epilogue (caller checks).  bn = 256: 256x256
+// tiles; bn = 128: 512x128 tiles.  Returns 1 if the tile is not built.
+int pgt_igemm4_launch(const void* pv, int bn, hipStream_t st) {
+    const ConvP& p = *reinterpret_cast<const ConvP*>(pv);
+    if (bn == 256) return p.ups ? launch4<2, 4, true>(p, st) : launch4<2, 4, false>(p, st);
+    if (bn == 128) return p.ups ? launch4<4, 2, true>(p, st) : launch4<4, 2, false>(p, st);
+    return 1;
 }

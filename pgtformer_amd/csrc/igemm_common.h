@@ -35,6 +35,7 @@ struct ConvP {
     float sft_w;
     int M, K, nbm, nbn;
     int splitk, kt_per_split;   // > 1: K is cut in `splitk` slices of `kt_per_split` K tiles each
+    int wo_shift, ho_shift;     // igemm4: log2(Wo), log2(Ho) when both are powers of two, else -1 (set by its launcher)
 };
 
 }  // namespace

@@ -16,5 +16,5 @@ int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, co
 
 // igemm3.hip: large-tile LDS-DMA implicit GEMM (bf16, stride 1, no up-sampling, Cin % 64 == 0); 1 = combination not built
 int pgt_igemm3_launch(const void* conv_p, int bm, int bn, int stages, hipStream_t st);
-// igemm4.hip: 256x256 tile, 8 waves, phase-interleaved schedule (same preconditions as igemm3)
-int pgt_igemm4_launch(const void* conv_p, hipStream_t st);
+// igemm4.hip: phase-interleaved 8-wave schedule; bn = 256 -> 256x256 tiles, bn = 128 -> 512x128 tiles; 1 = tile not built
+int pgt_igemm4_launch(const void* conv_p, int bn, hipStream_t st);

@@ -69,7 +69,7 @@ def _ld_rows(x):
 # heuristic stays one of the candidates, so tuning never loses to it.  fp32 (parity) launches are never tuned.
 AUTOTUNE = None
 _TUNE_CANDIDATES = ((0, (0, 0), 0), (1, (64, 64), 0), (1, (64, 128), 0), (1, (128, 64), 0), (1, (128, 128), 0),
-                    (3, (256, 256), 2), (4, (0, 0), 0))
+                    (3, (256, 256), 2), (4, (0, 256), 0), (4, (0, 128), 0))
 
 
 def enable_autotune(flag=True):
@@ -157,7 +157,8 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         prof.append({"kernel": "igemm", "flops": 2.0 * m * cout * kh * kw * cin,
                      "bytes": float(n * h * wd * cin * es + m * cout * out.element_size() + w.numel() * es
                                     + (m * cout * es if res is not None else 0)),
-                     "shape": (n, h, wd, cin, cout, kh, stride, int(ups)), "events": (e0, e1)})
+                     "shape": (n, h, wd, cin, cout, kh, stride, int(ups)), "events": (e0, e1),
+                     "cfg": (d.kernel, d.force_bm, d.force_bn)})
     return out
 
 

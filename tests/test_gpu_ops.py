@@ -410,33 +410,39 @@ def test_conv2d_large_tile_kernel(shape, tile):
           E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)
 
 
-V4_SHAPES = V3_SHAPES + [("v4_1tile_k64", 1, 8, 8, 64, 64, 1), ("v4_odd_ktiles", 1, 24, 40, 192, 320, 3),
-                         ("v4_big", 4, 64, 64, 256, 256, 3)]
+V4_SHAPES = [(n, a, b, c, d, e, f, 1, False) for (n, a, b, c, d, e, f) in V3_SHAPES] + [
+    ("v4_1tile_k64", 1, 8, 8, 64, 64, 1, 1, False), ("v4_odd_ktiles", 1, 24, 40, 192, 320, 3, 1, False),
+    ("v4_big", 4, 64, 64, 256, 256, 3, 1, False), ("v4_ups", 2, 20, 28, 128, 128, 3, 1, True),
+    ("v4_ups_odd", 1, 9, 13, 64, 72, 3, 1, True), ("v4_stride2", 2, 32, 40, 128, 128, 3, 2, False)]
 
 
+@pytest.mark.parametrize("bn", [256, 128])
 @pytest.mark.parametrize("shape", V4_SHAPES, ids=[s[0] for s in V4_SHAPES])
-def test_conv2d_phased_kernel(shape):
-    """igemm4 (256x256 tile, 8 waves, phase-interleaved LDS-DMA schedule) against the emulation and v1, plus a
-    repeat-run screen: the hand-placed vmcnt/barrier schedule must give bit-identical results on every launch."""
-    name, n, h, w_, cin, cout, k = shape
+def test_conv2d_phased_kernel(shape, bn):
+    """igemm4 (256x256 / 512x128 tiles, 8 waves, phase-interleaved LDS-DMA schedule, strided and up-sampled inputs)
+    against the emulation and v1, plus a repeat-run screen: the hand-placed vmcnt/barrier schedule must give
+    bit-identical results on every launch."""
+    name, n, h, w_, cin, cout, k, stride, ups = shape
     dtype = torch.bfloat16
     x = rnd((n, h, w_, cin), 310, dtype)
     wt = rnd((cout, k * k * cin), 311, dtype, 1.0 / np.sqrt(k * k * cin))
     wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
     b = rnd((cout,), 312, torch.float32, 0.1)
-    kw = dict(kh=k, kw=k, pad=(k // 2,) * 4)
+    pad = (0, 1, 0, 1) if stride == 2 else (k // 2,) * 4   # Downsample pads bottom/right only (rstt_layers.py:891)
+    kw = dict(kh=k, kw=k, pad=pad, stride=stride, ups=ups)
+    v4 = dict(kernel=4, tile=(0, bn))
     gx, gw, gb = g(x), g(wt), g(b)
     want = E.conv2d(x, wt, b, act=E.ACT_SILU, **kw)
-    check(f"{name}_v4", ops().conv2d(gx, gw, gb, act=E.ACT_SILU, kernel=4, **kw), want, dtype)
+    check(f"{name}_v4", ops().conv2d(gx, gw, gb, act=E.ACT_SILU, **v4, **kw), want, dtype)
     res = rnd(tuple(want.shape), 313, dtype)
     gres = g(res)
-    got = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=4, **kw)
+    got = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, **v4, **kw)
     check(f"{name}_v4_res", got, E.conv2d(x, wt, b, res=res, post_relu=True, **kw), dtype)
     v1 = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=1, **kw)
     check(f"{name}_v4_v1", got, v1, dtype, 0.2)
     for _ in range(20):
-        again = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=4, **kw)
+        again = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, **v4, **kw)
         assert torch.equal(again, got), f"{name}: igemm4 is not run-to-run deterministic"
     dec, shf = rnd(tuple(want.shape), 314, dtype), rnd(tuple(want.shape), 315, dtype)
-    check(f"{name}_v4_sft", ops().conv2d(gx, gw, gb, sft=(g(dec), g(shf), 0.6), kernel=4, **kw),
+    check(f"{name}_v4_sft", ops().conv2d(gx, gw, gb, sft=(g(dec), g(shf), 0.6), **v4, **kw),
           E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)

@@ -99,9 +99,11 @@ def main():
                 t3 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=3, tile=(bm, bn), stages=nst), args.iters)
                 best = min(best, t3)
                 v3 += f" v3/{bm}x{bn}s{nst}={t3:6.1f}"
-            t4 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=4), args.iters)
-            best = min(best, t4)
-            v3 += f" v4={t4:6.1f}"
+        if dt == torch.bfloat16 and cin % 64 == 0 and cout % 8 == 0:
+            for bn in (256, 128):
+                t4 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res, kernel=4, tile=(0, bn)), args.iters)
+                best = min(best, t4)
+                v3 += f" v4/{bn}={t4:6.1f}"
         cells.append(v3)
         ta = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res), args.iters)
         total_best += best * cnt

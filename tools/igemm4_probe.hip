@@ -27,11 +27,12 @@ __global__ void fill_bf16(bf16_t* p, long n, unsigned seed, float scale) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 7) { fprintf(stderr, "usage: probe N H W Cin Cout k [iters]\n"); return 2; }
+    if (argc < 7) { fprintf(stderr, "usage: probe N H W Cin Cout k [iters] [bn=256|128] [ups=0|1]\n"); return 2; }
     const int N = atoi(argv[1]), H = atoi(argv[2]), W = atoi(argv[3]), Cin = atoi(argv[4]), Cout = atoi(argv[5]), k = atoi(argv[6]);
     const int iters = argc > 7 ? atoi(argv[7]) : 5;
+    const int bn = argc > 8 ? atoi(argv[8]) : 256, ups = argc > 9 ? atoi(argv[9]) : 0;
     ConvP p{};
-    const long nx = (long)N * H * W * Cin, nw = (long)Cout * k * k * Cin, ny = (long)N * H * W * Cout;
+    const long nx = (long)N * H * W * Cin, nw = (long)Cout * k * k * Cin, ny = (long)N * H * W * Cout * 4;
     bf16_t *x, *w, *y;
     float* bias;
     hipMalloc(&x, nx * 2); hipMalloc(&w, nw * 2); hipMalloc(&y, ny * 2); hipMalloc(&bias, Cout * 4);
@@ -40,14 +41,14 @@ int main(int argc, char** argv) {
     hipMemset(bias, 0, Cout * 4);
     p.x = (const char*)x; p.w = (const char*)w; p.bias = bias; p.y = (char*)y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ldx = Cin; p.KH = p.KW = k; p.stride = 1; p.pad_t = p.pad_l = k / 2;
-    p.Ho = H; p.Wo = W; p.Cout = Cout; p.ldy = Cout; p.vec_epi = 1;
-    p.M = N * H * W; p.K = k * k * Cin;
+    p.ups = ups; p.Ho = ups ? 2 * H : H; p.Wo = ups ? 2 * W : W; p.Cout = Cout; p.ldy = Cout; p.vec_epi = 1;
+    p.M = N * p.Ho * p.Wo; p.K = k * k * Cin;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    pgt_igemm4_launch(&p, 0);
+    pgt_igemm4_launch(&p, bn, 0);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) pgt_igemm4_launch(&p, 0);
+    for (int i = 0; i < iters; ++i) pgt_igemm4_launch(&p, bn, 0);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0;
@@ -56,13 +57,17 @@ int main(int argc, char** argv) {
     printf("PROBE=%d  %dx%dx%dx%d -> %d k%d : %.1f us  %.1f TFLOP/s  (%s)\n", PGT_PROBE, N, H, W, Cin, Cout, k, us,
            flops / us / 1e6, hipGetErrorString(hipGetLastError()));
 #if PGT_PROBE & 32
-    const int nb = ((p.M + 255) / 256) * ((Cout + 255) / 256);
-    std::vector<unsigned long long> ts(4096 * 4);
+    const int bm = bn == 256 ? 256 : 512;
+    const int nb = ((p.M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+    std::vector<unsigned long long> ts(4096 * 8);
     hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(g_pgt_probe_ts), ts.size() * 8);
-    double s[3] = {0, 0, 0};
+    double s[3] = {0, 0, 0}, s4 = 0, s5 = 0;
     const int cnt = nb < 4096 ? nb : 4096;
     for (int b = 0; b < cnt; ++b)
-        for (int j = 0; j < 3; ++j) s[j] += (double)(ts[b * 4 + j + 1] - ts[b * 4 + j]);
+        for (int j = 0; j < 3; ++j) s[j] += (double)(ts[b * 8 + j + 1] - ts[b * 8 + j]);
+    for (int b = 0; b < cnt; ++b) { s4 += (double)(ts[b * 8 + 4] - ts[b * 8]); s5 += (double)(ts[b * 8 + 5] - ts[b * 8 + 4]); }
+    printf("  setup split: address arithmetic %.0f  prologue issue + first wait %.0f  barrier %.0f\n", s4 / cnt, s5 / cnt,
+           (s[0] - s4 - s5) / cnt);
     printf("  per workgroup (s_memtime ticks, avg of %d): setup+prologue %.0f  main loop %.0f (%.0f per K tile, %.0f per phase)  epilogue %.0f\n",
            cnt, s[0] / cnt, s[1] / cnt, s[1] / cnt / (p.K / 64), s[1] / cnt / (p.K / 64) / 4, s[2] / cnt);
 #endif
