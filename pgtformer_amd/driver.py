@@ -30,11 +30,23 @@ class WindowRunner:
         self.static_in = torch.zeros((batch * self.t, height, width, 3), dtype=torch.uint8, device=self.dev)
         self.graph = None
         self.static_out = None
-        if use_graph:
-            if os.environ.get("PGT_AUTOTUNE", "1") != "0" and self.dev.type == "cuda":
-                from . import ops   # per-shape kernel selection during the eager warm-up passes (bf16 launches only)
+        # per-shape kernel selection during the first eager passes (bf16 launches only); PGT_AUTOTUNE=0 keeps the
+        # library's static heuristic, PGT_AUTOTUNE_CACHE=<file> reloads / stores the tuned table across processes
+        cache = os.environ.get("PGT_AUTOTUNE_CACHE")
+        tune = os.environ.get("PGT_AUTOTUNE", "1") != "0" and self.dev.type == "cuda"
+        if tune:
+            from . import ops
+            if cache and os.path.exists(cache):
+                ops.load_autotune(cache)
+            else:
                 ops.enable_autotune()
+        if use_graph:
             self._capture()
+        elif tune:
+            self.model.restore_middle_u8(self.static_in, w=self.w)
+            torch.cuda.synchronize(self.dev)
+        if tune and cache and not os.path.exists(cache):
+            ops.save_autotune(cache)
 
     def _capture(self):
         s = torch.cuda.Stream(device=self.dev)

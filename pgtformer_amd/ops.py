@@ -77,6 +77,20 @@ def enable_autotune(flag=True):
     AUTOTUNE = ({} if AUTOTUNE is None else AUTOTUNE) if flag else None
 
 
+def save_autotune(path):
+    """Write the tuned (signature -> kernel variant) table as JSON (reload with load_autotune to skip re-tuning)."""
+    import json
+    with open(path, "w") as f:
+        json.dump([[list(k[:9]) + [list(k[9])] + list(k[10:]), [v[0], list(v[1]), v[2]]] for k, v in (AUTOTUNE or {}).items()], f)
+
+
+def load_autotune(path):
+    import json
+    enable_autotune()
+    for k, v in json.load(open(path)):
+        AUTOTUNE[tuple(k[:9]) + (tuple(k[9]),) + tuple(k[10:])] = (v[0], tuple(v[1]), v[2])
+
+
 def _tune_conv(d, args, device, iters=4):
     L = hip.lib()
     best, best_t = _TUNE_CANDIDATES[0], None

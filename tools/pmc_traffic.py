@@ -23,9 +23,9 @@ def per_kernel(db, counter, like):
 
 
 def main(fetch_db, write_db, out):
-    f_kib, nf = per_kernel(fetch_db, "FETCH_SIZE", "%igemm_kernel%")
-    w_kib, nw = per_kernel(write_db, "WRITE_SIZE", "%igemm_kernel%")
-    res = {"kernel": "igemm_kernel", "launches": nf,
+    f_kib, nf = per_kernel(fetch_db, "FETCH_SIZE", "%igemm%_kernel%")
+    w_kib, nw = per_kernel(write_db, "WRITE_SIZE", "%igemm%_kernel%")
+    res = {"kernel": "igemm*_kernel (igemm, igemm3, igemm4)", "launches": nf,
            "fetch_bytes_per_launch_raw": f_kib * 1024 / max(nf, 1),
            "fetch_bytes_per_launch_corrected_x2": 2 * f_kib * 1024 / max(nf, 1),
            "write_bytes_per_launch": w_kib * 1024 / max(nw, 1),
