@@ -481,6 +481,12 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     const bool v4_legal = v2_legal && d->KH * d->KW <= 30 && (long)d->N * d->H * d->W * d->ldx * 2 < (1L << 31) &&
                           (long)d->Cout * p.K * 2 < (1L << 31);
     PGT_CHECK(d->kernel != 4 || v4_legal, "pgt_conv2d: kernel=4 needs bf16, Cin %% 64 == 0, <= 30 taps, tensors < 2 GiB");
+    // v5 (v4's 256x256 schedule + horizontal tap reuse): 3-wide filters, stride 1, same-size power-of-two maps
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const bool v5_legal = v4_legal && d->stride == 1 && d->ups == 0 && d->KW == 3 && d->KH <= 8 && d->Ho == d->H &&
+                          d->Wo == d->W && pow2(d->W) && pow2(d->H) && d->W >= 32;
+    PGT_CHECK(d->kernel != 5 || v5_legal, "pgt_conv2d: kernel=5 needs a 3-wide stride-1 same-size conv on power-of-two maps (W >= 32)");
+    if (d->kernel == 5) return pgt_igemm5_launch(&p, st);
     if (d->kernel == 4) {
         const int rc = pgt_igemm4_launch(&p, d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256), st);
         PGT_CHECK(rc != 1, "pgt_conv2d: kernel=4 has no %d-column tile (128, 256)", d->force_bn);

@@ -30,6 +30,7 @@
 #include "common.h"
 #include "pgt_internal.h"
 #include "igemm_common.h"
+#include "igemm_epi.h"
 
 // Probe hooks (tools/igemm4_probe.hip compiles this file with -DPGT_PROBE=<bits>; the library build has none):
 //   1 no DMA in the main loop   2 no fragment reads   4 no s_setprio   8 no wave stagger   16 no epilogue
@@ -53,7 +54,7 @@ namespace {
 
 // dynamic LDS: two K-tile stages, or the fp32 epilogue stage of WR*64 rows if that is larger
 constexpr int lds_bytes4(int wr, int wc) {
-    const int stages = 2 * (wr * 128 + wc * 64) * 128, epi = wr * 64 * (wc * 64 + 4) * 4;
+    const int stages = 2 * (wr * 128 + wc * 64) * 128, epi = wr * 64 * (wc * 64 + 4) * 4;   // = epi_stage_bytes<wr, wc>()
     return stages > epi ? stages : epi;
 }
 
@@ -303,97 +304,7 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     return;
 #endif
 
-    // ---- epilogue in two passes (ih = 0, 1): every wave stages its 64 x 64 half (acc + bias, fp32) in LDS, then each
-    //      thread finishes CPT chunks of 8 channels of one pixel: activation, residual / SFT, 16-byte store.  The
-    //      residual (dec, shift) chunks of a pass are requested before its staging writes so that their latency
-    //      overlaps the LDS round trip.
-    constexpr int SROW = BN + 4, SROWS = WR * 64, CPT = SROWS * (BN / 8) / 512;
-    static_assert(SROWS * SROW * 4 <= kLds && SROWS * (BN / 8) % 512 == 0, "epilogue stage must fit");
-    float* stage = reinterpret_cast<float*>(smem);
-    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
-    const bf16_t* dec = reinterpret_cast<const bf16_t*>(p.dec);
-    const bf16_t* shf = reinterpret_cast<const bf16_t*>(p.shift);
-    float bv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wc * 64 + j * 32 + (lane & 31);
-        bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        uint4 pre0[CPT], pre1[CPT];
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            const int cidx = tid + 512 * c;
-            const int rl = cidx / (BN / 8), n = n0 + (cidx % (BN / 8)) * 8;
-            const int m = m0 + (rl >> 6) * 128 + pass * 64 + (rl & 63);
-            pre0[c] = pre1[c] = make_uint4(0, 0, 0, 0);
-            if (m < p.M && n < p.Cout) {
-                if (p.epi == 1) {
-                    pre0[c] = *reinterpret_cast<const uint4*>(dec + (long)m * p.ld_dec + n);
-                    pre1[c] = *reinterpret_cast<const uint4*>(shf + (long)m * p.ld_shift + n);
-                } else if (res) {
-                    pre0[c] = *reinterpret_cast<const uint4*>(res + (long)m * p.ldr + n);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cl = wc * 64 + j * 32 + (lane & 31);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rl = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    stage[rl * SROW + cl] = acc[pass * 2 + i][j][e] + bv[j];
-                }
-        }
-        __syncthreads();
-        if (p.act != ACT_NONE) {   // in place on the thread's own chunks, in a ROLLED loop: one copy of the switch
-#pragma unroll 1
-            for (int c = 0; c < CPT; ++c) {
-                const int cidx = tid + 512 * c;
-                float* sp = stage + (cidx / (BN / 8)) * SROW + (cidx % (BN / 8)) * 8;
-                float v[8];
-                *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(sp);
-                *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(sp + 4);
-                apply_act8(v, p.act);
-                *reinterpret_cast<float4*>(sp) = *reinterpret_cast<const float4*>(v);
-                *reinterpret_cast<float4*>(sp + 4) = *reinterpret_cast<const float4*>(v + 4);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            const int cidx = tid + 512 * c;
-            const int rl = cidx / (BN / 8), c8 = (cidx % (BN / 8)) * 8;
-            const int m = m0 + (rl >> 6) * 128 + pass * 64 + (rl & 63), n = n0 + c8;
-            if (m >= p.M || n >= p.Cout) continue;
-            float v[8];
-            *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8);
-            *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8 + 4);
-            if (p.epi == 1) {
-                float d[8], sh[8];
-                Vec16<bf16_t>::unpack(pre0[c], d);
-                Vec16<bf16_t>::unpack(pre1[c], sh);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + sh[e]);
-            } else {
-                if (res) {
-                    float r[8];
-                    Vec16<bf16_t>::unpack(pre0[c], r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r[e];
-                }
-                if (p.post_relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                }
-            }
-            if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n, v);
-            else store8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + n, v);
-        }
-        if (pass == 0) __syncthreads();
-    }
+    epilogue_128x64<WR, WC>(p, acc, smem, m0, n0, tid, lane, wr, wc);
     PGT_STAMP(3);
 }
 

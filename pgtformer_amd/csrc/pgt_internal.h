@@ -18,3 +18,5 @@ int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, co
 int pgt_igemm3_launch(const void* conv_p, int bm, int bn, int stages, hipStream_t st);
 // igemm4.hip: phase-interleaved 8-wave schedule; bn = 256 -> 256x256 tiles, bn = 128 -> 512x128 tiles; 1 = tile not built
 int pgt_igemm4_launch(const void* conv_p, int bn, hipStream_t st);
+// igemm5.hip: igemm4's 256x256 schedule with one LDS input image shared by the three horizontal taps (3-wide filters)
+int pgt_igemm5_launch(const void* conv_p, hipStream_t st);

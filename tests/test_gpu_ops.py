@@ -446,3 +446,37 @@ def test_conv2d_phased_kernel(shape, bn):
     dec, shf = rnd(tuple(want.shape), 314, dtype), rnd(tuple(want.shape), 315, dtype)
     check(f"{name}_v4_sft", ops().conv2d(gx, gw, gb, sft=(g(dec), g(shf), 0.6), **v4, **kw),
           E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)
+
+
+V5_SHAPES = [("v5_w32", 2, 32, 32, 64, 256, 3), ("v5_w64_c128", 1, 64, 64, 128, 200, 3), ("v5_w128", 1, 32, 128, 192, 256, 3),
+             ("v5_w256", 1, 8, 256, 64, 72, 3), ("v5_w512_ragged_m", 1, 2, 512, 64, 64, 3), ("v5_big", 4, 64, 64, 256, 256, 3),
+             ("v5_1x3", 1, 32, 64, 128, 128, (1, 3))]
+
+
+@pytest.mark.parametrize("shape", V5_SHAPES, ids=[s[0] for s in V5_SHAPES])
+def test_conv2d_tap_reuse_kernel(shape):
+    """igemm5 (igemm4 schedule, one LDS input image shared by the three horizontal taps, reads shifted by kx) against
+    the emulation and v1, all epilogues, plus the repeat-run determinism screen of the hand-placed schedule."""
+    name, n, h, w_, cin, cout, k = shape
+    kh, kw_ = k if isinstance(k, tuple) else (k, k)
+    dtype = torch.bfloat16
+    x = rnd((n, h, w_, cin), 410, dtype)
+    wt = rnd((cout, kh * kw_ * cin), 411, dtype, 1.0 / np.sqrt(kh * kw_ * cin))
+    wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
+    b = rnd((cout,), 412, torch.float32, 0.1)
+    kw = dict(kh=kh, kw=kw_, pad=(kh // 2, kh // 2, 1, 1))
+    gx, gw, gb = g(x), g(wt), g(b)
+    want = E.conv2d(x, wt, b, act=E.ACT_SILU, **kw)
+    check(f"{name}_v5", ops().conv2d(gx, gw, gb, act=E.ACT_SILU, kernel=5, **kw), want, dtype)
+    res = rnd(tuple(want.shape), 413, dtype)
+    gres = g(res)
+    got = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=5, **kw)
+    check(f"{name}_v5_res", got, E.conv2d(x, wt, b, res=res, post_relu=True, **kw), dtype)
+    v1 = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=1, **kw)
+    check(f"{name}_v5_v1", got, v1, dtype, 0.2)
+    for _ in range(20):
+        again = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=5, **kw)
+        assert torch.equal(again, got), f"{name}: igemm5 is not run-to-run deterministic"
+    dec, shf = rnd(tuple(want.shape), 414, dtype), rnd(tuple(want.shape), 415, dtype)
+    check(f"{name}_v5_sft", ops().conv2d(gx, gw, gb, sft=(g(dec), g(shf), 0.6), kernel=5, **kw),
+          E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)

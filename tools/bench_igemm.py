@@ -104,6 +104,10 @@ def main():
                 t4 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res, kernel=4, tile=(0, bn)), args.iters)
                 best = min(best, t4)
                 v3 += f" v4/{bn}={t4:6.1f}"
+        if dt == torch.bfloat16 and cin % 64 == 0 and cout % 8 == 0 and stride == 1 and not ups and k == 3 and w >= 32:
+            t5 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=5), args.iters)
+            best = min(best, t5)
+            v3 += f" v5/256={t5:6.1f}"
         cells.append(v3)
         ta = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res), args.iters)
         total_best += best * cnt

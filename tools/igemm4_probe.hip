@@ -8,7 +8,13 @@
 #include <cstdlib>
 #include <vector>
 
+#ifdef PGT_PROBE_V5
+#include "../pgtformer_amd/csrc/igemm5.hip"
+#define PROBE_LAUNCH(p, bn) pgt_igemm5_launch(p, 0)
+#else
 #include "../pgtformer_amd/csrc/igemm4.hip"
+#define PROBE_LAUNCH(p, bn) pgt_igemm4_launch(p, bn, 0)
+#endif
 
 void pgt_set_error(const char* fmt, ...) {
     va_list ap;
@@ -45,10 +51,10 @@ int main(int argc, char** argv) {
     p.M = N * p.Ho * p.Wo; p.K = k * k * Cin;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    pgt_igemm4_launch(&p, bn, 0);
+    PROBE_LAUNCH(&p, bn);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) pgt_igemm4_launch(&p, bn, 0);
+    for (int i = 0; i < iters; ++i) PROBE_LAUNCH(&p, bn);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0;
