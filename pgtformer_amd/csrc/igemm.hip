@@ -419,6 +419,9 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     PGT_CHECK(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->Cout >= 1 && d->N >= 1, "pgt_conv2d: bad geometry");
     PGT_CHECK(d->ups == 0 || d->ups == 1, "pgt_conv2d: ups must be 0 or 1");
     PGT_CHECK(d->ldy >= d->Cout, "pgt_conv2d: ldy < Cout");
+    // the gather offsets of every kernel are 32-bit byte offsets
+    PGT_CHECK((long)d->N * d->H * d->W * d->ldx * es < (1L << 31), "pgt_conv2d: the input tensor must be smaller than 2 GiB "
+              "(N=%d H=%d W=%d ldx=%d): split the batch", d->N, d->H, d->W, d->ldx);
     PGT_CHECK(d->epi == 0 || (sft_dec && sft_shift), "pgt_conv2d: SFT epilogue needs dec and shift");
     ConvP p;
     p.x = (const char*)x; p.w = (const char*)w; p.bias = bias; p.res = (const char*)residual;

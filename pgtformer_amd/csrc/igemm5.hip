@@ -2,10 +2,13 @@
 // staggered wave halves) fed with ONE LDS image of the input rows per (filter row ky, 64-channel block) that serves the
 // three horizontal taps kx = 0, 1, 2 - the A fragments of tap kx are the same LDS rows shifted by kx pixels.
 //
-// Why: with every tap fetched separately igemm4 moves 64 KiB of L2 -> LDS per 64-deep K tile and its phases run at the
-// LDS-DMA rate of the CU (~27 B/clk: 590-740 cycles per phase against 530 of MFMA, tools/igemm4_probe.hip).  Sharing
-// the A image between the kx taps cuts the A side to a third (32 -> ~11.6 KiB per K tile): 44 KiB per K tile, below
-// what the matrix pipes consume.
+// Why: with every tap fetched separately igemm4 moves 64 KiB of L2 -> LDS per 64-deep K tile; sharing the A image between
+// the kx taps cuts the A side to a third (32 -> ~11.6 KiB per K tile, 44 KiB in total) and the DMA instruction count
+// per wave from 8 to 5.7 per K tile.  Measured (tools/igemm4_probe.hip -DPGT_PROBE_V5, 256->256 3x3 @ 12x128x128):
+// 598 ticks per phase against 619 for igemm4 and 527 with neither DMA nor fragment reads; DMA instructions cost ~14,
+// their memory traffic ~33, fragment reads ~24 ticks per phase.  Both kernels are within 15 % of the MFMA-only loop;
+// what remains is the clock (1.6-1.9 GHz under MFMA load) and the per-tile setup + epilogue (~18 % of a tile at
+// K = 2304).  The autotuner picks this kernel where it wins (small margins).
 //
 //   * K order: for ky, for channel block cb (64 ch), for kx - a GROUP is the 3 K tiles (12 phases) of one (ky, cb).
 //   * A image of a group ("extended tile"): the tile's 256 output pixels are consecutive pixels of the feature map, i.e.
@@ -14,15 +17,14 @@
 //     segment reads row x + kx.  The image is XOR-swizzled with key (row >> 1) & 7 on the 16-byte chunk index, which
 //     is bank-conflict free for ds_read_b128 fragment reads at ANY row offset (8 rows of equal parity in a 16-lane
 //     group always carry 8 different keys), so the shifted reads cost nothing.
-//   * double-buffered A images (group g+1 is fetched during phases 0..4 of group g, one 1-KiB piece per wave and
-//     phase); the B operand lives in a RING of five 16-KiB units (unit 2kt = B0 of K tile kt, 2kt+1 = B1), unit v is
-//     issued in phase 2v - 8 and first read in phase 2v (B0) / 2v - 1 (B1): 7-8 phases ahead.  The DMA round trip
-//     under load is ~2400 cycles (igemm4's 4-phase window made every phase wait for it: 600+ cycles per phase whatever
-//     the byte count); with a 6-phase window the phases run at the MFMA rate.
+//   * double-buffered A images: group g+1 is fetched during group g, one 1-KiB piece per wave in phases 0, 2, 4, 5, 6
+//     (the phases with fragment reads carry one DMA); the B operand lives in a RING of five 16-KiB units (unit 2kt =
+//     B0 of K tile kt, 2kt+1 = B1), unit v = 2 pieces per wave is issued in the odd phase 2v - 7 and first read in
+//     phase 2v (B0) / 2v - 1 (B1): 6-7 phases ahead (the DMA round trip under load is ~2400 cycles).
 //   * every phase issues the same DMAs in every group (past the end of K they read out of range and land in a buffer
 //     nobody reads), so the wait before the phase's first barrier is the compile-time constant
-//     vmcnt(DMAs issued in the 6 newest phases): it retires everything issued >= 6 phases earlier, which covers every
-//     read of the next phase; all units are issued >= 7 phases ahead of their first read and >= 2 phases after the
+//     vmcnt(DMAs issued in the 5 newest phases): it retires everything issued >= 5 phases earlier, which covers every
+//     read of the next phase; all units are issued >= 6 phases ahead of their first read and >= 2 phases after the
 //     last read of the bytes they replace (same RAW / WAR argument as igemm4.hip).
 //
 // Preconditions (checked by the caller): bf16, stride 1, no up-sampling, KW == 3, pad_l == 1, Ho == H, Wo == W, W and H
