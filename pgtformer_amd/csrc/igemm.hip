@@ -490,6 +490,11 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
                           d->Wo == d->W && pow2(d->W) && pow2(d->H) && d->W >= 32;
     PGT_CHECK(d->kernel != 5 || v5_legal, "pgt_conv2d: kernel=5 needs a 3-wide stride-1 same-size conv on power-of-two maps (W >= 32)");
     if (d->kernel == 5) return pgt_igemm5_launch(&p, st);
+    // v6 (register-resident weights, persistent, halo images): the 64-channel 3x3 layers
+    const bool v6_legal = d->Cin == 64 && d->Cout <= 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ups == 0 &&
+                          d->Ho == d->H && d->Wo == d->W && pow2(d->W) && pow2(d->H) && d->W >= 32 && d->ldx % 8 == 0;
+    PGT_CHECK(d->kernel != 6 || v6_legal, "pgt_conv2d: kernel=6 needs a 3x3 stride-1 same-size conv, Cin == 64, Cout <= 64, power-of-two maps");
+    if (d->kernel == 6) return pgt_igemm6_launch(&p, st);
     if (d->kernel == 4) {
         const int rc = pgt_igemm4_launch(&p, d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256), st);
         PGT_CHECK(rc != 1, "pgt_conv2d: kernel=4 has no %d-column tile (128, 256)", d->force_bn);

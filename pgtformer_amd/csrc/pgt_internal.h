@@ -20,3 +20,5 @@ int pgt_igemm3_launch(const void* conv_p, int bm, int bn, int stages, hipStream_
 int pgt_igemm4_launch(const void* conv_p, int bn, hipStream_t st);
 // igemm5.hip: igemm4's 256x256 schedule with one LDS input image shared by the three horizontal taps (3-wide filters)
 int pgt_igemm5_launch(const void* conv_p, hipStream_t st);
+// igemm6.hip: 3x3, Cin == 64, Cout <= 64: weights in registers, persistent workgroups, one halo image per filter row
+int pgt_igemm6_launch(const void* conv_p, hipStream_t st);

@@ -69,7 +69,7 @@ def _ld_rows(x):
 # heuristic stays one of the candidates, so tuning never loses to it.  fp32 (parity) launches are never tuned.
 AUTOTUNE = None
 _TUNE_CANDIDATES = ((0, (0, 0), 0), (1, (64, 64), 0), (1, (64, 128), 0), (1, (128, 64), 0), (1, (128, 128), 0),
-                    (3, (256, 256), 2), (4, (0, 256), 0), (4, (0, 128), 0), (5, (0, 0), 0))
+                    (3, (256, 256), 2), (4, (0, 256), 0), (4, (0, 128), 0), (5, (0, 0), 0), (6, (0, 0), 0))
 
 
 def enable_autotune(flag=True):

@@ -480,3 +480,35 @@ def test_conv2d_tap_reuse_kernel(shape):
     dec, shf = rnd(tuple(want.shape), 414, dtype), rnd(tuple(want.shape), 415, dtype)
     check(f"{name}_v5_sft", ops().conv2d(gx, gw, gb, sft=(g(dec), g(shf), 0.6), kernel=5, **kw),
           E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)
+
+
+V6_SHAPES = [("v6_w32", 2, 32, 32, 64, 64), ("v6_w64_c40", 1, 16, 64, 64, 40), ("v6_w128", 3, 8, 128, 64, 64),
+             ("v6_w512_ragged_m", 1, 2, 512, 64, 64), ("v6_many_tiles", 6, 128, 128, 64, 64), ("v6_c8", 1, 32, 64, 64, 8), ("v6_c3_scalar_epilogue", 2, 32, 64, 64, 3)]
+
+
+@pytest.mark.parametrize("shape", V6_SHAPES, ids=[s[0] for s in V6_SHAPES])
+def test_conv2d_c64_kernel(shape):
+    """igemm6 (3x3, Cin = 64, Cout <= 64: register-resident weights, persistent workgroups, halo images) against the
+    emulation and v1, all epilogues, repeat-run determinism."""
+    name, n, h, w_, cin, cout = shape
+    dtype = torch.bfloat16
+    x = rnd((n, h, w_, cin), 510, dtype)
+    wt = rnd((cout, 9 * cin), 511, dtype, 1.0 / np.sqrt(9 * cin))
+    wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
+    b = rnd((cout,), 512, torch.float32, 0.1)
+    kw = dict(kh=3, kw=3, pad=(1, 1, 1, 1))
+    gx, gw, gb = g(x), g(wt), g(b)
+    want = E.conv2d(x, wt, b, act=E.ACT_SILU, **kw)
+    check(f"{name}_v6", ops().conv2d(gx, gw, gb, act=E.ACT_SILU, kernel=6, **kw), want, dtype)
+    res = rnd(tuple(want.shape), 513, dtype)
+    gres = g(res)
+    got = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=6, **kw)
+    check(f"{name}_v6_res", got, E.conv2d(x, wt, b, res=res, post_relu=True, **kw), dtype)
+    v1 = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=1, **kw)
+    check(f"{name}_v6_v1", got, v1, dtype, 0.2)
+    for _ in range(10):
+        again = ops().conv2d(gx, gw, gb, res=gres, post_relu=True, kernel=6, **kw)
+        assert torch.equal(again, got), f"{name}: igemm6 is not run-to-run deterministic"
+    dec, shf = rnd(tuple(want.shape), 514, dtype), rnd(tuple(want.shape), 515, dtype)
+    check(f"{name}_v6_sft", ops().conv2d(gx, gw, gb, sft=(g(dec), g(shf), 0.6), kernel=6, **kw),
+          E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)

@@ -108,6 +108,10 @@ def main():
             t5 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=5), args.iters)
             best = min(best, t5)
             v3 += f" v5/256={t5:6.1f}"
+        if dt == torch.bfloat16 and cin == 64 and cout <= 64 and cout % 8 == 0 and stride == 1 and not ups and k == 3:
+            t6 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=6), args.iters)
+            best = min(best, t6)
+            v3 += f" v6={t6:6.1f}"
         cells.append(v3)
         ta = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res), args.iters)
         total_best += best * cnt
