@@ -63,6 +63,11 @@ typedef struct pgt_conv_desc {
     int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 3 = large-tile v3; 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-channel 3x3 */
     int32_t splitk;             /* 0 = auto (needs a workspace); 1 = never; 2..16 = that many K slices           */
     int32_t stages;             /* LDS pipeline depth for kernel = 3 (0 = default)                             */
+    /* output placement: row index of output pixel m = orow_mul*m + orow_xmul*(m % Wo) + orow_off (orow_mul = 0: dense,
+     * row m).  (4, -2, py*2*Wo + px) writes parity (py, px) of a 2x larger map: the four 2x2 sub-pixel convolutions
+     * that replace nearest-x2 up-sampling + conv3x3 (archs/tdcrqvae3_arch.py:34-52).  Plain epilogue only (no
+     * residual / SFT operands); kernels 1 and 4 (and 0 = auto).                                                  */
+    int32_t orow_mul, orow_xmul, orow_off;
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,

@@ -263,8 +263,8 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
                 }
-                if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n, v);
-                else store8<T>(reinterpret_cast<T*>(p.y) + (long)m * p.ldy + n, v);
+                if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + out_row(p, m) * p.ldy + n, v);
+                else store8<T>(reinterpret_cast<T*>(p.y) + out_row(p, m) * p.ldy + n, v);
             }
             __syncthreads();
         }
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
                     if (res) v += ldf(res + (long)m * p.ldr + n);
                     if (p.post_relu) v = v > 0.f ? v : 0.f;
                 }
-                if (p.out_f32) reinterpret_cast<float*>(p.y)[(long)m * p.ldy + n] = v;
-                else stf(y + (long)m * p.ldy + n, v);
+                if (p.out_f32) reinterpret_cast<float*>(p.y)[out_row(p, m) * p.ldy + n] = v;
+                else stf(y + out_row(p, m) * p.ldy + n, v);
             }
         }
     }
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, const flo
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
     }
-    if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n, v);
-    else store8<T>(reinterpret_cast<T*>(p.y) + (long)m * p.ldy + n, v);
+    if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + out_row(p, m) * p.ldy + n, v);
+    else store8<T>(reinterpret_cast<T*>(p.y) + out_row(p, m) * p.ldy + n, v);
 }
 
 // Split-K policy: deep-K layers whose 64x64 tiling leaves most of the chip idle (32x32-resolution convs).
@@ -433,6 +433,10 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.ld_shift = d->ld_shift; p.sft_w = d->sft_w; p.out_f32 = d->out_f32;
     p.M = d->N * d->Ho * d->Wo;
     p.K = d->KH * d->KW * d->Cin;
+    p.orow_mul = d->orow_mul; p.orow_xmul = d->orow_xmul; p.orow_off = d->orow_off;
+    const bool placed = d->orow_mul != 0;
+    PGT_CHECK(!placed || (!residual && d->epi == 0), "pgt_conv2d: output placement (orow_*) takes the plain epilogue without residual");
+    PGT_CHECK(!placed || d->kernel == 0 || d->kernel == 1 || d->kernel == 4, "pgt_conv2d: output placement needs kernel 0, 1 or 4");
     p.nbm = p.nbn = 0;
     p.splitk = 1;
     p.kt_per_split = 0;
@@ -451,6 +455,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         ps.bias = nullptr; ps.res = nullptr; ps.dec = nullptr; ps.shift = nullptr;
         ps.act = 0; ps.post_relu = 0; ps.epi = 0; ps.out_f32 = 1; ps.vec_epi = 1;
         ps.y = (char*)workspace; ps.ldy = p.Cout;
+        ps.orow_mul = ps.orow_xmul = ps.orow_off = 0;   // the fp32 slabs are dense; only the reduce kernel places rows
         ps.splitk = slices;
         const int bk = d->dtype == PGT_F32 ? 32 : 64;
         const int nk = (p.K + bk - 1) / bk;
@@ -472,7 +477,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     const bool v2_legal = d->Cin % 64 == 0 && p.vec_epi && ((uintptr_t)x & 15) == 0 && d->ldx % 8 == 0;
     PGT_CHECK(d->kernel != 2 || v2_legal, "pgt_conv2d: kernel=2 needs bf16, Cin %% 64 == 0 and a 16-byte-legal epilogue");
     // v3 (large tiles, 8-16 waves): additionally stride 1, no up-sampling, <= 32 taps, 32-bit byte offsets
-    const bool v3_legal = v2_legal && d->stride == 1 && d->ups == 0 && d->KH * d->KW <= 32 &&
+    const bool v3_legal = v2_legal && !placed && d->stride == 1 && d->ups == 0 && d->KH * d->KW <= 32 &&
                           (long)d->N * d->H * d->W * d->ldx * 2 < (1L << 31);
     PGT_CHECK(d->kernel != 3 || v3_legal, "pgt_conv2d: kernel=3 needs bf16, stride 1, no up-sampling, Cin %% 64 == 0");
     // auto: 256x256 tiles (16 waves, 2 LDS stages) win on the Cout >= 256 convs once the grid covers the chip at
@@ -486,12 +491,12 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     PGT_CHECK(d->kernel != 4 || v4_legal, "pgt_conv2d: kernel=4 needs bf16, Cin %% 64 == 0, <= 30 taps, tensors < 2 GiB");
     // v5 (v4's 256x256 schedule + horizontal tap reuse): 3-wide filters, stride 1, same-size power-of-two maps
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    const bool v5_legal = v4_legal && d->stride == 1 && d->ups == 0 && d->KW == 3 && d->KH <= 8 && d->Ho == d->H &&
+    const bool v5_legal = v4_legal && !placed && d->stride == 1 && d->ups == 0 && d->KW == 3 && d->KH <= 8 && d->Ho == d->H &&
                           d->Wo == d->W && pow2(d->W) && pow2(d->H) && d->W >= 32;
     PGT_CHECK(d->kernel != 5 || v5_legal, "pgt_conv2d: kernel=5 needs a 3-wide stride-1 same-size conv on power-of-two maps (W >= 32)");
     if (d->kernel == 5) return pgt_igemm5_launch(&p, st);
     // v6 (register-resident weights, persistent, halo images): the 64-channel 3x3 layers
-    const bool v6_legal = d->Cin == 64 && d->Cout <= 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ups == 0 &&
+    const bool v6_legal = !placed && d->Cin == 64 && d->Cout <= 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ups == 0 &&
                           d->Ho == d->H && d->Wo == d->W && pow2(d->W) && pow2(d->H) && d->W >= 32 && d->ldx % 8 == 0;
     PGT_CHECK(d->kernel != 6 || v6_legal, "pgt_conv2d: kernel=6 needs a 3x3 stride-1 same-size conv, Cin == 64, Cout <= 64, power-of-two maps");
     if (d->kernel == 6) return pgt_igemm6_launch(&p, st);
@@ -506,7 +511,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         PGT_CHECK(rc != 1, "pgt_conv2d: kernel=3 tile %dx%d with %d stages is not built", d->force_bm, d->force_bn, d->stages);
         return rc;
     }
-    if (v2_legal && d->kernel != 1) {
+    if (v2_legal && !placed && d->kernel != 1) {
         const int bn = (d->force_bn == 64 || (d->force_bn == 0 && d->Cout <= 64)) ? 64 : 128;
         const long blocks = (long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
         if (d->kernel == 2 || (d->kernel == 0 && d->force_bm == 0 && d->force_bn == 0 && blocks >= kV2MinBlocks && p.K >= kV2MinK))

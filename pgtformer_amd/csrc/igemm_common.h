@@ -36,7 +36,13 @@ struct ConvP {
     int M, K, nbm, nbn;
     int splitk, kt_per_split;   // > 1: K is cut in `splitk` slices of `kt_per_split` K tiles each
     int wo_shift, ho_shift;     // igemm4: log2(Wo), log2(Ho) when both are powers of two, else -1 (set by its launcher)
+    int orow_mul, orow_xmul, orow_off;   // output row of pixel m (orow_mul = 0: m), see pgt_conv_desc
 };
+
+// row index of output pixel m in y (dense, or the sub-pixel placement of pgt_conv_desc::orow_*)
+__device__ __forceinline__ long out_row(const ConvP& p, int m) {
+    return p.orow_mul ? (long)p.orow_mul * m + p.orow_xmul * (m % p.Wo) + p.orow_off : (long)m;
+}
 
 }  // namespace
 

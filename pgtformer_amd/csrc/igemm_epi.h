@@ -99,8 +99,8 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
                     for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
             }
-            if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + n, v);
-            else store8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + n, v);
+            if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + out_row(p, m) * p.ldy + n, v);
+            else store8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + out_row(p, m) * p.ldy + n, v);
         }
         if (pass == 0) __syncthreads();
     }

@@ -21,7 +21,8 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("dtype", "N", "H", "W", "Cin", "ldx", "ups", "KH", "KW", "stride", "pad_t",
                                    "pad_l", "Ho", "Wo", "Cout", "ldy", "act", "post_relu", "ldr", "epi",
                                    "ld_dec", "ld_shift")] + [("sft_w", f32)] + \
-               [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue", "kernel", "splitk", "stages")]
+               [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue", "kernel", "splitk", "stages",
+                                   "orow_mul", "orow_xmul", "orow_off")]
 
 
 # name -> argtypes (restype is int32 unless listed in _RESTYPES); must cover every symbol of pgt_hip.h

@@ -512,3 +512,49 @@ def test_conv2d_c64_kernel(shape):
     dec, shf = rnd(tuple(want.shape), 514, dtype), rnd(tuple(want.shape), 515, dtype)
     check(f"{name}_v6_sft", ops().conv2d(gx, gw, gb, sft=(g(dec), g(shf), 0.6), kernel=6, **kw),
           E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)
+
+
+def test_conv2d_output_parity_placement_splitk():
+    """Split-K with output placement: the fp32 slabs stay dense, the reduce kernel scatters the rows (small, deep-K layer:
+    the first decoder up-sampling at 16x16)."""
+    dtype = torch.bfloat16
+    n, h, w_, cin, cout = 3, 16, 16, 512, 512
+    x = rnd((n, h, w_, cin), 620, dtype)
+    b = rnd((cout,), 622, torch.float32, 0.1)
+    out = torch.zeros((n, 2 * h, 2 * w_, cout), dtype=dtype, device="cuda")
+    guard = torch.zeros((1 << 20,), dtype=torch.float32, device="cuda")   # lands right after `out` in a fresh pool
+    ref = torch.zeros((n, 2 * h, 2 * w_, cout), dtype=dtype)
+    for py in (0, 1):
+        for px in (0, 1):
+            w2 = rnd((cout, 4 * cin), 623 + 2 * py + px, dtype, 1.0 / np.sqrt(4 * cin))
+            kw = dict(kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out_parity=(py, px))
+            ops().conv2d(g(x), g(w2), g(b), out=out, splitk=4, **kw)
+            E.conv2d(x, w2, b, out=ref, **kw)
+    torch.cuda.synchronize()
+    check("parity_splitk", out, ref, dtype)
+    assert float(guard.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 4])
+def test_conv2d_output_parity_placement(kernel):
+    """2x2 sub-pixel convolution written to out[:, py::2, px::2, :] (pgt_conv_desc::orow_*) for all four parities; the
+    merged-tap decomposition reproduces nearest-x2 + conv3x3."""
+    dtype = torch.bfloat16
+    n, h, w_, cin, cout = 2, 12, 32, 64, 128
+    x = rnd((n, h, w_, cin), 610, dtype)
+    w3 = rnd((cout, 3, 3, cin), 611, torch.float32, 1.0 / np.sqrt(9 * cin))
+    b = rnd((cout,), 612, torch.float32, 0.1)
+    rows = (((0,), (1, 2)), ((0, 1), (2,)))
+    out = torch.zeros((n, 2 * h, 2 * w_, cout), dtype=dtype, device="cuda")
+    ref = torch.zeros((n, 2 * h, 2 * w_, cout), dtype=dtype)
+    for py in (0, 1):
+        for px in (0, 1):
+            w2 = torch.stack([torch.stack([sum(w3[:, ky, kx, :] for ky in rows[py][a] for kx in rows[px][bb])
+                                           for bb in (0, 1)], 1) for a in (0, 1)], 1).reshape(cout, -1).to(dtype)
+            kw = dict(kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out_parity=(py, px))
+            extra = dict(kernel=kernel, tile=(0, 128)) if kernel == 4 else dict(kernel=kernel)
+            ops().conv2d(g(x), g(w2), g(b), out=out, **extra, **kw)
+            E.conv2d(x, w2, b, out=ref, **kw)
+    check(f"parity_k{kernel}", out, ref, dtype)
+    full = E.conv2d(x, w3.reshape(cout, -1).to(dtype), b, kh=3, kw=3, pad=(1, 1, 1, 1), ups=True)
+    check(f"parity_vs_ups_k{kernel}", out, full, dtype, 2.0)   # merged taps are rounded to bf16 once, not three times

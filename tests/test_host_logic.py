@@ -90,3 +90,23 @@ def test_stage1_host_logic_matches_reference(cpu_model, golden_window, monkeypat
     out, _, codes = TDCRQVAE3.forward(cpu_model, x)
     assert (codes.numpy().astype(np.int16) == g["stage1_codes"]).mean() == 1.0
     assert np.abs(out[1, :, 192:320, 192:320].numpy() - g["stage1_out_mid_crop"]).max() < 5e-3
+
+
+def test_subpixel_upsample_matches_resize_then_conv():
+    """Upsample in the bf16 modes runs four 2x2 sub-pixel convolutions with merged taps instead of nearest-x2 + conv3x3
+    (reference: tdcrqvae3_arch.py:34-52): same result (checked in fp32 through the CPU emulation of the ops)."""
+    import torch
+    from pgtformer_amd.archs.tdcrqvae3_arch import Upsample
+    torch.manual_seed(3)
+    up = Upsample(16, True)
+    x = torch.randn(2, 5, 7, 16)
+    want = emu_ops.conv2d(x, up.conv.weight.detach().permute(0, 2, 3, 1).reshape(16, -1).contiguous(), up.conv.bias.detach(),
+                          kh=3, kw=3, pad=(1, 1, 1, 1), ups=True)
+    up._pack("cpu", torch.bfloat16)          # builds the merged 2x2 weights (bf16) ...
+    out = torch.empty(2, 10, 14, 16)
+    for (py, px), w2 in up.sub_w.items():    # ... checked here in fp32 from the same fp32 sums
+        w2f = torch.stack([torch.stack([sum(up.conv.weight.detach()[:, :, ky, kx] for ky in up._ROWS[py][a] for kx in up._ROWS[px][b])
+                                        for b in (0, 1)], -1) for a in (0, 1)], -2).permute(0, 2, 3, 1).reshape(16, -1).contiguous()
+        assert torch.allclose(w2.float(), w2f, atol=2e-2, rtol=1e-2)
+        emu_ops.conv2d(x, w2f, up.conv.bias.detach(), kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, out_parity=(py, px))
+    assert torch.allclose(out, want, atol=1e-5, rtol=1e-5), float((out - want).abs().max())
