@@ -210,8 +210,25 @@ class ResBlock(HipModule):
         if self.in_channels != self.out_channels:
             self.conv_out = Conv2d(in_channels, self.out_channels, 1)
 
+    def _pack(self, device, dtype):
+        # bf16: a channel count that is not a multiple of 64 (the [enc|dec|fut] concats: 288, 544, 1056) is padded with
+        # zero channels / zero filter taps so that the large-tile LDS-DMA kernels (64-channel K blocks) apply
+        cin = self.in_channels
+        self.cpad = (cin + 63) // 64 * 64 if (dtype != torch.float32 and cin % 64 and cin > 64) else None
+        self.conv1.cin_pad = self.cpad
+        if cin != self.out_channels:
+            self.conv_out.cin_pad = self.cpad
+
     def forward(self, x_in):
-        h = self.conv1.run(self.norm1.run(x_in, ACT_SILU))
+        """x_in: (n,h,w,Cin); with channel padding active the caller passes the (n,h,w,cpad) buffer (zero pad channels)."""
+        if self.cpad is not None:
+            assert x_in.shape[-1] == self.cpad, (x_in.shape, self.cpad)
+            n, hh, ww, _ = x_in.shape
+            hbuf = torch.zeros((n, hh, ww, self.cpad), device=x_in.device, dtype=x_in.dtype)
+            self.norm1.run(x_in[..., :self.in_channels], ACT_SILU, out=hbuf[..., :self.in_channels])
+            h = self.conv1.run(hbuf)
+        else:
+            h = self.conv1.run(self.norm1.run(x_in, ACT_SILU))
         h = self.norm2.run(h, ACT_SILU)
         sc = self.conv_out.run(x_in) if self.in_channels != self.out_channels else x_in
         return self.conv2.run(h, res=sc)
@@ -242,6 +259,24 @@ class Fuse_sft_block(HipModule):
             return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
         self.w_ss0 = torch.cat([packed(self.scale[0]), packed(self.shift[0])], 0).to(device=device, dtype=dtype).contiguous()
         self.b_ss0 = _f32(torch.cat([self.scale[0].bias.detach(), self.shift[0].bias.detach()], 0), device)
+        # bf16: tconvenc/tconvdec -> stack over T -> tfusion0 -> tfusion1 are all 1x1 and linear (reference :467-473), so
+        # fut of output frame `to` is ONE linear map of the window's T [enc|dec] pixels: a (T x 1)-tap conv over the
+        # concat buffer viewed as (windows, T, h*w, channels), K = T * 2C, composed here in fp32.
+        self.w_mix = None
+        if dtype != torch.float32:
+            t, tcc, c = self.t, self.tcc, self.in_ch
+            we, be = self.tconvenc.weight.detach().float().view(tcc, c), self.tconvenc.bias.detach().float()
+            wd_, bd = self.tconvdec.weight.detach().float().view(tcc, c), self.tconvdec.bias.detach().float()
+            w0, b0 = self.tfusion0.weight.detach().float().view(t * tcc, 2 * t * tcc), self.tfusion0.bias.detach().float()
+            w1, b1 = self.tfusion1.weight.detach().float().view(tcc, tcc), self.tfusion1.bias.detach().float()
+            bcat = torch.cat([be] * t + [bd] * t)
+            self.w_mix, self.b_mix = [], []
+            for to in range(t):
+                rows = w0[to * tcc:(to + 1) * tcc]                                           # (tcc, 2*t*tcc)
+                taps = [torch.cat([w1 @ rows[:, ti * tcc:(ti + 1) * tcc] @ we,
+                                   w1 @ rows[:, (t + ti) * tcc:(t + ti + 1) * tcc] @ wd_], 1) for ti in range(t)]
+                self.w_mix.append(torch.stack(taps, 1).reshape(tcc, -1).contiguous().to(device=device, dtype=dtype))
+                self.b_mix.append(_f32(w1 @ (rows @ bcat + b0[to * tcc:(to + 1) * tcc]) + b1, device))
 
     def forward(self, enc_feat, dec_feat, temb=None, w=1):
         """enc_feat, dec_feat: (B*T, h, w, C) (reference: :460-484)."""
@@ -249,6 +284,21 @@ class Fuse_sft_block(HipModule):
         t, tcc = self.t, self.tcc
         b = n // t
         dev, dt = dec_feat.device, dec_feat.dtype
+        if self.w_mix is not None:
+            ct = 2 * c + tcc
+            ctp = self.encode_enc.cpad if self.encode_enc.cpad is not None else ct
+            cat = (torch.zeros if ctp != ct else torch.empty)((n, h, wd, ctp), device=dev, dtype=dt)   # [enc | dec | fut | 0]
+            ops.copy_into(enc_feat, cat[..., :c])
+            ops.copy_into(dec_feat, cat[..., c:2 * c])
+            src = cat.view(b, t, h * wd, ctp)[..., :2 * c]            # windows x T frames x pixels x [enc|dec]
+            dst = cat.view(n, 1, h * wd, ctp)[..., 2 * c:ct]          # fut channels, rows = frame * h*w + pixel
+            for to in range(t):   # output pixel m = window*h*w + pix  ->  row (window*T + to)*h*w + pix
+                ops.conv2d(src, self.w_mix[to], self.b_mix[to], kh=t, kw=1, out=dst, out_rows=(t, 1 - t, to * h * wd))
+            e = self.encode_enc(cat if self.encode_enc.cpad is not None else cat[..., :ct])
+            ss = ops.conv2d(e, self.w_ss0, self.b_ss0, kh=3, kw=3, pad=(1, 1, 1, 1), act=ACT_LEAKY02)
+            co = self.out_ch
+            shift = self.shift[2].run(ss[..., co:])
+            return self.scale[2].run(ss[..., :co], sft=(dec_feat, shift, w))
         # per-frame 1x1 -> T frames stacked on channels: [enc t0..t2 | dec t0..t2]
         stacked = torch.empty((b, h, wd, 2 * t * tcc), device=dev, dtype=dt)
         for bi in range(b):

@@ -86,8 +86,8 @@ class GroupNorm(nn.GroupNorm, HipModule):
     def _pack(self, device, dtype):
         self.pg, self.pbeta = _f32(self.weight, device), _f32(self.bias, device)
 
-    def run(self, x, act=ACT_SILU):
-        return ops.groupnorm_act(x, self.pg, self.pbeta, act, self.num_groups, self.eps)
+    def run(self, x, act=ACT_SILU, out=None):
+        return ops.groupnorm_act(x, self.pg, self.pbeta, act, self.num_groups, self.eps, out=out)
 
 
 class LayerNorm(nn.LayerNorm, HipModule):

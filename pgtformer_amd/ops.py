@@ -115,11 +115,13 @@ def _tune_conv(d, args, device, iters=4):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None):
+           out_parity=None, out_rows=None):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout).
     out_parity=(py, px): write the (N,Ho,Wo,Cout) result to out[:, py::2, px::2, :] of a required (N,2Ho,2Wo,Cout) `out`
-    (sub-pixel convolutions; plain epilogue only)."""
+    (sub-pixel convolutions; plain epilogue only).
+    out_rows=(mul, xmul, off): general form - output pixel m is written to row mul*m + xmul*(m % Wo) + off of `out`
+    (any (..., Cout) view; its pixel stride is the row pitch)."""
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     assert w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
@@ -129,6 +131,9 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     wo = (wv + pad[2] + pad[3] - kw) // stride + 1
     if out_parity is not None:
         assert out is not None and tuple(out.shape) == (n, 2 * ho, 2 * wo, cout) and res is None and sft is None
+        out_rows = (4, -2, out_parity[0] * 2 * wo + out_parity[1])
+    elif out_rows is not None:
+        assert out is not None and out.shape[-1] == cout and res is None and sft is None
     else:
         if out is None:
             out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
@@ -146,8 +151,8 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.kernel = int(kernel)
     d.splitk = int(splitk)
     d.stages = int(stages)
-    if out_parity is not None:
-        d.orow_mul, d.orow_xmul, d.orow_off = 4, -2, out_parity[0] * 2 * wo + out_parity[1]
+    if out_rows is not None:
+        d.orow_mul, d.orow_xmul, d.orow_off = out_rows
     dec = shift = None
     if sft is not None:
         dec, shift, sw = sft
@@ -163,7 +168,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     if (AUTOTUNE is not None and kernel == 0 and tile == (0, 0) and splitk == 0 and not scalar_epi
             and x.dtype == torch.bfloat16):
         key = (n, h, wd, cin, d.ldx, d.ups, kh, kw, stride, tuple(pad), cout, d.ldy, act, d.post_relu, d.ldr, d.epi,
-               d.ld_dec, d.ld_shift, d.out_f32, bias is None, d.orow_mul, d.orow_off)
+               d.ld_dec, d.ld_shift, d.out_f32, bias is None, d.orow_mul, d.orow_xmul, d.orow_off)
         cfg = AUTOTUNE.get(key)
         if cfg is None and not torch.cuda.is_current_stream_capturing():
             cfg = AUTOTUNE[key] = _tune_conv(d, (_p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out)), x.device)
@@ -219,9 +224,9 @@ def affine_act(x, scale, shift, act=ACT_NONE, out=None):
     return out
 
 
-def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6):
+def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6, out=None):
     scale, shift = groupnorm_affine(x, gamma, beta, groups, eps)
-    return affine_act(x, scale, shift, act)
+    return affine_act(x, scale, shift, act, out=out)
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pos=None):

@@ -36,7 +36,7 @@ def _store(val, out, dtype):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None):
+           out_parity=None, out_rows=None):
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     assert w.shape[1] == kh * kw * cin and w.dtype == x.dtype
@@ -57,6 +57,14 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
             y = F.relu(y)
     if out_parity is not None:
         out[:, out_parity[0]::2, out_parity[1]::2, :] = y.to(out.dtype)
+        return out
+    if out_rows is not None:
+        mul, xmul, off = out_rows
+        wo = y.shape[2]
+        m = torch.arange(y.shape[0] * y.shape[1] * wo)
+        rows = mul * m + xmul * (m % wo) + off
+        flat = out.as_strided((int(rows.max()) + 1, cout), (out.stride(-2), 1))
+        flat[rows] = y.reshape(-1, cout).to(out.dtype)
         return out
     return _store(y, out, torch.float32 if out_f32 else x.dtype)
 
@@ -87,9 +95,9 @@ def affine_act(x, scale, shift, act=ACT_NONE, out=None):
     return _store(y, out, x.dtype)
 
 
-def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6):
+def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6, out=None):
     s, b = groupnorm_affine(x, gamma, beta, groups, eps)
-    return affine_act(x, s, b, act)
+    return affine_act(x, s, b, act, out=out)
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pos=None):

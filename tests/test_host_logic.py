@@ -110,3 +110,26 @@ def test_subpixel_upsample_matches_resize_then_conv():
         assert torch.allclose(w2.float(), w2f, atol=2e-2, rtol=1e-2)
         emu_ops.conv2d(x, w2f, up.conv.bias.detach(), kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, out_parity=(py, px))
     assert torch.allclose(out, want, atol=1e-5, rtol=1e-5), float((out - want).abs().max())
+
+
+def test_fuse_block_bf16_restructuring_matches_fp32_path(monkeypatch):
+    """bf16 modes restructure Fuse_sft_block (reference :460-484): the per-frame 1x1 temporal mix becomes three (T x 1)-tap
+    convs with composed weights written in place into the concat buffer, and the 2C+32-channel concat is zero-padded to
+    a multiple of 64 channels.  Same function as the reference-order fp32 path (checked through the CPU emulation)."""
+    import torch
+    from pgtformer_amd.archs.pgtformer_arch import Fuse_sft_block
+    from pgtformer_amd.modules.rstt_layers import prepare_tree
+    emu_ops.install(monkeypatch)
+    torch.manual_seed(0)
+    blk = Fuse_sft_block(128, 128)
+    for p_ in blk.parameters():
+        torch.nn.init.normal_(p_, std=0.05)
+    enc, dec = torch.randn(6, 8, 8, 128), torch.randn(6, 8, 8, 128)
+    prepare_tree(blk, "cpu", torch.float32)
+    assert blk.w_mix is None and blk.encode_enc.cpad is None
+    ref = blk(enc, dec, w=0.7)
+    prepare_tree(blk, "cpu", torch.bfloat16)
+    assert blk.w_mix is not None and blk.encode_enc.cpad == 320
+    got = blk(enc.to(torch.bfloat16), dec.to(torch.bfloat16), w=0.7).float()
+    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert rel < 3e-2, rel
