@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "mixed", "fp32"])
-    ap.add_argument("--windows-per-forward", type=int, default=8,
+    ap.add_argument("--windows-per-forward", type=int, default=16,
                     help="independent 3-frame windows batched into one forward (reference semantics: B separate calls)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -126,6 +126,21 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     cout = w.shape[0]
     assert w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
     assert w.dtype == x.dtype and w.is_contiguous()
+    if n > 1 and n * h * wd * _ld_img(x) * x.element_size() >= (1 << 31) and out_rows is None and out_parity is None:
+        # the kernels take 32-bit byte offsets: run a >= 2 GiB input as frame chunks (frames are independent)
+        hv0, wv0 = (h * 2, wd * 2) if ups else (h, wd)
+        ho0 = (hv0 + pad[0] + pad[1] - kh) // stride + 1
+        wo0 = (wv0 + pad[2] + pad[3] - kw) // stride + 1
+        if out is None:
+            out = torch.empty((n, ho0, wo0, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+        per = max(1, ((1 << 31) - 1) // (h * wd * _ld_img(x) * x.element_size()))
+        for i in range(0, n, per):
+            sl = slice(i, min(n, i + per))
+            conv2d(x[sl], w, bias, kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, act=act,
+                   res=None if res is None else res[sl], post_relu=post_relu,
+                   sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
+                   tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages)
+        return out
     hv, wv = (h * 2, wd * 2) if ups else (h, wd)
     ho = (hv + pad[0] + pad[1] - kh) // stride + 1
     wo = (wv + pad[2] + pad[3] - kw) // stride + 1

@@ -228,3 +228,21 @@ def test_batched_windows_equal_separate_forwards(models):
     for j in range(3):
         want = (sep[j][1].clamp(0, 1) * 255).to(torch.uint8)
         assert (out[j].int() - want.int()).abs().max().item() <= 1, j
+
+
+def test_large_batch_chunks_inputs_over_2gib(models):
+    """16 windows per forward: the 128-channel 512x512 tensors exceed 2 GiB (32-bit gather offsets), ops.conv2d then runs
+    frame chunks; first / middle / last window equal their single-window forwards (fp32: round-off only)."""
+    from pgtformer_amd.synth import make_clip
+
+    m = models["fp32"]
+    lq, _ = make_clip(18, 512, seed=78)
+    clip = torch.from_numpy(lq).to(DEV)
+    wins = [clip[j:j + 3] for j in range(16)]
+    both = m.forward_nhwc(torch.cat(wins, 0).contiguous(), w=1.0)[0].float()
+    err = 0.0
+    for j in (0, 9, 15):
+        sep = m.forward_nhwc(wins[j].contiguous(), w=1.0)[0].float()
+        err = max(err, (both[3 * j:3 * j + 3] - sep).abs().max().item())
+    _LOG["batch16_vs_separate_f32"] = {"max_abs_err": err}
+    assert err < 2e-3
