@@ -13,19 +13,24 @@ import sqlite3
 import sys
 
 
-def per_kernel(db, counter, like):
+FAMILY = ("%igemm%_kernel%", "%conv3x3_c64_kernel%")   # the conv / linear kernels of csrc/igemm*.hip
+
+
+def per_kernel(db, counter, likes):
     c = sqlite3.connect(db)
-    rows = c.execute("select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? "
-                     "and kernel_name like ? group by kernel_name", (counter, like)).fetchall()
+    rows = []
+    for like in likes:
+        rows += c.execute("select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? "
+                          "and kernel_name like ? group by kernel_name", (counter, like)).fetchall()
     tot = sum(r[1] for r in rows)
     n = sum(r[2] for r in rows)
     return tot, n
 
 
 def main(fetch_db, write_db, out):
-    f_kib, nf = per_kernel(fetch_db, "FETCH_SIZE", "%igemm%_kernel%")
-    w_kib, nw = per_kernel(write_db, "WRITE_SIZE", "%igemm%_kernel%")
-    res = {"kernel": "igemm*_kernel (igemm, igemm3, igemm4)", "launches": nf,
+    f_kib, nf = per_kernel(fetch_db, "FETCH_SIZE", FAMILY)
+    w_kib, nw = per_kernel(write_db, "WRITE_SIZE", FAMILY)
+    res = {"kernel": "conv/linear family: igemm*_kernel (igemm, igemm3, igemm4, igemm5) + conv3x3_c64_kernel (igemm6)", "launches": nf,
            "fetch_bytes_per_launch_raw": f_kib * 1024 / max(nf, 1),
            "fetch_bytes_per_launch_corrected_x2": 2 * f_kib * 1024 / max(nf, 1),
            "write_bytes_per_launch": w_kib * 1024 / max(nw, 1),
