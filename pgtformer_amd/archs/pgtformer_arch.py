@@ -224,7 +224,8 @@ class ResBlock(HipModule):
         if self.cpad is not None:
             assert x_in.shape[-1] == self.cpad, (x_in.shape, self.cpad)
             n, hh, ww, _ = x_in.shape
-            hbuf = torch.zeros((n, hh, ww, self.cpad), device=x_in.device, dtype=x_in.dtype)
+            hbuf = torch.empty((n, hh, ww, self.cpad), device=x_in.device, dtype=x_in.dtype)
+            hbuf[..., self.in_channels:].zero_()                     # only the pad channels need the zeros
             self.norm1.run(x_in[..., :self.in_channels], ACT_SILU, out=hbuf[..., :self.in_channels])
             h = self.conv1.run(hbuf)
         else:
@@ -287,7 +288,9 @@ class Fuse_sft_block(HipModule):
         if self.w_mix is not None:
             ct = 2 * c + tcc
             ctp = self.encode_enc.cpad if self.encode_enc.cpad is not None else ct
-            cat = (torch.zeros if ctp != ct else torch.empty)((n, h, wd, ctp), device=dev, dtype=dt)   # [enc | dec | fut | 0]
+            cat = torch.empty((n, h, wd, ctp), device=dev, dtype=dt)   # [enc | dec | fut | 0]
+            if ctp != ct:
+                cat[..., ct:].zero_()
             ops.copy_into(enc_feat, cat[..., :c])
             ops.copy_into(dec_feat, cat[..., c:2 * c])
             src = cat.view(b, t, h * wd, ctp)[..., :2 * c]            # windows x T frames x pixels x [enc|dec]
