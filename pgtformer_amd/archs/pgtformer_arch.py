@@ -279,20 +279,34 @@ class Fuse_sft_block(HipModule):
                 self.w_mix.append(torch.stack(taps, 1).reshape(tcc, -1).contiguous().to(device=device, dtype=dtype))
                 self.b_mix.append(_f32(w1 @ (rows @ bcat + b0[to * tcc:(to + 1) * tcc]) + b1, device))
 
-    def forward(self, enc_feat, dec_feat, temb=None, w=1):
-        """enc_feat, dec_feat: (B*T, h, w, C) (reference: :460-484)."""
+    def concat_width(self):
+        """(real, padded) channel count of the [enc | dec | fut] concat buffer."""
+        ct = 2 * self.in_ch + self.tcc
+        return ct, (self.encode_enc.cpad if self.encode_enc.cpad is not None else ct)
+
+    def new_concat(self, n, h, wd, device, dtype):
+        """Concat buffer for a (n,h,wd,C) level (bf16 modes): producers may write its enc / dec slices directly."""
+        ct, ctp = self.concat_width()
+        cat = torch.empty((n, h, wd, ctp), device=device, dtype=dtype)
+        if ctp != ct:
+            cat[..., ct:].zero_()
+        return cat
+
+    def forward(self, enc_feat, dec_feat, temb=None, w=1, cat=None):
+        """enc_feat, dec_feat: (B*T, h, w, C) (reference: :460-484).  cat: a new_concat() buffer whose enc and/or dec
+        slices were already written by the producers (then enc_feat / dec_feat ARE those slices and are not copied)."""
         n, h, wd, c = dec_feat.shape
         t, tcc = self.t, self.tcc
         b = n // t
         dev, dt = dec_feat.device, dec_feat.dtype
         if self.w_mix is not None:
-            ct = 2 * c + tcc
-            ctp = self.encode_enc.cpad if self.encode_enc.cpad is not None else ct
-            cat = torch.empty((n, h, wd, ctp), device=dev, dtype=dt)   # [enc | dec | fut | 0]
-            if ctp != ct:
-                cat[..., ct:].zero_()
-            ops.copy_into(enc_feat, cat[..., :c])
-            ops.copy_into(dec_feat, cat[..., c:2 * c])
+            ct, ctp = self.concat_width()
+            if cat is None:
+                cat = self.new_concat(n, h, wd, dev, dt)               # [enc | dec | fut | 0]
+            if enc_feat.data_ptr() != cat.data_ptr():
+                ops.copy_into(enc_feat, cat[..., :c])
+            if dec_feat.data_ptr() != cat[..., c:2 * c].data_ptr():
+                ops.copy_into(dec_feat, cat[..., c:2 * c])
             src = cat.view(b, t, h * wd, ctp)[..., :2 * c]            # windows x T frames x pixels x [enc|dec]
             dst = cat.view(n, 1, h * wd, ctp)[..., 2 * c:ct]          # fut channels, rows = frame * h*w + pixel
             for to in range(t):   # output pixel m = window*h*w + pix  ->  row (window*T + to)*h*w + pix
@@ -386,8 +400,20 @@ class PGTFormer(TDCRQVAE3):
         cond = self.convpos.run(self.conditionnet(nx))                      # (bt,32,32,512)
         th, tw = cond.shape[1], cond.shape[2]
         pos = cond.reshape(bt * th * tw, cond.shape[3])                      # rows (b,t,y,x) == (T*H*W, B) order
-        # encoder
-        z, feats = self.encoder(raw, return_multi_res_feats=True)
+        # encoder.  bf16: the fusion blocks' [enc | dec | fut] concat buffers exist up front and the encoder levels / the
+        # decoder levels write their feature maps straight into the enc / dec slices (no concat copies)
+        cats, feat_out = {}, None
+        direct = (self.enc_dt == torch.bfloat16 and self.dec_dt == torch.bfloat16 and w > 0 and not code_only)
+        if direct:
+            feat_out = {}
+            for f_size in self.connect_list:
+                blk = self.fuse_convs_dict[f_size]
+                if blk.w_mix is None:
+                    continue
+                res = int(f_size)
+                cats[f_size] = blk.new_concat(bt, res, res, raw.device, torch.bfloat16)
+                feat_out[self.fuse_encoder_indices[f_size]] = cats[f_size][..., :blk.in_ch]
+        z, feats = self.encoder(raw, return_multi_res_feats=True, feat_out=feat_out)
         enc_feat = {}
         for f_size in self.connect_list:
             f = feats[self.fuse_encoder_indices[f_size]]
@@ -414,10 +440,17 @@ class PGTFormer(TDCRQVAE3):
 
         def fuse(f_size, h):
             if f_size in self.connect_list and w > 0:
-                return self.fuse_convs_dict[f_size](ops.cast(enc_feat[f_size], self.dec_dt), h, temb=None, w=w)
+                return self.fuse_convs_dict[f_size](ops.cast(enc_feat[f_size], self.dec_dt), h, temb=None, w=w,
+                                                    cat=cats.get(f_size))
             return h
 
-        out = self.decoder(z_q, fuse=fuse)                                   # (bt,512,512,3)
+        def fuse_dst(f_size):
+            if f_size in cats:
+                c = self.fuse_convs_dict[f_size].in_ch
+                return cats[f_size][..., c:2 * c]
+            return None
+
+        out = self.decoder(z_q, fuse=fuse, fuse_dst=fuse_dst if cats else None)   # (bt,512,512,3)
         return out, logits, lq_feat
 
     @torch.no_grad()

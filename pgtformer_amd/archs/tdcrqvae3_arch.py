@@ -169,16 +169,20 @@ class Encoder(HipModule):
         self.norm_out = Normalize(block_in)
         self.conv_out = Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
 
-    def forward(self, x, return_multi_res_feats=False):
-        """x: (B*T, H, W, 8) channel-padded input (reference: :540-573)."""
+    def forward(self, x, return_multi_res_feats=False, feat_out=None):
+        """x: (B*T, H, W, 8) channel-padded input (reference: :540-573).  feat_out: {level: (B*T,h,w,C) view} - the
+        level's feature map is written straight into that view (a channel slice of the decoder-side concat buffer)."""
         feats = []
         h = self.conv_in.run(x)
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]
+            dst = None if feat_out is None else feat_out.get(i_level)
             for i_block in range(self.num_res_blocks):
-                h = lvl.block[i_block](h)
-                if len(lvl.attn) > 0:
-                    h = lvl.attn[i_block](h)
+                last = dst is not None and i_block == self.num_res_blocks - 1
+                has_attn = len(lvl.attn) > 0
+                h = lvl.block[i_block](h, out=dst if last and not has_attn else None)
+                if has_attn:
+                    h = lvl.attn[i_block](h, out=dst if last else None)
             feats.append(h)
             if i_level != self.num_resolutions - 1:
                 h = lvl.downsample(h)
@@ -223,18 +227,23 @@ class Decoder(HipModule):
         self.norm_out = Normalize(block_in)
         self.conv_out = Conv2d(block_in, out_ch, 3, padding=1)
 
-    def forward(self, z, fuse=None):
+    def forward(self, z, fuse=None, fuse_dst=None):
         """z: (B*T, h, w, z_channels) (reference: :672-707; with `fuse`, the loop inlined in
-        PGTFormer.forward, archs/pgtformer_arch.py:684-710). fuse(f_size:str, h) -> h."""
+        PGTFormer.forward, archs/pgtformer_arch.py:684-710). fuse(f_size:str, h) -> h.
+        fuse_dst(f_size:str) -> (B*T,h,w,C) view or None: where the level's last block writes the feature map that
+        goes into `fuse` (the `dec` slice of the fusion block's concat buffer: no copy later)."""
         self.last_z_shape = z.shape
         h = self.conv_in.run(z)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         for i_level in reversed(range(self.num_resolutions)):
             lvl = self.up[i_level]
+            dst = None if fuse_dst is None else fuse_dst(str(h.shape[2]))
             for i_block in range(self.num_res_blocks + 1):
-                h = lvl.block[i_block](h)
-                if len(lvl.attn) > 0:
-                    h = lvl.attn[i_block](h)
+                last = dst is not None and i_block == self.num_res_blocks
+                has_attn = len(lvl.attn) > 0
+                h = lvl.block[i_block](h, out=dst if last and not has_attn else None)
+                if has_attn:
+                    h = lvl.attn[i_block](h, out=dst if last else None)
             if fuse is not None:
                 h = fuse(str(h.shape[2]), h)
             if i_level != 0:

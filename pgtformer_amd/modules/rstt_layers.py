@@ -133,11 +133,12 @@ class TDResnetBlock(HipModule):
         if in_channels != out_channels:
             self.nin_shortcut = Conv2d(in_channels, out_channels, 1)
 
-    def forward(self, x, temb=None):
+    def forward(self, x, temb=None, out=None):
+        """out: optional (N,H,W,Cout) view (e.g. a channel slice of a concat buffer) that receives the result."""
         h = self.conv1.run(self.norm1.run(x, ACT_SILU))
         h = self.norm2.run(h, ACT_SILU)
         sc = self.nin_shortcut.run(x) if self.in_channels != self.out_channels else x
-        return self.conv2.run(h, res=sc)
+        return self.conv2.run(h, res=sc, out=out)
 
 
 class Mlp(HipModule):
@@ -188,8 +189,8 @@ class VSTSREncoderTransformerBlock(HipModule):
         self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, xt, B, H, W):
-        """xt: (B*D*H*W, C) tokens in (b,d,y,x) order."""
+    def forward(self, xt, B, H, W, out=None):
+        """xt: (B*D*H*W, C) tokens in (b,d,y,x) order; out: optional (rows, C) view receiving the result."""
         C = self.dim
         win, shift = get_window_size((H, W), self.window_size, self.shift_size)
         ln = self.norm1.run(xt)
@@ -197,7 +198,7 @@ class VSTSREncoderTransformerBlock(HipModule):
         ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift)
         x1 = self.attn.proj.run(ao, res=xt)
         m = self.mlp.fc1.run(self.norm2.run(x1), act=ACT_GELU)
-        return self.mlp.fc2.run(m, res=x1)
+        return self.mlp.fc2.run(m, res=x1, out=out)
 
 
 class EncoderLayer(HipModule):
@@ -213,11 +214,13 @@ class EncoderLayer(HipModule):
                                          (0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio, qkv_bias)
             for i in range(depth)])
 
-    def forward(self, x):
-        """x: (B*D, H, W, C) -> same."""
+    def forward(self, x, out=None):
+        """x: (B*D, H, W, C) -> same; out: optional (B*D, H, W, C) view (channel slice of a wider buffer) for the result."""
         n, h, w, c = x.shape
         assert h % self.window_size[0] == 0 or h <= self.window_size[0]
         xt = x.reshape(n * h * w, c)
-        for blk in self.blocks:
-            xt = blk(xt, n // self.num_frames, h, w)
-        return xt.reshape(n, h, w, c)
+        for i, blk in enumerate(self.blocks):
+            last = out is not None and i == len(self.blocks) - 1
+            xt = blk(xt, n // self.num_frames, h, w,
+                     out=out.as_strided((n * h * w, c), (out.stride(2), 1), out.storage_offset()) if last else None)
+        return out if out is not None else xt.reshape(n, h, w, c)
