@@ -156,7 +156,7 @@ def main(argv=None):
     ap.add_argument("--fps", type=int, default=30)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "mixed", "fp32"])
     ap.add_argument("--weights", default=None)
-    ap.add_argument("--batch", type=int, default=4, help="independent windows per forward")
+    ap.add_argument("--batch", type=int, default=16, help="independent windows per forward (<= 20: 2 GiB tensor limit)")
     args = ap.parse_args(argv)
     frames = read_frames(args.input_video, args.size, args.size)
     model = load_architecture(args.precision, args.weights)
