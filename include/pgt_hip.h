@@ -27,7 +27,13 @@ extern "C" {
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
-enum { PGT_F32 = 0, PGT_BF16 = 1 };
+/* PGT_BF16X3: split-bf16 storage, value = hi + lo (hi = bf16(v), lo = bf16(v - hi)): a tensor of C logical channels
+ * keeps two bf16 planes per pixel / token row, hi at channel offset 0 and lo at an explicit `*_lo` element offset (C for
+ * a dense tensor, the parent's width for a channel slice); row strides count bf16 elements (>= 2C).  Products are
+ * formed as hi*hi + lo*hi + hi*lo on the bf16 MFMA with fp32 accumulation (16 significand bits instead of 8): the
+ * code-prediction branch runs in this type so that the arg-max codes reproduce the fp32 reference
+ * (archs/pgtformer_arch.py:638-664) at bf16-MFMA speed. */
+enum { PGT_F32 = 0, PGT_BF16 = 1, PGT_BF16X3 = 2 };
 enum { PGT_ACT_NONE = 0, PGT_ACT_RELU = 1, PGT_ACT_GELU = 2, PGT_ACT_SILU = 3, PGT_ACT_LEAKY02 = 4, PGT_ACT_SIGMOID = 5 };
 enum { PGT_EPI_PLAIN = 0, PGT_EPI_SFT = 1 };
 
@@ -68,6 +74,11 @@ typedef struct pgt_conv_desc {
      * that replace nearest-x2 up-sampling + conv3x3 (archs/tdcrqvae3_arch.py:34-52).  Plain epilogue only (no
      * residual / SFT operands); kernels 1 and 4 (and 0 = auto).                                                  */
     int32_t orow_mul, orow_xmul, orow_off;
+    /* dtype == PGT_BF16X3: element offsets of the lo planes of x, y and the residual inside a pixel row (0 = Cin / Cout /
+     * Cout, i.e. dense [hi | lo] tensors).  w then has 3*KH*KW*Cin columns: per filter tap [w_hi | w_hi | w_lo] (Cin
+     * each), matching the K order [x_hi | x_lo | x_hi].  y is split as well unless out_f32.  Kernel 4 only (bf16 MFMA,
+     * Cin % 64 == 0); no SFT epilogue.                                                                              */
+    int32_t x_lo, y_lo, r_lo;
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -126,6 +137,33 @@ int pgt_mha(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ld
             int32_t ldv, void* out, int32_t ldo, int32_t B, int32_t L, int32_t heads, int32_t hd,
             float scale, pgt_stream_t stream);
 
+/* ---- split-bf16 (PGT_BF16X3) forms of the normalisation / attention entry points ------------------------------
+ * Same arithmetic as the functions above on tensors stored as [hi | lo] bf16 planes; every tensor argument carries the
+ * element offset of its lo plane (`*_lo`) next to its row stride.  Statistics, softmax and accumulation are fp32;
+ * every MFMA product is hi*hi + lo*hi + hi*lo.  Used by the code-prediction branch (encoder levels with temporal
+ * attention, quant_conv, feat_emb, the 9 TransformerSALayers, idx_pred_layer: archs/pgtformer_arch.py:626-649). */
+int pgt_groupnorm_affine_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t N, int32_t HW, int32_t C,
+                            int32_t groups, float eps, const float* gamma, const float* beta, float* scale,
+                            float* shift, void* workspace, size_t workspace_bytes, pgt_stream_t stream);
+int pgt_affine_act_x3(const void* x, int32_t ldx, int32_t x_lo, void* y, int32_t ldy, int32_t y_lo, int32_t N,
+                      int32_t HW, int32_t C, const float* scale, const float* shift, int32_t act,
+                      pgt_stream_t stream);
+int pgt_layernorm_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t rows, int32_t C, const float* gamma,
+                     const float* beta, float eps, void* y, int32_t ldy, int32_t y_lo, const void* pos,
+                     int32_t ldpos, int32_t pos_lo, void* y2, int32_t ldy2, int32_t y2_lo, pgt_stream_t stream);
+int pgt_window_attention_x3(const void* qkv, int32_t ldqkv, int32_t qkv_lo, void* out, int32_t ldo,
+                            int32_t out_lo, const float* bias, int32_t B, int32_t T, int32_t H, int32_t W,
+                            int32_t C, int32_t heads, int32_t wh, int32_t ww, int32_t sh, int32_t sw,
+                            pgt_stream_t stream);
+int pgt_mha_x3(const void* q, int32_t ldq, int32_t q_lo, const void* k, int32_t ldk, int32_t k_lo, const void* v,
+               int32_t ldv, int32_t v_lo, void* out, int32_t ldo, int32_t out_lo, int32_t B, int32_t L,
+               int32_t heads, int32_t hd, float scale, pgt_stream_t stream);
+/* fp32 (rows, cols) <-> split-bf16 planes (hi = bf16(v), lo = bf16(v - hi)) */
+int pgt_x3_split(const float* src, int32_t lds, void* dst, int32_t ldd, int32_t dst_lo, int64_t rows,
+                 int32_t cols, pgt_stream_t stream);
+int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float* dst, int32_t ldd, int64_t rows,
+                 int32_t cols, pgt_stream_t stream);
+
 /* ---- quantiser -------------------------------------------------------------------------------
  * codes[r] = first argmax_j logits[r, j]  (logits.argmax(-1), pgtformer_arch.py:663) */
 int pgt_argmax_rows(const float* logits, int32_t ld, int32_t rows, int32_t K, int32_t* codes,
@@ -160,6 +198,14 @@ int pgt_resize_bilinear_ac(int32_t dtype, const void* x, int32_t ldx, int32_t N,
 /* strided 2-D copy with dtype conversion (channel concat, casts) */
 int pgt_copy2d(int32_t src_dtype, const void* src, int32_t lds, int32_t dst_dtype, void* dst, int32_t ldd,
                int64_t rows, int32_t cols, pgt_stream_t stream);
+
+/* frame gather: dst frame i <- src frame idx[i] (idx: n_dst int32 on the device).  A frame is `rows` rows of
+ * `row_bytes` bytes (a multiple of 16) with independent row strides in bytes.  Replaces the index_select / stack that
+ * turns per-frame tensors into per-window (B*T) tensors: consecutive windows of the reference driver share 2 of 3
+ * frames (inference.py:47-74) and everything before the first temporal attention is per-frame
+ * (archs/tdcrqvae3_arch.py:546-555), so it is computed once per frame and gathered here. */
+int pgt_gather_frames(const void* src, int64_t src_row_stride, void* dst, int64_t dst_row_stride,
+                      const int32_t* idx, int32_t n_dst, int64_t rows, int32_t row_bytes, pgt_stream_t stream);
 
 /* ---- driver edges (inference.py:6-19) ----------------------------------------------------------
  * input window -> channels-last 8-channel (RGB + 5 zero) tensors: raw = v/255 (encoder input) and

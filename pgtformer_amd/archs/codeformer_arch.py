@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules.rstt_layers import HipModule, LayerNorm, Linear, _f32
+from ..modules.rstt_layers import HipModule, LayerNorm, Linear, _f32, _is_x3, _pack_matrix
 from ..ops import ACT_GELU
 
 
@@ -35,20 +35,24 @@ class TransformerSALayer(HipModule):
     def _pack(self, device, dtype):
         e = self.embed_dim
         w, b = self.self_attn.in_proj_weight.detach(), self.self_attn.in_proj_bias.detach()
-        self.w_qk = w[:2 * e].to(device=device, dtype=dtype).contiguous()   # applied to LN(x)+pos
+        self.w_qk = _pack_matrix(w[:2 * e].float(), 1, device, dtype)   # applied to LN(x)+pos
         self.b_qk = _f32(b[:2 * e], device)
-        self.w_v = w[2 * e:].to(device=device, dtype=dtype).contiguous()    # applied to LN(x)
+        self.w_v = _pack_matrix(w[2 * e:].float(), 1, device, dtype)    # applied to LN(x)
         self.b_v = _f32(b[2 * e:], device)
-        self.w_o = self.self_attn.out_proj.weight.detach().to(device=device, dtype=dtype).contiguous()
+        self.w_o = _pack_matrix(self.self_attn.out_proj.weight.detach().float(), 1, device, dtype)
         self.b_o = _f32(self.self_attn.out_proj.bias, device)
 
     def forward(self, tgt, B, L, query_pos=None):
         """tgt, query_pos: (B*L, E)."""
         e, hd = self.embed_dim, self.embed_dim // self.nhead
+        x3 = _is_x3(self.dt)
         t2, t2p = self.norm1.run(tgt, pos=query_pos)
-        qk = ops.linear(t2p, self.w_qk, self.b_qk)
-        v = ops.linear(t2, self.w_v, self.b_v)
-        ao = ops.mha(qk[:, :e], qk[:, e:], v, B, L, self.nhead, hd, float(hd) ** -0.5)
-        tgt = ops.linear(ao, self.w_o, self.b_o, res=tgt)
+        qk = ops.linear(t2p, self.w_qk, self.b_qk, x3=x3)           # x3: (rows, 4E) = [hi q k | lo q k]
+        v = ops.linear(t2, self.w_v, self.b_v, x3=x3)               # x3: (rows, 2E) = [hi v | lo v]
+        if x3:
+            ao = ops.mha(qk[:, :e], qk[:, e:2 * e], v[:, :e], B, L, self.nhead, hd, float(hd) ** -0.5, x3=(2 * e, 2 * e, e))
+        else:
+            ao = ops.mha(qk[:, :e], qk[:, e:], v, B, L, self.nhead, hd, float(hd) ** -0.5)
+        tgt = ops.linear(ao, self.w_o, self.b_o, res=tgt, x3=x3)
         m = self.linear1.run(self.norm2.run(tgt), act=ACT_GELU)
         return self.linear2.run(m, res=tgt)

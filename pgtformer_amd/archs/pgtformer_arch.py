@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules.rstt_layers import Conv2d, HipModule, LayerNorm, Linear, TDResnetBlock, _f32  # noqa: F401
+from ..modules.rstt_layers import Conv2d, HipModule, LayerNorm, Linear, TDResnetBlock, _f32, _is_x3  # noqa: F401
 from ..ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU
 from ..registry import ARCH_REGISTRY
 from .codeformer_arch import TransformerSALayer, adaptive_instance_normalization
@@ -380,30 +380,53 @@ class PGTFormer(TDCRQVAE3):
         """x: (B*T,3,512,512) fp32 in [0,1] (or uint8 (B*T,512,512,3)).  Returns the reference's tuple
         (out (B*T,3,512,512) fp32, logits (B*T,32,32,1,1024) fp32, lq_feat (B*T,32,32,512) fp32)."""
         out_nhwc, logits, lq = self.forward_nhwc(x, w=w, code_only=code_only, adain=adain)
-        lq32 = ops.cast(lq, torch.float32)
+        lq32 = ops.from_x3(lq) if _is_x3(self.enc_dt) else ops.cast(lq, torch.float32)
         if code_only:
             return logits, lq32
         return ops.nhwc_to_nchw_f32(out_nhwc), logits, lq32
 
+    @staticmethod
+    def window_index(n_windows, t=3, device="cuda"):
+        """Frame indices of `n_windows` consecutive sliding windows over n_windows + t - 1 frames: window i = frames
+        i .. i+t-1 (the reference driver's window policy, inference.py:47-74)."""
+        return (torch.arange(n_windows, dtype=torch.int32)[:, None] + torch.arange(t, dtype=torch.int32)[None, :]).reshape(-1).to(device)
+
     @torch.no_grad()
-    def forward_nhwc(self, x, w=None, code_only=None, adain=None):
+    def forward_nhwc(self, x, w=None, code_only=None, adain=None, win=None, codes=None, direct=None):
         """Same computation, channels-last results and no layout conversion: out (B*T,512,512,3) in the
-        decoder dtype, logits fp32, lq_feat (B*T,32,32,512) in the encoder dtype."""
+        decoder dtype, logits fp32, lq_feat (B*T,32,32,512) in the encoder dtype ((B*T,32,32,1024) split-bf16 planes
+        [hi | lo] in bf16x3 mode).
+
+        win: None (x holds the B*T frames of B windows back to back), or an int32 device tensor (B*T,) of indices into
+        the frames of x: the windows' UNIQUE frames are given once and everything per-frame (BiSeNet, convpos, the encoder
+        up to its first temporal attention) is computed once per frame, then gathered to window order.  Results equal the
+        win=None call on x[win] (the per-frame operators act on each frame independently).
+        codes: optional (B*T,32,32,depth) integer tensor that REPLACES the predicted codes (teacher forcing: tests feed the
+        reference's codes to separate decoder arithmetic from code flips).
+        direct: None = automatic; False forces the copying (non in-place) concat path in bf16 (tests)."""
         self._check_ready()
         w = self.w if w is None else w
         adain = self.adain if adain is None else adain
         t = self.t
         raw, nx = self._ingest(x)
-        bt = raw.shape[0]
+        bt = raw.shape[0] if win is None else win.numel()
         b = bt // t
-        # condition branch: BiSeNet parsing map -> positional embedding of the code transformer
-        cond = self.convpos.run(self.conditionnet(nx))                      # (bt,32,32,512)
+        # condition branch: BiSeNet parsing map -> positional embedding of the code transformer (per frame)
+        self.last_parsing = self.conditionnet(nx)                           # (F,32,32,64): 3 x 19 parsing logits + pad
+        cond = self.convpos.run(self.last_parsing)                          # (F,32,32,512)
+        if win is not None:
+            cond = ops.gather_frames(cond, win)                              # (bt,32,32,512)
+        self.last_cond = cond
         th, tw = cond.shape[1], cond.shape[2]
         pos = cond.reshape(bt * th * tw, cond.shape[3])                      # rows (b,t,y,x) == (T*H*W, B) order
+        x3 = _is_x3(self.enc_dt)
+        if x3:
+            pos = ops.to_x3(pos)                                             # fp32 BiSeNet map -> split-bf16 operand
         # encoder.  bf16: the fusion blocks' [enc | dec | fut] concat buffers exist up front and the encoder levels / the
         # decoder levels write their feature maps straight into the enc / dec slices (no concat copies)
         cats, feat_out = {}, None
-        direct = (self.enc_dt == torch.bfloat16 and self.dec_dt == torch.bfloat16 and w > 0 and not code_only)
+        can_direct = (self.dec_dt == torch.bfloat16 and w > 0 and not code_only)
+        direct = can_direct if direct is None else (direct and can_direct)
         if direct:
             feat_out = {}
             for f_size in self.connect_list:
@@ -413,29 +436,34 @@ class PGTFormer(TDCRQVAE3):
                 res = int(f_size)
                 cats[f_size] = blk.new_concat(bt, res, res, raw.device, torch.bfloat16)
                 feat_out[self.fuse_encoder_indices[f_size]] = cats[f_size][..., :blk.in_ch]
-        z, feats = self.encoder(raw, return_multi_res_feats=True, feat_out=feat_out)
+        want = {self.fuse_encoder_indices[f] for f in self.connect_list}
+        z, feats = self.encoder(raw, return_multi_res_feats=True, feat_out=feat_out, win=win, want_feats=want)
         enc_feat = {}
         for f_size in self.connect_list:
             f = feats[self.fuse_encoder_indices[f_size]]
             enc_feat[str(f.shape[2])] = f
-        lq_feat = self.quant_conv.run(z)                                     # (bt,32,32,512)
+        lq_feat = self.quant_conv.run(z)                                     # (bt,32,32,512); x3: (bt,32,32,1024)
+        lq_style = lq_feat[..., :lq_feat.shape[3] // 2] if x3 else lq_feat   # AdaIN style statistics: the hi plane
         # code-prediction transformer over the T*32*32 tokens of each window
         L = t * th * tw
         q = self.feat_emb.run(lq_feat.reshape(bt * th * tw, lq_feat.shape[3]))
         for layer in self.ft_layers:
             q = layer(q, b, L, query_pos=pos)
         ln = self.idx_pred_layer[0].run(q)
-        logits2d = ops.linear(ln, self.idx_pred_layer[1].pw, None, out_f32=True)   # (bt*32*32, depth*K) fp32
+        logits2d = ops.linear(ln, self.idx_pred_layer[1].pw, None, out_f32=True, x3=x3)   # (bt*32*32, depth*K) fp32
         logits = logits2d.reshape(bt, *self.quantizer.code_shape, self.codebook_size)
         if code_only:
             return None, logits, lq_feat
         # quantisation: first-max code per token, codebook gather, AdaIN against the LQ features
         depth = self.quantizer_depth
-        codes = ops.argmax_rows(logits2d.reshape(bt * th * tw * depth, self.codebook_size))
+        if codes is None:
+            codes = ops.argmax_rows(logits2d.reshape(bt * th * tw * depth, self.codebook_size))
+        else:
+            codes = codes.to(device=raw.device, dtype=torch.int32).contiguous()
         self.last_codes = codes.reshape(bt, th, tw, depth)
         quant = self.quantizer.embed_code(self.last_codes, self.dec_dt)      # (bt,32,32,512)
         if adain:
-            quant = adaptive_instance_normalization(quant, lq_feat)
+            quant = adaptive_instance_normalization(quant, lq_style)
         z_q = self.post_quant_conv.run(quant)
 
         def fuse(f_size, h):
@@ -454,16 +482,18 @@ class PGTFormer(TDCRQVAE3):
         return out, logits, lq_feat
 
     @torch.no_grad()
-    def restore_middle_u8(self, window_u8, w=1.0):
+    def restore_middle_u8(self, window_u8, w=1.0, win=None, out=None):
         """Driver fast path (reference: inference.py:12-19): uint8 (3,H,W,3) window -> restored middle
         frame as uint8 (H,W,3) with floor(clamp(x,0,1)*255), without leaving the device.
         B windows stacked on the frame axis, (B*3,H,W,3), give (B,H,W,3): B independent windows per forward
-        (the reference accepts only B=1, modules/rstt_layers.py:904; here B>1 == B separate calls)."""
-        out, _, _ = self.forward_nhwc(window_u8, w=w)
-        b = out.shape[0] // self.t
-        if b == 1:
-            return ops.frame_to_u8(out[self.t // 2])
-        res = torch.empty((b,) + tuple(out.shape[1:3]) + (3,), device=out.device, dtype=torch.uint8)
+        (the reference accepts only B=1, modules/rstt_layers.py:904; here B>1 == B separate calls).
+        win: see forward_nhwc - window_u8 then holds the windows' unique frames."""
+        res, _, _ = self.forward_nhwc(window_u8, w=w, win=win)
+        b = res.shape[0] // self.t
+        if b == 1 and out is None:
+            return ops.frame_to_u8(res[self.t // 2])
+        if out is None:
+            out = torch.empty((b,) + tuple(res.shape[1:3]) + (3,), device=res.device, dtype=torch.uint8)
         for i in range(b):
-            ops.frame_to_u8(out[i * self.t + self.t // 2], out=res[i])
-        return res
+            ops.frame_to_u8(res[i * self.t + self.t // 2], out=out[i])
+        return out

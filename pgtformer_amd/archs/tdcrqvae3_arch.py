@@ -6,12 +6,17 @@ RQBottleneck :206, TDCRQVAE3 :711).  Activations are channels-last (B*T, H, W, C
 reference's (B*T, 3, H, W) fp32 tensor (or uint8 (B*T,H,W,3) frames) and returns the reference's
 tuple.  EMA-codebook training updates and their collectives (:138-186) are out of scope.
 """
+import functools
+import inspect
+import json
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, prepare_tree)
-from ..ops import ACT_SILU
+from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _is_x3, prepare_tree)
+from ..ops import ACT_SILU, X3
 from ..registry import ARCH_REGISTRY
 
 
@@ -169,23 +174,81 @@ class Encoder(HipModule):
         self.norm_out = Normalize(block_in)
         self.conv_out = Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
 
-    def forward(self, x, return_multi_res_feats=False, feat_out=None):
-        """x: (B*T, H, W, 8) channel-padded input (reference: :540-573).  feat_out: {level: (B*T,h,w,C) view} - the
-        level's feature map is written straight into that view (a channel slice of the decoder-side concat buffer)."""
+    def first_attn_level(self):
+        for i, lvl in enumerate(self.down):
+            if len(lvl.attn) > 0:
+                return i
+        return self.num_resolutions
+
+    def prepare_split(self, device):
+        """bf16x3 mode: the levels below the first temporal attention (64 / 128 channels at 512^2 / 256^2: HBM-bound, and
+        computed once per FRAME by the overlap-aware driver) stay in exact fp32; from the first attention level on
+        (C >= 256: MFMA-bound) every module runs on split-bf16 operands."""
+        fa = self.first_attn_level()
+        prepare_tree(self.conv_in, device, torch.float32)
+        for i, lvl in enumerate(self.down):
+            prepare_tree(lvl, device, torch.float32 if i < fa else X3)
+        for m in (self.mid, self.norm_out, self.conv_out):
+            prepare_tree(m, device, X3)
+        self.dev, self.dt = device, X3
+
+    @staticmethod
+    def _convert(h, cur, want):
+        if _is_x3(want) and not _is_x3(cur):
+            assert cur == torch.float32, "split-bf16 levels follow fp32 levels"
+            return ops.to_x3(h)
+        assert _is_x3(cur) == _is_x3(want) and (_is_x3(cur) or cur == want), (cur, want)
+        return h
+
+    def forward(self, x, return_multi_res_feats=False, feat_out=None, win=None, want_feats=None):
+        """x: (F, H, W, 8) channel-padded input (reference: :540-573).  feat_out: {level: (B*T,h,w,C) view} - the
+        level's feature map is delivered in that view (a channel slice of the decoder-side concat buffer): written
+        in place by the producing kernel when the dtypes and frame order allow it, else copied / gathered into it.
+
+        win: None, or int32 device tensor (B*T,) of frame indices into x: the B windows of a batch are given as their
+        UNIQUE frames (consecutive windows of the driver share 2 of 3 frames, reference inference.py:47-74).  Everything
+        up to the first temporal attention is per-frame (conv_in, the res blocks and down-samplings of the levels without
+        attention, and the first res block of the first level with attention: reference :546-555 with
+        attn_resolutions starting at 128), so it runs once per frame and is gathered to window order (B*T frames) where
+        the first EncoderLayer starts.  want_feats: levels whose feature maps the caller needs (None: all); the others
+        are returned as None (a per-frame 512x512 map would otherwise be gathered for nothing).
+        Feature maps of split-bf16 levels are returned as their hi planes (bf16 views)."""
         feats = []
+        cur = self.conv_in.dt
         h = self.conv_in.run(x)
+        per_frame = win is not None
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]
             dst = None if feat_out is None else feat_out.get(i_level)
+            has_attn = len(lvl.attn) > 0
+            h = self._convert(h, cur, lvl.block[0].dt)
+            cur = lvl.block[0].dt
+            in_place = dst is not None and not _is_x3(cur) and dst.dtype == cur     # the producer can write dst itself
             for i_block in range(self.num_res_blocks):
-                last = dst is not None and i_block == self.num_res_blocks - 1
-                has_attn = len(lvl.attn) > 0
-                h = lvl.block[i_block](h, out=dst if last and not has_attn else None)
+                last = in_place and i_block == self.num_res_blocks - 1
+                h = lvl.block[i_block](h, out=dst if last and not has_attn and not per_frame else None)
                 if has_attn:
+                    if per_frame:
+                        h = ops.gather_frames(h, win)
+                        per_frame = False
                     h = lvl.attn[i_block](h, out=dst if last else None)
-            feats.append(h)
+            wanted = return_multi_res_feats and (want_feats is None or i_level in want_feats)
+            if not wanted:
+                feats.append(None)
+            else:
+                f = h[..., :h.shape[-1] // 2] if _is_x3(cur) else h              # hi plane of a split map
+                if per_frame:     # per-frame level: cast on the unique frames, then gather to window order
+                    if dst is not None and f.dtype != dst.dtype:
+                        f = ops.cast(f, dst.dtype)
+                    f = ops.gather_frames(f, win, out=dst)
+                elif dst is not None and f.data_ptr() != dst.data_ptr():
+                    f = ops.copy_into(f, dst)
+                feats.append(f)
             if i_level != self.num_resolutions - 1:
                 h = lvl.downsample(h)
+        if per_frame:
+            h = ops.gather_frames(h, win)
+        h = self._convert(h, cur, self.mid.block_1.dt)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         h = self.conv_out.run(self.norm_out.run(h, ACT_SILU))
         return (h, feats) if return_multi_res_feats else h
@@ -253,8 +316,74 @@ class Decoder(HipModule):
         return self.conv_out.run(self.norm_out.run(h, ACT_SILU))
 
 
+class HubMixin:
+    """`from_pretrained` / `save_pretrained` with the file layout of huggingface_hub's PyTorchModelHubMixin, which the
+    reference mixes into TDCRQVAE3 (archs/tdcrqvae3_arch.py:711; call site inference.py:118): `config.json` holds the
+    constructor kwargs, `model.safetensors` the state dict, loaded strictly.  The constructor arguments of the
+    outermost class are recorded at construction time (what the mixin serialises as config.json)."""
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        orig = cls.__dict__.get("__init__")
+        if orig is None:
+            return
+
+        @functools.wraps(orig)
+        def init(self, *a, **k):
+            if "_hub_config" not in self.__dict__:
+                bound = inspect.signature(orig).bind(self, *a, **k)
+                cfg = {}
+                for name, val in list(bound.arguments.items())[1:]:
+                    if inspect.signature(orig).parameters[name].kind is inspect.Parameter.VAR_KEYWORD:
+                        cfg.update(val)
+                    else:
+                        cfg[name] = val
+                object.__setattr__(self, "_hub_config", cfg)
+            orig(self, *a, **k)
+
+        cls.__init__ = init
+
+    def save_pretrained(self, save_directory):
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(self._hub_config, f, indent=2, default=list)
+        # shared_codebook registers one VQEmbedding under several names: safetensors wants each storage once
+        sd, seen = {}, {}
+        for k, v in self.state_dict().items():
+            v = v.detach().cpu().contiguous()
+            sd[k] = v.clone() if v.data_ptr() in seen else v
+            seen[v.data_ptr()] = k
+        save_file(sd, os.path.join(save_directory, "model.safetensors"))
+        return save_directory
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, device=None, precision="bf16x3", **model_kwargs):
+        """`PGTFormer.from_pretrained("kepeng/pgtformer-base")` of the reference (inference.py:118).  A local directory
+        holding config.json + model.safetensors is loaded directly; a hub id is resolved through huggingface_hub (needs
+        network access or a populated cache).  With `device` the model is also prepared (weights repacked for the
+        kernels) and ready to run; without it the caller calls .prepare(device, precision)."""
+        path = str(pretrained_model_name_or_path)
+        if not os.path.isdir(path):
+            try:
+                from huggingface_hub import snapshot_download
+                path = snapshot_download(path, allow_patterns=["config.json", "model.safetensors"])
+            except Exception as e:  # no network / unknown id
+                raise FileNotFoundError(f"{pretrained_model_name_or_path!r} is not a local directory and could not be "
+                                        f"fetched from the hub: {e}") from e
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        cfg.update(model_kwargs)
+        model = cls(**cfg)
+        model.load_state_dict(load_file(os.path.join(path, "model.safetensors")), strict=True)
+        nn.Module.eval(model)
+        model.requires_grad_(False)
+        return model.prepare(device, precision) if device is not None else model
+
+
 @ARCH_REGISTRY.register()
-class TDCRQVAE3(HipModule):
+class TDCRQVAE3(HubMixin, HipModule):
     """Stage-I temporal RQ-VAE (reference: :711-872). `prepare(device, precision)` must be called after
     weights are loaded; precision in {"fp32", "bf16", "mixed"} ("mixed": encoder side fp32, decoder bf16)."""
 
@@ -277,17 +406,35 @@ class TDCRQVAE3(HipModule):
 
     # -- precision / weight repack ------------------------------------------------------------
     ENC_SIDE = ("encoder", "quant_conv", "quantizer", "conditionnet", "convpos", "feat_emb", "ft_layers", "idx_pred_layer")
+    F32_IN_X3 = ("conditionnet", "convpos", "quantizer")    # bf16x3 mode: per-frame BiSeNet + codebook stay exact fp32
 
-    def prepare(self, device="cuda", precision="bf16"):
+    def prepare(self, device="cuda", precision="bf16x3"):
+        """Repack the weights for the kernels.  precision:
+          "fp32"    exact-f32 MFMA everywhere (parity mode)
+          "bf16x3"  decoder / SFT fusion in bf16; the code-prediction branch on split-bf16 operands (3 bf16 MFMAs per
+                    product, 16 significand bits: the arg-max codes reproduce the fp32 reference) with its per-frame,
+                    HBM-bound front (BiSeNet, encoder levels below the first temporal attention) in exact fp32
+          "mixed"   decoder bf16, the whole code-prediction branch in exact fp32
+          "bf16"    bf16 everywhere (fastest; ~2 % of the codes differ from the fp32 reference with random weights)"""
         dts = {"fp32": (torch.float32, torch.float32), "bf16": (torch.bfloat16, torch.bfloat16),
-               "mixed": (torch.float32, torch.bfloat16)}
+               "mixed": (torch.float32, torch.bfloat16), "bf16x3": (X3, torch.bfloat16)}
         if precision not in dts:
             raise ValueError(f"precision must be one of {list(dts)}")
         self.enc_dt, self.dec_dt = dts[precision]
         self.precision = precision
         self.dev = torch.device(device)
         for name, child in self.named_children():
-            prepare_tree(child, self.dev, self.enc_dt if name in self.ENC_SIDE else self.dec_dt)
+            if name not in self.ENC_SIDE:
+                prepare_tree(child, self.dev, self.dec_dt)
+            elif not _is_x3(self.enc_dt):
+                prepare_tree(child, self.dev, self.enc_dt)
+            elif name == "encoder":
+                child.prepare_split(self.dev)
+            elif name in self.F32_IN_X3:
+                prepare_tree(child, self.dev, torch.float32)
+            else:
+                prepare_tree(child, self.dev, X3)
+        self.in_dt = self.encoder.conv_in.dt          # dtype the input frames are converted to
         self._prepare_extra()
         return self
 
@@ -303,11 +450,12 @@ class TDCRQVAE3(HipModule):
         """(B*T,3,H,W) fp32 in [0,1] or uint8 (B*T,H,W,3) -> raw / ImageNet-normalised (B*T,H,W,8)."""
         self._check_ready()
         x = x.to(self.dev)
-        return ops.prep_input(x.contiguous(), self.enc_dt)
+        return ops.prep_input(x.contiguous(), self.in_dt)
 
     def encode(self, x):
         raw, _ = self._ingest(x)
-        return self.quant_conv.run(self.encoder(raw))  # (B*T,h,w,embed_dim) == reference's NHWC z_e
+        z_e = self.quant_conv.run(self.encoder(raw))   # (B*T,h,w,embed_dim) == reference's NHWC z_e
+        return ops.from_x3(z_e) if _is_x3(self.enc_dt) else z_e
 
     def decode(self, z_q):
         z = self.post_quant_conv.run(ops.cast(z_q, self.dec_dt))

@@ -305,3 +305,28 @@ extern "C" int pgt_mha(int32_t dtype, const void* q, int32_t ldq, const void* k,
     PGT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- split-bf16 (PGT_BF16X3) forms: MFMA kernels only ------------------------------------------------------------
+extern "C" int pgt_window_attention_x3(const void* qkv, int32_t ldqkv, int32_t qkv_lo, void* out, int32_t ldo,
+                                       int32_t out_lo, const float* bias, int32_t B, int32_t T, int32_t H, int32_t W,
+                                       int32_t C, int32_t heads, int32_t wh, int32_t ww, int32_t sh, int32_t sw,
+                                       pgt_stream_t stream) {
+    PGT_CHECK(qkv && out && bias, "window_attention_x3: null argument");
+    PGT_CHECK(H % wh == 0 && W % ww == 0, "window_attention_x3: H=%d W=%d not multiples of window %dx%d", H, W, wh, ww);
+    PGT_CHECK(sh >= 0 && sh < wh && sw >= 0 && sw < ww, "window_attention_x3: shift must be in [0, window)");
+    PGT_CHECK(C % heads == 0 && qkv_lo >= 3 * C && ldqkv >= qkv_lo + 3 * C && out_lo >= C && ldo >= out_lo + C,
+              "window_attention_x3: planes do not fit the rows (ldqkv=%d qkv_lo=%d ldo=%d out_lo=%d C=%d)", ldqkv, qkv_lo, ldo, out_lo, C);
+    const int rc = pgt_window_attn_mfma_bf16(qkv, ldqkv, out, ldo, bias, B, T, H, W, C, heads, wh, ww, sh, sw,
+                                             (hipStream_t)stream, 1, qkv_lo, out_lo);
+    PGT_CHECK(rc != 1, "window_attention_x3: shape not covered by the MFMA kernel (N = T*wh*ww multiple of 48 up to 192, "
+              "head_dim 32 or 64, 16-byte aligned rows)");
+    return rc;
+}
+
+extern "C" int pgt_mha_x3(const void* q, int32_t ldq, int32_t q_lo, const void* k, int32_t ldk, int32_t k_lo, const void* v,
+                          int32_t ldv, int32_t v_lo, void* out, int32_t ldo, int32_t out_lo, int32_t B, int32_t L,
+                          int32_t heads, int32_t hd, float scale, pgt_stream_t stream) {
+    PGT_CHECK(q && k && v && out, "mha_x3: null argument");
+    PGT_CHECK(hd == 64, "mha_x3: head_dim=%d unsupported (64)", hd);
+    return pgt_mha_mfma_bf16(q, ldq, k, ldk, v, ldv, out, ldo, B, L, heads, scale, (hipStream_t)stream, 1, q_lo, k_lo, v_lo, out_lo);
+}

@@ -26,10 +26,16 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf2(lo,
 // raw v_exp_f32 (2^x): arguments here are <= 0 and results feed a bf16 operand, no range fix-up needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// X3: q, k, v and out are split-bf16 rows, lo planes qlo / klo / vlo / olo elements after the hi planes; S^T and O^T
+// take three MFMAs per product (hi*hi + lo*hi + hi*lo), P is split in registers after the exp.
+template <bool X3>
 __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k,
                                                        int ldk, const uint16_t* __restrict__ v, int ldv,
-                                                       uint16_t* __restrict__ out, int ldo, int L, float c /* scale*log2(e) */) {
-    __shared__ __attribute__((aligned(16))) char smem[BKV * KSTR + HD * VSTR];
+                                                       uint16_t* __restrict__ out, int ldo, int L, float c /* scale*log2(e) */,
+                                                       int qlo, int klo, int vlo, int olo) {
+    constexpr int NP = X3 ? 2 : 1;
+    constexpr int PLANE = BKV * KSTR + HD * VSTR;
+    __shared__ __attribute__((aligned(16))) char smem[NP * PLANE];
     char* Ks = smem;
     char* Vt = smem + BKV * KSTR;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,39 +45,48 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
     const long rowbase = (long)b * L;
 
     // Q^T fragments (B operand of S^T): 4 k-steps of 16 head-dims, this half's 8 dims each
-    uint4 qf[4];
+    uint4 qf[4], qfl[X3 ? 4 : 1];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         qf[s] = make_uint4(0, 0, 0, 0);
         if (qi < L) qf[s] = *reinterpret_cast<const uint4*>(q + (rowbase + qi) * ldq + head * HD + s * 16 + h * 8);
+        if constexpr (X3) {
+            qfl[s] = make_uint4(0, 0, 0, 0);
+            if (qi < L) qfl[s] = *reinterpret_cast<const uint4*>(q + (rowbase + qi) * ldq + qlo + head * HD + s * 16 + h * 8);
+        }
     }
     // staging roles
     const int k_r0 = tid >> 3, k_cc = tid & 7;      // K: rows k_r0, k_r0+32; 16-byte chunk k_cc
     const int v_kp = tid >> 3, v_c = tid & 7;       // V: key pair (2kp, 2kp+1), head-dim chunk 8c..8c+7
-    uint4 rk[2], rv[2];
+    uint4 rk[NP][2], rv[NP][2];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kj = k0 + k_r0 + 32 * i;
-            rk[i] = make_uint4(0, 0, 0, 0);
-            if (kj < L) rk[i] = *reinterpret_cast<const uint4*>(k + (rowbase + kj) * ldk + head * HD + k_cc * 8);
-            const int vj = k0 + 2 * v_kp + i;
-            rv[i] = make_uint4(0, 0, 0, 0);
-            if (vj < L) rv[i] = *reinterpret_cast<const uint4*>(v + (rowbase + vj) * ldv + head * HD + v_c * 8);
-        }
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kj = k0 + k_r0 + 32 * i;
+                rk[pl][i] = make_uint4(0, 0, 0, 0);
+                if (kj < L) rk[pl][i] = *reinterpret_cast<const uint4*>(k + (rowbase + kj) * ldk + pl * klo + head * HD + k_cc * 8);
+                const int vj = k0 + 2 * v_kp + i;
+                rv[pl][i] = make_uint4(0, 0, 0, 0);
+                if (vj < L) rv[pl][i] = *reinterpret_cast<const uint4*>(v + (rowbase + vj) * ldv + pl * vlo + head * HD + v_c * 8);
+            }
     };
     auto sstore = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(Ks + (k_r0 + 32 * i) * KSTR + k_cc * 16) = rk[i];
-        // transpose V: dword = {V[2kp][d], V[2kp+1][d]} -> Vt[d][2kp..2kp+1]
-        const uint32_t a[4] = {rv[0].x, rv[0].y, rv[0].z, rv[0].w};
-        const uint32_t bb[4] = {rv[1].x, rv[1].y, rv[1].z, rv[1].w};
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t lo = (a[j] & 0xffffu) | (bb[j] << 16);
-            const uint32_t hi = (a[j] >> 16) | (bb[j] & 0xffff0000u);
-            *reinterpret_cast<uint32_t*>(Vt + (v_c * 8 + 2 * j) * VSTR + v_kp * 4) = lo;
-            *reinterpret_cast<uint32_t*>(Vt + (v_c * 8 + 2 * j + 1) * VSTR + v_kp * 4) = hi;
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(Ks + pl * PLANE + (k_r0 + 32 * i) * KSTR + k_cc * 16) = rk[pl][i];
+            // transpose V: dword = {V[2kp][d], V[2kp+1][d]} -> Vt[d][2kp..2kp+1]
+            const uint32_t a[4] = {rv[pl][0].x, rv[pl][0].y, rv[pl][0].z, rv[pl][0].w};
+            const uint32_t bb[4] = {rv[pl][1].x, rv[pl][1].y, rv[pl][1].z, rv[pl][1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = (a[j] & 0xffffu) | (bb[j] << 16);
+                const uint32_t hi = (a[j] >> 16) | (bb[j] & 0xffff0000u);
+                *reinterpret_cast<uint32_t*>(Vt + pl * PLANE + (v_c * 8 + 2 * j) * VSTR + v_kp * 4) = lo;
+                *reinterpret_cast<uint32_t*>(Vt + pl * PLANE + (v_c * 8 + 2 * j + 1) * VSTR + v_kp * 4) = hi;
+            }
         }
     };
 
@@ -101,6 +116,13 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const uint4 a = *reinterpret_cast<const uint4*>(k_rd + kb * 32 * KSTR + st * 32);
+                if constexpr (X3) {   // small terms first
+                    const uint4 al = *reinterpret_cast<const uint4*>(k_rd + PLANE + kb * 32 * KSTR + st * 32);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al),
+                                                                    __builtin_bit_cast(bf16x8, qf[st]), s[kb], 0, 0, 0);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                    __builtin_bit_cast(bf16x8, qfl[st]), s[kb], 0, 0, 0);
+                }
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                                 __builtin_bit_cast(bf16x8, qf[st]), s[kb], 0, 0, 0);
             }
@@ -123,17 +145,29 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
         const float alpha = fast_exp2((m - mnew) * c);
         const float mc = mnew * c;
         float lsum = 0.f;
-        uint4 pf[2][2];   // P^T B-operands: [key block][k-step]
+        uint4 pf[2][2], pfl[X3 ? 2 : 1][2];   // P^T B-operands: [key block][k-step]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             float p[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                p[e] = fast_exp2(s[kb][e] * c - mc);
+                p[e] = fast_exp2(X3 ? (s[kb][e] - mnew) * c : s[kb][e] * c - mc);
                 lsum += p[e];
             }
             pf[kb][0] = make_uint4(pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7]));
             pf[kb][1] = make_uint4(pack2(p[8], p[9]), pack2(p[10], p[11]), pack2(p[12], p[13]), pack2(p[14], p[15]));
+            if constexpr (X3) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const uint32_t w4[4] = {pf[kb][s2].x, pf[kb][s2].y, pf[kb][s2].z, pf[kb][s2].w};
+                    uint32_t r4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        r4[j] = pack2(p[s2 * 8 + 2 * j] - __uint_as_float(w4[j] << 16),
+                                      p[s2 * 8 + 2 * j + 1] - __uint_as_float(w4[j] & 0xffff0000u));
+                    pfl[kb][s2] = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+                }
+            }
         }
         l = l * alpha + lsum;
         m = mnew;
@@ -152,6 +186,15 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
                     const uint2 lo = *reinterpret_cast<const uint2*>(pa);        // keys 4h..4h+3 of the group
                     const uint2 hi = *reinterpret_cast<const uint2*>(pa + 16);   // keys 8+4h..8+4h+3
                     const uint4 a = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    if constexpr (X3) {
+                        const uint2 llo = *reinterpret_cast<const uint2*>(pa + PLANE);
+                        const uint2 lhi = *reinterpret_cast<const uint2*>(pa + PLANE + 16);
+                        const uint4 al = make_uint4(llo.x, llo.y, lhi.x, lhi.y);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al),
+                                                                       __builtin_bit_cast(bf16x8, pf[kb][s2]), o[d], 0, 0, 0);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                       __builtin_bit_cast(bf16x8, pfl[kb][s2]), o[d], 0, 0, 0);
+                    }
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                                    __builtin_bit_cast(bf16x8, pf[kb][s2]), o[d], 0, 0, 0);
                 }
@@ -170,10 +213,18 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int dd = d * 32 + 8 * g4 + 4 * h;   // rows (e&3) + 8*(e>>2) + 4h of the accumulator
+                const float v0 = o[d][4 * g4 + 0] * inv, v1 = o[d][4 * g4 + 1] * inv;
+                const float v2 = o[d][4 * g4 + 2] * inv, v3 = o[d][4 * g4 + 3] * inv;
                 uint2 w;
-                w.x = pack2(o[d][4 * g4 + 0] * inv, o[d][4 * g4 + 1] * inv);
-                w.y = pack2(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
+                w.x = pack2(v0, v1);
+                w.y = pack2(v2, v3);
                 *reinterpret_cast<uint2*>(orow + dd) = w;
+                if constexpr (X3) {
+                    uint2 wl;
+                    wl.x = pack2(v0 - __uint_as_float(w.x << 16), v1 - __uint_as_float(w.x & 0xffff0000u));
+                    wl.y = pack2(v2 - __uint_as_float(w.y << 16), v3 - __uint_as_float(w.y & 0xffff0000u));
+                    *reinterpret_cast<uint2*>(orow + olo + dd) = wl;
+                }
             }
     }
 }
@@ -181,12 +232,17 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
 }  // namespace
 
 int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
-                      int L, int heads, float scale, hipStream_t st) {
+                      int L, int heads, float scale, hipStream_t st, int x3, int qlo, int klo, int vlo, int olo) {
     PGT_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "mha: row strides must be multiples of 8");
     PGT_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "mha: misaligned pointer");
+    PGT_CHECK(!x3 || (qlo % 8 == 0 && klo % 8 == 0 && vlo % 8 == 0 && olo % 4 == 0), "mha: misaligned lo planes");
     const dim3 grid((L + 127) / 128, heads, B);
-    hipLaunchKernelGGL(mha_mfma_kernel, grid, dim3(256), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
-                       (const uint16_t*)v, ldv, (uint16_t*)out, ldo, L, scale * 1.44269504088896340736f);
+    if (x3)
+        hipLaunchKernelGGL(mha_mfma_kernel<true>, grid, dim3(256), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
+                           (const uint16_t*)v, ldv, (uint16_t*)out, ldo, L, scale * 1.44269504088896340736f, qlo, klo, vlo, olo);
+    else
+        hipLaunchKernelGGL(mha_mfma_kernel<false>, grid, dim3(256), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
+                           (const uint16_t*)v, ldv, (uint16_t*)out, ldo, L, scale * 1.44269504088896340736f, 0, 0, 0, 0);
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -392,7 +392,7 @@ template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm,
 
 // number of K slices pgt_conv2d_ws would use for this layer (1 = single pass)
 static int planned_splitk(const pgt_conv_desc* d) {
-    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0) return 1;
+    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_BF16X3) return 1;
     const long M = (long)d->N * d->Ho * d->Wo;
     const int K = d->KH * d->KW * d->Cin;
     const int bk = d->dtype == PGT_F32 ? 32 : 64;
@@ -410,7 +410,8 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
                              const void* residual, const void* sft_dec, const void* sft_shift, void* y,
                              void* workspace, size_t workspace_bytes, pgt_stream_t stream) {
     PGT_CHECK(d && x && w && y, "pgt_conv2d: null argument");
-    PGT_CHECK(d->dtype == PGT_F32 || d->dtype == PGT_BF16, "pgt_conv2d: bad dtype %d", d->dtype);
+    PGT_CHECK(d->dtype == PGT_F32 || d->dtype == PGT_BF16 || d->dtype == PGT_BF16X3, "pgt_conv2d: bad dtype %d", d->dtype);
+    const bool x3 = d->dtype == PGT_BF16X3;
     const int es = d->dtype == PGT_F32 ? 4 : 2;
     const int ch = 16 / es;
     PGT_CHECK(d->Cin > 0 && d->Cin % ch == 0, "pgt_conv2d: Cin=%d must be a multiple of %d", d->Cin, ch);
@@ -432,7 +433,11 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.post_relu = d->post_relu; p.ldr = d->ldr; p.epi = d->epi; p.ld_dec = d->ld_dec;
     p.ld_shift = d->ld_shift; p.sft_w = d->sft_w; p.out_f32 = d->out_f32;
     p.M = d->N * d->Ho * d->Wo;
-    p.K = d->KH * d->KW * d->Cin;
+    p.K = d->KH * d->KW * d->Cin * (x3 ? 3 : 1);
+    p.x3 = x3 ? 1 : 0;
+    p.xlo = d->x_lo ? d->x_lo : d->Cin;
+    p.ylo = d->y_lo ? d->y_lo : d->Cout;
+    p.rlo = d->r_lo ? d->r_lo : d->Cout;
     p.orow_mul = d->orow_mul; p.orow_xmul = d->orow_xmul; p.orow_off = d->orow_off;
     const bool placed = d->orow_mul != 0;
     PGT_CHECK(!placed || (!residual && d->epi == 0), "pgt_conv2d: output placement (orow_*) takes the plain epilogue without residual");
@@ -445,6 +450,18 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.vec_epi = (d->Cout % 8 == 0) && al(y, d->ldy) && al(residual, d->ldr) &&
                 (d->epi == 0 || (al(sft_dec, d->ld_dec) && al(sft_shift, d->ld_shift))) && !d->scalar_epilogue;
     hipStream_t st = (hipStream_t)stream;
+
+    if (x3) {   // split-bf16 operands: the phase-interleaved LDS-DMA kernel with the three-segment K order
+        PGT_CHECK(d->Cin % 64 == 0 && d->ups == 0 && d->epi == 0 && d->KH * d->KW <= 30,
+                  "pgt_conv2d: bf16x3 needs Cin %% 64 == 0 (Cin=%d), no up-sampling, the plain epilogue", d->Cin);
+        PGT_CHECK(d->ldx >= p.xlo + d->Cin && p.xlo % 8 == 0 && p.xlo >= d->Cin, "pgt_conv2d: bf16x3 x_lo=%d / ldx=%d do not hold [hi | lo] planes of %d channels", p.xlo, d->ldx, d->Cin);
+        PGT_CHECK(d->out_f32 || (d->ldy >= p.ylo + d->Cout && p.ylo % 8 == 0 && p.ylo >= d->Cout), "pgt_conv2d: bf16x3 y_lo=%d / ldy=%d do not hold [hi | lo] planes of %d channels", p.ylo, d->ldy, d->Cout);
+        PGT_CHECK(!residual || (d->ldr >= p.rlo + d->Cout && p.rlo % 8 == 0), "pgt_conv2d: bf16x3 residual planes");
+        PGT_CHECK(p.vec_epi && (long)d->Cout * p.K * 2 < (1L << 31), "pgt_conv2d: bf16x3 needs Cout %% 8 == 0, 16-byte aligned rows and weights < 2 GiB");
+        const int rc = pgt_igemm4_launch(&p, d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256), st);
+        PGT_CHECK(rc != 1, "pgt_conv2d: bf16x3 has no %d-column tile (128, 256)", d->force_bn);
+        return rc;
+    }
 
     // ---- split-K: slices write fp32 partial tiles to the workspace, a second kernel sums + applies the epilogue
     const int slices = (workspace && p.vec_epi) ? planned_splitk(d) : 1;

@@ -27,6 +27,8 @@
 //     which also covers strided and nearest-2x up-sampled inputs; the K-tile channel offset is the scalar soffset.
 //
 // Swizzle (swz128) and epilogue as igemm3.hip.  Preconditions: bf16, Cin % 64 == 0, KH*KW <= 30, tensors < 2 GiB.
+#include <atomic>
+
 #include "common.h"
 #include "pgt_internal.h"
 #include "igemm_common.h"
@@ -58,7 +60,7 @@ constexpr int lds_bytes4(int wr, int wc) {
     return stages > epi ? stages : epi;
 }
 
-template <int WR, int WC, bool UPS>
+template <int WR, int WC, bool UPS, bool X3 = false>
 __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     static_assert(WR * WC == 8, "8 waves");
     constexpr int BM = WR * 128, BN = WC * 64;
@@ -96,6 +98,9 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     int a_pix[2][PA];
     unsigned a_mask[2][PA], a_sel[2][PA], b_off[2][PB];
     int ky = 0, kx = 0, c0 = 0;   // filter tap / first channel of the K tile whose A units are issued next (uniform)
+    // X3: per tap the K axis runs over three Cin-wide segments [x_hi | x_lo | x_hi] (the weights hold [w_hi | w_hi |
+    // w_lo]): `seg` is the segment, a_soff the byte offset of the K tile's first channel inside the pixel row.
+    int seg = 0, a_soff = 0;
 
     auto setup_b = [&](int h) {
 #pragma unroll
@@ -172,16 +177,22 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
 #pragma unroll
         for (int g = 0; g < PA; ++g)
             if (g >= g0 && g < g1)
-                bufdma16(a_sel[h][g], rsrc_x, c0 * 2, lds0 + buf * STAGE + (g * 128 + h * 64 + wave * 8) * 128);
+                bufdma16(a_sel[h][g], rsrc_x, a_soff, lds0 + buf * STAGE + (g * 128 + h * 64 + wave * 8) * 128);
     };
     auto advance = [&]() {
         c0 += 64;
         if (c0 == p.Cin) {
             c0 = 0;
-            if (++kx == p.KW) { kx = 0; ++ky; }
-            select_tap(0);
-            select_tap(1);
+            if (X3 && ++seg < 3) {
+                // next segment of the same tap: same pixels, other plane
+            } else {
+                seg = 0;
+                if (++kx == p.KW) { kx = 0; ++ky; }
+                select_tap(0);
+                select_tap(1);
+            }
         }
+        a_soff = (c0 + ((X3 && seg == 1) ? p.xlo : 0)) * 2;
     };
     auto issue_b = [&](int h, int buf, int kt) {
 #pragma unroll
@@ -304,11 +315,11 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     return;
 #endif
 
-    epilogue_128x64<WR, WC>(p, acc, smem, m0, n0, tid, lane, wr, wc);
+    epilogue_128x64<WR, WC, X3>(p, acc, smem, m0, n0, tid, lane, wr, wc);
     PGT_STAMP(3);
 }
 
-template <int WR, int WC, bool UPS> int launch4(const ConvP& p0, hipStream_t st) {
+template <int WR, int WC, bool UPS, bool X3 = false> int launch4(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     constexpr int BM = WR * 128, BN = WC * 64, bytes = lds_bytes4(WR, WC);
     const bool pow2 = (p.Wo & (p.Wo - 1)) == 0 && (p.Ho & (p.Ho - 1)) == 0;
@@ -316,14 +327,17 @@ template <int WR, int WC, bool UPS> int launch4(const ConvP& p0, hipStream_t st)
     p.ho_shift = pow2 ? __builtin_ctz(p.Ho) : -1;
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.Cout + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS>),
+    // the attribute is per device and per function: set it once per (device, instantiation), thread-safe
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { pgt_set_error("igemm4: cannot reserve %d B of LDS: %s", bytes, hipGetErrorString(e)); return -12; }
-        attr_set = true;
+        attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
+    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS, X3>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -334,6 +348,12 @@ template <int WR, int WC, bool UPS> int launch4(const ConvP& p0, hipStream_t st)
 // tiles; bn = 128: 512x128 tiles.  Returns 1 if the tile is not built.
 int pgt_igemm4_launch(const void* pv, int bn, hipStream_t st) {
     const ConvP& p = *reinterpret_cast<const ConvP*>(pv);
+    if (p.x3) {   // split-bf16 operands (no up-sampled inputs on that path)
+        if (p.ups) return 1;
+        if (bn == 256) return launch4<2, 4, false, true>(p, st);
+        if (bn == 128) return launch4<4, 2, false, true>(p, st);
+        return 1;
+    }
     if (bn == 256) return p.ups ? launch4<2, 4, true>(p, st) : launch4<2, 4, false>(p, st);
     if (bn == 128) return p.ups ? launch4<4, 2, true>(p, st) : launch4<4, 2, false>(p, st);
     return 1;

@@ -37,6 +37,8 @@ struct ConvP {
     int splitk, kt_per_split;   // > 1: K is cut in `splitk` slices of `kt_per_split` K tiles each
     int wo_shift, ho_shift;     // igemm4: log2(Wo), log2(Ho) when both are powers of two, else -1 (set by its launcher)
     int orow_mul, orow_xmul, orow_off;   // output row of pixel m (orow_mul = 0: m), see pgt_conv_desc
+    int x3;                     // split-bf16 operands: x = [hi | lo] planes, K runs over [x_hi | x_lo | x_hi] per tap
+    int xlo, ylo, rlo;          // element offset of the lo plane inside a pixel row of x / y / residual
 };
 
 // row index of output pixel m in y (dense, or the sub-pixel placement of pgt_conv_desc::orow_*)

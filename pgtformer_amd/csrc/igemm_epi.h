@@ -8,7 +8,8 @@ namespace {
 template <int WR, int WC> constexpr int epi_stage_bytes() { return WR * 64 * (WC * 64 + 4) * 4; }
 
 // smem: at least epi_stage_bytes<WR, WC>() bytes, no DMA in flight, all waves past their last fragment read.
-template <int WR, int WC>
+// X3: split-bf16 output (hi at n, lo at n + p.ylo) and split residual (p.rlo); plain epilogue only.
+template <int WR, int WC, bool X3 = false>
 __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&acc)[4][2], char* smem, int m0, int n0,
                                                 int tid, int lane, int wr, int wc) {
     constexpr int BN = WC * 64;
@@ -39,7 +40,12 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
             const int m = m0 + (rl >> 6) * 128 + pass * 64 + (rl & 63);
             pre0[c] = pre1[c] = make_uint4(0, 0, 0, 0);
             if (m < p.M && n < p.Cout) {
-                if (p.epi == 1) {
+                if (X3) {
+                    if (res) {
+                        pre0[c] = *reinterpret_cast<const uint4*>(res + (long)m * p.ldr + n);
+                        pre1[c] = *reinterpret_cast<const uint4*>(res + (long)m * p.ldr + p.rlo + n);
+                    }
+                } else if (p.epi == 1) {
                     pre0[c] = *reinterpret_cast<const uint4*>(dec + (long)m * p.ld_dec + n);
                     pre1[c] = *reinterpret_cast<const uint4*>(shf + (long)m * p.ld_shift + n);
                 } else if (res) {
@@ -81,7 +87,22 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
             float v[8];
             *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8);
             *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8 + 4);
-            if (p.epi == 1) {
+            if (X3) {
+                if (res) {
+                    float r[8];
+                    merge8(pre0[c], pre1[c], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                if (!p.out_f32) {
+                    uint4 hi, lo;
+                    split8(v, hi, lo);
+                    bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + out_row(p, m) * p.ldy + n;
+                    *reinterpret_cast<uint4*>(yp) = hi;
+                    *reinterpret_cast<uint4*>(yp + p.ylo) = lo;
+                    continue;
+                }
+            } else if (p.epi == 1) {
                 float d[8], sh[8];
                 Vec16<bf16_t>::unpack(pre0[c], d);
                 Vec16<bf16_t>::unpack(pre1[c], sh);

@@ -201,6 +201,50 @@ __global__ void frame_to_u8_kernel(const T* __restrict__ x, int ldx, long npix, 
     y[i] = (uint8_t)v;   // truncation toward zero, like np.array(float, np.uint8)
 }
 
+
+// dst frame i <- src frame idx[i]; a frame is `rows` rows of `row_bytes` bytes (multiple of 16) with independent
+// row strides (channel slices of wider buffers are valid on both sides).  One thread per 16-byte chunk.
+__global__ __launch_bounds__(256) void gather_frames_kernel(const char* __restrict__ src, long src_row_stride,
+                                                            char* __restrict__ dst, long dst_row_stride,
+                                                            const int* __restrict__ idx, long rows, int chunks) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * chunks) return;
+    const long r = i / chunks;
+    const int c = (int)(i % chunks);
+    const int f = blockIdx.y;
+    const long sf = idx[f];
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (sf * rows + r) * src_row_stride + (long)c * 16);
+    *reinterpret_cast<uint4*>(dst + ((long)f * rows + r) * dst_row_stride + (long)c * 16) = v;
+}
+
+// fp32 (rows, cols) -> split-bf16 planes (hi at dst, lo at dst + dlo), 8 columns per thread
+__global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int lds, bf16_t* __restrict__ dst, int ldd,
+                                                       int dlo, long rows, int cols8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols8) return;
+    const long r = i / cols8;
+    const int c = (int)(i % cols8) * 8;
+    float f[8];
+    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(src + r * lds + c);
+    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(src + r * lds + c + 4);
+    uint4 hi, lo;
+    split8(f, hi, lo);
+    *reinterpret_cast<uint4*>(dst + r * ldd + c) = hi;
+    *reinterpret_cast<uint4*>(dst + r * ldd + dlo + c) = lo;
+}
+// split-bf16 planes -> fp32
+__global__ __launch_bounds__(256) void x3_merge_kernel(const bf16_t* __restrict__ src, int lds, int slo, float* __restrict__ dst,
+                                                       int ldd, long rows, int cols8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols8) return;
+    const long r = i / cols8;
+    const int c = (int)(i % cols8) * 8;
+    float f[8];
+    merge8(*reinterpret_cast<const uint4*>(src + r * lds + c), *reinterpret_cast<const uint4*>(src + r * lds + slo + c), f);
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = *reinterpret_cast<const float4*>(f);
+    *reinterpret_cast<float4*>(dst + r * ldd + c + 4) = *reinterpret_cast<const float4*>(f + 4);
+}
+
 inline dim3 grid1d(long n, int blk = 256) { return dim3((unsigned)((n + blk - 1) / blk)); }
 
 }  // namespace
@@ -333,4 +377,41 @@ extern "C" int pgt_frame_to_u8(int32_t dtype, const void* x, int32_t ldx, int32_
     DT_DISPATCH(dtype, "frame_to_u8",
                 hipLaunchKernelGGL((frame_to_u8_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, npix, y),
                 hipLaunchKernelGGL((frame_to_u8_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, npix, y));
+}
+
+extern "C" int pgt_gather_frames(const void* src, int64_t src_row_stride, void* dst, int64_t dst_row_stride,
+                                 const int32_t* idx, int32_t n_dst, int64_t rows, int32_t row_bytes,
+                                 pgt_stream_t stream) {
+    PGT_CHECK(src && dst && idx && n_dst > 0 && rows > 0, "gather_frames: bad argument");
+    PGT_CHECK(row_bytes > 0 && row_bytes % 16 == 0 && src_row_stride % 16 == 0 && dst_row_stride % 16 == 0 &&
+              ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0,
+              "gather_frames: rows must be 16-byte aligned multiples of 16 bytes (row_bytes=%d)", row_bytes);
+    const int chunks = row_bytes / 16;
+    const long per_frame = rows * chunks;
+    PGT_CHECK((per_frame + 255) / 256 < (1L << 31) && n_dst < 65536, "gather_frames: grid too large");
+    hipLaunchKernelGGL(gather_frames_kernel, dim3((unsigned)((per_frame + 255) / 256), n_dst), dim3(256), 0,
+                       (hipStream_t)stream, (const char*)src, (long)src_row_stride, (char*)dst, (long)dst_row_stride, idx,
+                       (long)rows, chunks);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_x3_split(const float* src, int32_t lds, void* dst, int32_t ldd, int32_t dst_lo, int64_t rows,
+                            int32_t cols, pgt_stream_t stream) {
+    PGT_CHECK(src && dst && cols % 8 == 0 && lds % 4 == 0 && ldd % 8 == 0 && dst_lo % 8 == 0 && dst_lo >= cols &&
+              ldd >= dst_lo + cols && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "x3_split: bad argument / alignment");
+    hipLaunchKernelGGL(x3_split_kernel, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream, src, lds,
+                       (bf16_t*)dst, ldd, dst_lo, (long)rows, cols / 8);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float* dst, int32_t ldd, int64_t rows,
+                            int32_t cols, pgt_stream_t stream) {
+    PGT_CHECK(src && dst && cols % 8 == 0 && lds % 8 == 0 && ldd % 4 == 0 && src_lo % 8 == 0 && lds >= src_lo + cols &&
+              ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "x3_merge: bad argument / alignment");
+    hipLaunchKernelGGL(x3_merge_kernel, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, lds, src_lo, dst, ldd, (long)rows, cols / 8);
+    PGT_LAUNCH_CHECK();
+    return 0;
 }

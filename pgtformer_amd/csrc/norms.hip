@@ -11,9 +11,11 @@ constexpr int kT = 256;
 // GroupNorm statistics, stage 1: per (image, pixel-chunk) partial sum / sum-of-squares per group.
 // Thread -> (pixel slot, 16-byte channel chunk); the chunk is fixed per thread, pixels strided.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NQ>
+// X3: x is a split-bf16 tensor (T = bf16_t): the value of a channel is hi + lo, the lo plane sits xlo elements
+// after the hi plane in every pixel row.
+template <typename T, int NQ, bool X3 = false>
 __global__ __launch_bounds__(kT) void gn_partial_kernel(const T* __restrict__ x, int ldx, int HW, int C, int groups,
-                                                        int pix_per_blk, float* __restrict__ part) {
+                                                        int pix_per_blk, float* __restrict__ part, int xlo = 0) {
     constexpr int CH = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C] sums, then [slots][C] sumsq
     const int QC = C / CH;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(kT) void gn_partial_kernel(const T* __restrict__ x,
         // cover the HBM latency (2.6 TB/s measured); accumulation order per thread is unchanged (ascending pixels).
         constexpr int kU = 4;
         for (int p = p_begin + slot; p < p_end; p += kU * PS) {
-            uint4 v[kU][NQ];
+            uint4 v[kU][NQ], vl[X3 ? kU : 1][NQ];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const int pu = p + u * PS;
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(kT) void gn_partial_kernel(const T* __restrict__ x,
                 for (int j = 0; j < NQ; ++j) {
                     const int q = q0 + j * kT;
                     v[u][j] = q < QC ? *reinterpret_cast<const uint4*>(row + q * CH) : make_uint4(0, 0, 0, 0);
+                    if constexpr (X3) vl[u][j] = q < QC ? *reinterpret_cast<const uint4*>(row + xlo + q * CH) : make_uint4(0, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(kT) void gn_partial_kernel(const T* __restrict__ x,
                 for (int j = 0; j < NQ; ++j) {
                     if (q0 + j * kT < QC) {
                         float f[CH];
-                        Vec16<T>::unpack(v[u][j], f);
+                        if constexpr (X3) merge8(v[u][j], vl[u][j], f);
+                        else Vec16<T>::unpack(v[u][j], f);
 #pragma unroll
                         for (int e = 0; e < CH; ++e) { s[j][e] += f[e]; ss[j][e] += f[e] * f[e]; }
                     }
@@ -168,10 +172,10 @@ template <typename T, int CH> __device__ __forceinline__ void act_vec(float* f, 
 }
 
 // y = act(x*scale[n,c] + shift[n,c])
-template <typename T, int NQ>
+template <typename T, int NQ, bool X3 = false>
 __global__ __launch_bounds__(kT) void affine_act_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                         int HW, int C, int pix_per_blk, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, int act) {
+                                                        const float* __restrict__ shift, int act, int xlo = 0, int ylo = 0) {
     constexpr int CH = Vec16<T>::N;
     const int QC = C / CH;
     const int PS = NQ > 1 ? 1 : kT / QC;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(kT) void affine_act_kernel(const T* __restrict__ x,
     const int p_end = min(HW, p_begin + pix_per_blk);
     constexpr int kU = 4;   // pixels per trip, loads first (see gn_partial_kernel)
     for (int p = p_begin + slot; p < p_end; p += kU * PS) {
-        uint4 v[kU][NQ];
+        uint4 v[kU][NQ], vl[X3 ? kU : 1][NQ];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int pu = p + u * PS;
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(kT) void affine_act_kernel(const T* __restrict__ x,
             for (int j = 0; j < NQ; ++j) {
                 const int q = q0 + j * kT;
                 v[u][j] = q < QC ? *reinterpret_cast<const uint4*>(row + q * CH) : make_uint4(0, 0, 0, 0);
+                if constexpr (X3) vl[u][j] = q < QC ? *reinterpret_cast<const uint4*>(row + xlo + q * CH) : make_uint4(0, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -215,11 +220,20 @@ __global__ __launch_bounds__(kT) void affine_act_kernel(const T* __restrict__ x,
                 const int q = q0 + j * kT;
                 if (q < QC) {
                     float f[CH];
-                    Vec16<T>::unpack(v[u][j], f);
+                    if constexpr (X3) merge8(v[u][j], vl[u][j], f);
+                    else Vec16<T>::unpack(v[u][j], f);
 #pragma unroll
                     for (int e = 0; e < CH; ++e) f[e] = f[e] * sc[j][e] + sh[j][e];
-                    act_vec<T, CH>(f, act);
-                    *reinterpret_cast<uint4*>(orow + q * CH) = Vec16<T>::pack(f);
+                    if constexpr (X3) {   // exact expf / division: this type exists for precision
+                        act_vec<float, CH>(f, act);
+                        uint4 hi, lo;
+                        split8(f, hi, lo);
+                        *reinterpret_cast<uint4*>(orow + q * CH) = hi;
+                        *reinterpret_cast<uint4*>(orow + ylo + q * CH) = lo;
+                    } else {
+                        act_vec<T, CH>(f, act);
+                        *reinterpret_cast<uint4*>(orow + q * CH) = Vec16<T>::pack(f);
+                    }
                 }
             }
         }
@@ -271,11 +285,13 @@ template <int EPL> struct RowIO<float, EPL, true> {    // EPL in {4, 8, 16}
     }
 };
 
-template <typename T, int EPL, bool VEC>
+// X3 (T = bf16_t): x, y, pos and y2 are split-bf16 rows, the lo plane xlo / ylo / plo / y2lo elements after the hi plane.
+template <typename T, int EPL, bool VEC, bool X3 = false>
 __global__ __launch_bounds__(kT) void layernorm_kernel(const T* __restrict__ x, int ldx, int rows, int C,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, T* __restrict__ y, int ldy, const T* __restrict__ pos,
-                                                       int ldpos, T* __restrict__ y2, int ldy2) {
+                                                       int ldpos, T* __restrict__ y2, int ldy2, int xlo = 0, int ylo = 0,
+                                                       int plo = 0, int y2lo = 0) {
     typedef RowIO<T, EPL, VEC> IO;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
@@ -283,6 +299,12 @@ __global__ __launch_bounds__(kT) void layernorm_kernel(const T* __restrict__ x, 
     const int c0 = lane * EPL;
     float v[EPL], gm[EPL], bt[EPL];
     IO::ld(x + (long)row * ldx + c0, v);
+    if constexpr (X3) {
+        float vl[EPL];
+        IO::ld(x + (long)row * ldx + xlo + c0, vl);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] += vl[e];
+    }
     RowIO<float, EPL, VEC>::ld(gamma + c0, gm);
     RowIO<float, EPL, VEC>::ld(beta + c0, bt);
     float s = 0.f;
@@ -295,13 +317,30 @@ __global__ __launch_bounds__(kT) void layernorm_kernel(const T* __restrict__ x, 
     const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) v[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
-    IO::st(y + (long)row * ldy + c0, v);
+    auto store = [&](T* dst, int lo_off, const float* f) {
+        if constexpr (X3) {
+            float hf[EPL], lf[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { hf[e] = bf2f(f2bf(f[e])); lf[e] = f[e] - hf[e]; }
+            IO::st(dst, hf);
+            IO::st(dst + lo_off, lf);
+        } else {
+            IO::st(dst, f);
+        }
+    };
+    store(y + (long)row * ldy + c0, ylo, v);
     if (y2) {
         float pv[EPL];
         IO::ld(pos + (long)row * ldpos + c0, pv);
+        if constexpr (X3) {
+            float pl[EPL];
+            IO::ld(pos + (long)row * ldpos + plo + c0, pl);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) pv[e] += pl[e];
+        }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) pv[e] += v[e];
-        IO::st(y2 + (long)row * ldy2 + c0, pv);
+        store(y2 + (long)row * ldy2 + c0, y2lo, pv);
     }
 }
 
@@ -390,9 +429,10 @@ extern "C" size_t pgt_groupnorm_workspace_bytes(int32_t N, int32_t HW, int32_t C
     return (size_t)N * nb * groups * 2 * sizeof(float);
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int gn_affine_impl(const void* x, int ldx, int N, int HW, int C, int groups, float eps, const float* gamma,
-                          const float* beta, float* scale, float* shift, void* ws, size_t ws_bytes, hipStream_t st) {
+                          const float* beta, float* scale, float* shift, void* ws, size_t ws_bytes, hipStream_t st,
+                          int xlo = 0) {
     constexpr int CH = Vec16<T>::N;
     PGT_CHECK(C % CH == 0 && ldx % CH == 0, "groupnorm: C=%d, ldx=%d must be multiples of %d", C, ldx, CH);
     PGT_CHECK(C % groups == 0 && groups <= 64, "groupnorm: C=%d not divisible by groups=%d (<=64)", C, groups);
@@ -405,9 +445,9 @@ static int gn_affine_impl(const void* x, int ldx, int N, int HW, int C, int grou
     const size_t lds = (size_t)2 * ps * C * sizeof(float);
     float* part = (float*)ws;
     if (QC > kT)
-        hipLaunchKernelGGL((gn_partial_kernel<T, 2>), dim3(nb, N), dim3(kT), lds, st, (const T*)x, ldx, HW, C, groups, ppb, part);
+        hipLaunchKernelGGL((gn_partial_kernel<T, 2, X3>), dim3(nb, N), dim3(kT), lds, st, (const T*)x, ldx, HW, C, groups, ppb, part, xlo);
     else
-        hipLaunchKernelGGL((gn_partial_kernel<T, 1>), dim3(nb, N), dim3(kT), lds, st, (const T*)x, ldx, HW, C, groups, ppb, part);
+        hipLaunchKernelGGL((gn_partial_kernel<T, 1, X3>), dim3(nb, N), dim3(kT), lds, st, (const T*)x, ldx, HW, C, groups, ppb, part, xlo);
     PGT_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(1024), 0, st, part, nb, HW, C, groups, eps, gamma, beta, scale, shift);
     PGT_LAUNCH_CHECK();
@@ -424,9 +464,9 @@ extern "C" int pgt_groupnorm_affine(int32_t dtype, const void* x, int32_t ldx, i
     PGT_CHECK(false, "groupnorm: bad dtype %d", dtype);
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int affine_act_impl(const void* x, int ldx, void* y, int ldy, int N, int HW, int C, const float* scale,
-                           const float* shift, int act, hipStream_t st) {
+                           const float* shift, int act, hipStream_t st, int xlo = 0, int ylo = 0) {
     constexpr int CH = Vec16<T>::N;
     PGT_CHECK(C % CH == 0 && ldx % CH == 0 && ldy % CH == 0, "affine_act: C/ldx/ldy must be multiples of %d", CH);
     const int QC = C / CH;
@@ -434,9 +474,9 @@ static int affine_act_impl(const void* x, int ldx, void* y, int ldy, int N, int 
     const int ppb = gn_pix_per_block(N, HW, QC);
     const int nb = (HW + ppb - 1) / ppb;
     if (QC > kT)
-        hipLaunchKernelGGL((affine_act_kernel<T, 2>), dim3(nb, N), dim3(kT), 0, st, (const T*)x, ldx, (T*)y, ldy, HW, C, ppb, scale, shift, act);
+        hipLaunchKernelGGL((affine_act_kernel<T, 2, X3>), dim3(nb, N), dim3(kT), 0, st, (const T*)x, ldx, (T*)y, ldy, HW, C, ppb, scale, shift, act, xlo, ylo);
     else
-        hipLaunchKernelGGL((affine_act_kernel<T, 1>), dim3(nb, N), dim3(kT), 0, st, (const T*)x, ldx, (T*)y, ldy, HW, C, ppb, scale, shift, act);
+        hipLaunchKernelGGL((affine_act_kernel<T, 1, X3>), dim3(nb, N), dim3(kT), 0, st, (const T*)x, ldx, (T*)y, ldy, HW, C, ppb, scale, shift, act, xlo, ylo);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -450,16 +490,35 @@ extern "C" int pgt_affine_act(int32_t dtype, const void* x, int32_t ldx, void* y
     PGT_CHECK(false, "affine_act: bad dtype %d", dtype);
 }
 
-template <typename T>
+extern "C" int pgt_groupnorm_affine_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t N, int32_t HW, int32_t C,
+                                       int32_t groups, float eps, const float* gamma, const float* beta, float* scale,
+                                       float* shift, void* workspace, size_t workspace_bytes, pgt_stream_t stream) {
+    PGT_CHECK(x && gamma && beta && scale && shift && workspace, "groupnorm_x3: null argument");
+    PGT_CHECK(((uintptr_t)x & 15) == 0 && x_lo % 8 == 0 && x_lo >= C && ldx >= x_lo + C, "groupnorm_x3: bad planes (ldx=%d x_lo=%d C=%d)", ldx, x_lo, C);
+    return gn_affine_impl<bf16_t, true>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream, x_lo);
+}
+
+extern "C" int pgt_affine_act_x3(const void* x, int32_t ldx, int32_t x_lo, void* y, int32_t ldy, int32_t y_lo, int32_t N,
+                                 int32_t HW, int32_t C, const float* scale, const float* shift, int32_t act,
+                                 pgt_stream_t stream) {
+    PGT_CHECK(x && y && scale && shift, "affine_act_x3: null argument");
+    PGT_CHECK((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && x_lo % 8 == 0 && y_lo % 8 == 0 && ldx >= x_lo + C && ldy >= y_lo + C &&
+              x_lo >= C && y_lo >= C, "affine_act_x3: bad planes");
+    return affine_act_impl<bf16_t, true>(x, ldx, y, ldy, N, HW, C, scale, shift, act, (hipStream_t)stream, x_lo, y_lo);
+}
+
+template <typename T, bool X3 = false>
 static int layernorm_impl(const void* x, int ldx, int rows, int C, const float* gamma, const float* beta, float eps,
-                          void* y, int ldy, const void* pos, int ldpos, void* y2, int ldy2, hipStream_t st) {
+                          void* y, int ldy, const void* pos, int ldpos, void* y2, int ldy2, hipStream_t st, int xlo = 0,
+                          int ylo = 0, int plo = 0, int y2lo = 0) {
     const dim3 grid((rows + 3) / 4), blk(kT);
     // 8/16-byte row accesses need 16-byte aligned rows on every tensor
     auto al = [](const void* ptr, int ld) { return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && ld % 8 == 0); };
-    const bool vec = al(x, ldx) && al(y, ldy) && al(pos, ldpos) && al(y2, ldy2) && al(gamma, 8) && al(beta, 8);
-#define LN_LAUNCH2(EPL, VEC)                                                                                          \
-    hipLaunchKernelGGL((layernorm_kernel<T, EPL, VEC>), grid, blk, 0, st, (const T*)x, ldx, rows, C, gamma, beta, eps, \
-                       (T*)y, ldy, (const T*)pos, ldpos, (T*)y2, ldy2)
+    const bool vec = al(x, ldx) && al(y, ldy) && al(pos, ldpos) && al(y2, ldy2) && al(gamma, 8) && al(beta, 8) &&
+                     xlo % 8 == 0 && ylo % 8 == 0 && plo % 8 == 0 && y2lo % 8 == 0;
+#define LN_LAUNCH2(EPL, VEC)                                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<T, EPL, VEC, X3>), grid, blk, 0, st, (const T*)x, ldx, rows, C, gamma, beta, eps, \
+                       (T*)y, ldy, (const T*)pos, ldpos, (T*)y2, ldy2, xlo, ylo, plo, y2lo)
 #define LN_LAUNCH(EPL) do { if (vec && EPL >= 4) LN_LAUNCH2(EPL, (EPL >= 4)); else LN_LAUNCH2(EPL, false); } while (0)
     switch (C) {
         case 64: LN_LAUNCH(1); break;
@@ -473,6 +532,17 @@ static int layernorm_impl(const void* x, int ldx, int rows, int C, const float* 
 #undef LN_LAUNCH2
     PGT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int pgt_layernorm_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t rows, int32_t C, const float* gamma,
+                                const float* beta, float eps, void* y, int32_t ldy, int32_t y_lo, const void* pos,
+                                int32_t ldpos, int32_t pos_lo, void* y2, int32_t ldy2, int32_t y2_lo, pgt_stream_t stream) {
+    PGT_CHECK(x && y && gamma && beta, "layernorm_x3: null argument");
+    PGT_CHECK(!y2 || pos, "layernorm_x3: y2 requested without pos");
+    PGT_CHECK(x_lo >= C && y_lo >= C && ldx >= x_lo + C && ldy >= y_lo + C, "layernorm_x3: bad planes");
+    PGT_CHECK(!y2 || (pos_lo >= C && y2_lo >= C && ldpos >= pos_lo + C && ldy2 >= y2_lo + C), "layernorm_x3: bad pos / y2 planes");
+    return layernorm_impl<bf16_t, true>(x, ldx, rows, C, gamma, beta, eps, y, ldy, pos, ldpos, y2, ldy2, (hipStream_t)stream,
+                                        x_lo, y_lo, pos_lo, y2_lo);
 }
 
 extern "C" int pgt_layernorm(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t C, const float* gamma,

@@ -5,14 +5,16 @@
 
 // attention_mfma.hip: bf16 MFMA flash attention (hd = 64)
 int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B,
-                      int L, int heads, float scale, hipStream_t st);
+                      int L, int heads, float scale, hipStream_t st, int x3 = 0, int qlo = 0, int klo = 0, int vlo = 0,
+                      int olo = 0);
 
 // igemm2.hip: LDS-DMA implicit GEMM (bf16, Cin % 64 == 0, 16-byte epilogue legal). `conv_p` is a ConvP.
 int pgt_igemm2_launch(const void* conv_p, int bn, int stages, hipStream_t st);
 
 // window_attn_mfma.hip: bf16 MFMA window attention; returns 1 if the shape is not covered (fall back)
 int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int T, int H,
-                              int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st);
+                              int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st, int x3 = 0,
+                              int qlo = 0, int olo = 0);
 
 // igemm3.hip: large-tile LDS-DMA implicit GEMM (bf16, stride 1, no up-sampling, Cin % 64 == 0); 1 = combination not built
 int pgt_igemm3_launch(const void* conv_p, int bm, int bn, int stages, hipStream_t st);

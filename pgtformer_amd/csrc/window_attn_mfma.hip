@@ -19,17 +19,22 @@ namespace {
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 
-template <int HD, int NW>
+// X3: qkv and out are split-bf16 rows (hi plane at the usual columns, lo plane qlo / olo elements further): every
+// product is taken as hi*hi + lo*hi + hi*lo (S^T from q, k; O^T from P, V with P split in registers after the exp).
+template <int HD, int NW, bool X3 = false>
 __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_t* __restrict__ qkv, int ldqkv,
                                                                    uint16_t* __restrict__ out, int ldo,
                                                                    const float* __restrict__ bias, int T_, int H, int W,
-                                                                   int C, int heads, int wh, int ww, int sh, int sw) {
+                                                                   int C, int heads, int wh, int ww, int sh, int sw,
+                                                                   int qlo = 0, int olo = 0) {
     constexpr int N = 48 * NW;
     constexpr int VSTR = N * 2 + 8;   // V^T row stride in bytes (keys contiguous, 8-byte pad)
     constexpr int KS = HD / 32;       // k-steps of the S^T MFMA
     constexpr int DT = HD / 16;       // 16-wide head-dim tiles of O^T
+    constexpr int NP = X3 ? 2 : 1;    // operand planes
     constexpr float LOG2E = 1.44269504088896340736f;
-    __shared__ __attribute__((aligned(16))) char vt[HD * VSTR];
+    __shared__ __attribute__((aligned(16))) char vt_all[NP * HD * VSTR];
+    char* const vt = vt_all;
     __shared__ int tok[N];
     __shared__ int reg[N];
 
@@ -55,24 +60,27 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
     }
     __syncthreads();
     // ---- V^T image: work item = (key pair, 8-channel chunk); dword = {V[2kp][d], V[2kp+1][d]}
-    for (int it = tid; it < (N / 2) * (HD / 8); it += 64 * NW) {
-        const int kp = it / (HD / 8), c = it % (HD / 8);
-        const uint4 v0 = *reinterpret_cast<const uint4*>(qkv + (long)tok[2 * kp] * ldqkv + 2 * C + head * HD + c * 8);
-        const uint4 v1 = *reinterpret_cast<const uint4*>(qkv + (long)tok[2 * kp + 1] * ldqkv + 2 * C + head * HD + c * 8);
+    for (int it = tid; it < NP * (N / 2) * (HD / 8); it += 64 * NW) {
+        const int pl = it / ((N / 2) * (HD / 8)), it2 = it % ((N / 2) * (HD / 8));   // plane (0 = hi, 1 = lo)
+        const int kp = it2 / (HD / 8), c = it2 % (HD / 8);
+        const uint16_t* vb = qkv + pl * qlo + 2 * C + head * HD + c * 8;
+        const uint4 v0 = *reinterpret_cast<const uint4*>(vb + (long)tok[2 * kp] * ldqkv);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(vb + (long)tok[2 * kp + 1] * ldqkv);
         const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w};
         const uint32_t bb[4] = {v1.x, v1.y, v1.z, v1.w};
+        char* vp = vt + pl * HD * VSTR;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<uint32_t*>(vt + (c * 8 + 2 * j) * VSTR + kp * 4) = (a[j] & 0xffffu) | (bb[j] << 16);
-            *reinterpret_cast<uint32_t*>(vt + (c * 8 + 2 * j + 1) * VSTR + kp * 4) = (a[j] >> 16) | (bb[j] & 0xffff0000u);
+            *reinterpret_cast<uint32_t*>(vp + (c * 8 + 2 * j) * VSTR + kp * 4) = (a[j] & 0xffffu) | (bb[j] << 16);
+            *reinterpret_cast<uint32_t*>(vp + (c * 8 + 2 * j + 1) * VSTR + kp * 4) = (a[j] >> 16) | (bb[j] & 0xffff0000u);
         }
     }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, col = lane & 15;
-    const float scale = rsqrtf((float)HD);
+    const float scale = X3 ? 1.0f / sqrtf((float)HD) : rsqrtf((float)HD);
     // Q^T fragments of this wave's 3 query tiles
-    uint4 qf[3][KS];
+    uint4 qf[3][KS], ql[X3 ? 3 : 1][KS];
     int qidx[3], rq[3];
 #pragma unroll
     for (int qt = 0; qt < 3; ++qt) {
@@ -80,7 +88,10 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
         rq[qt] = reg[qidx[qt]];
         const uint16_t* qrow = qkv + (long)tok[qidx[qt]] * ldqkv + head * HD + g * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = *reinterpret_cast<const uint4*>(qrow + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[qt][ks] = *reinterpret_cast<const uint4*>(qrow + ks * 32);
+            if constexpr (X3) ql[qt][ks] = *reinterpret_cast<const uint4*>(qrow + qlo + ks * 32);
+        }
     }
     float m[3], l[3];
     f32x4 o[3][DT];
@@ -93,12 +104,15 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
     }
 
     for (int kg = 0; kg < NW; ++kg) {   // groups of 48 keys
-        uint4 kf[3][KS];
+        uint4 kf[3][KS], kl[X3 ? 3 : 1][KS];
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             const uint16_t* krow = qkv + (long)tok[kg * 48 + kt * 16 + col] * ldqkv + C + head * HD + g * 8;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf[kt][ks] = *reinterpret_cast<const uint4*>(krow + ks * 32);
+            for (int ks = 0; ks < KS; ++ks) {
+                kf[kt][ks] = *reinterpret_cast<const uint4*>(krow + ks * 32);
+                if constexpr (X3) kl[kt][ks] = *reinterpret_cast<const uint4*>(krow + qlo + ks * 32);
+            }
         }
         int rk[3][4];
 #pragma unroll
@@ -113,9 +127,16 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
             for (int kt = 0; kt < 3; ++kt) {
                 s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int ks = 0; ks < KS; ++ks) {
+                    if constexpr (X3) {   // small terms first
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kl[kt][ks]),
+                                                                        __builtin_bit_cast(bf16x8, qf[qt][ks]), s[kt], 0, 0, 0);
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[kt][ks]),
+                                                                        __builtin_bit_cast(bf16x8, ql[qt][ks]), s[kt], 0, 0, 0);
+                    }
                     s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[kt][ks]),
                                                                     __builtin_bit_cast(bf16x8, qf[qt][ks]), s[kt], 0, 0, 0);
+                }
                 const float4 bv = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + kg * 48 + kt * 16 + 4 * g);
                 const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
@@ -133,7 +154,7 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
             const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
             m[qt] = mnew;
             float lsum = 0.f;
-            uint2 pf[3];
+            uint2 pf[3], pl2[X3 ? 3 : 1];
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 float p[4];
@@ -143,6 +164,11 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
                     lsum += p[r];
                 }
                 pf[kt] = make_uint2(f2bf2(p[0], p[1]), f2bf2(p[2], p[3]));
+                if constexpr (X3) {
+                    const float r0 = p[0] - __uint_as_float(pf[kt].x << 16), r1 = p[1] - __uint_as_float(pf[kt].x & 0xffff0000u);
+                    const float r2 = p[2] - __uint_as_float(pf[kt].y << 16), r3 = p[3] - __uint_as_float(pf[kt].y & 0xffff0000u);
+                    pl2[kt] = make_uint2(f2bf2(r0, r1), f2bf2(r2, r3));
+                }
             }
             l[qt] = l[qt] * alpha + lsum;
 #pragma unroll
@@ -152,6 +178,13 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
                     const uint2 a = *reinterpret_cast<const uint2*>(vt + (dt * 16 + col) * VSTR + (kg * 48 + kt * 16 + 4 * g) * 2);
+                    if constexpr (X3) {
+                        const uint2 al = *reinterpret_cast<const uint2*>(vt + HD * VSTR + (dt * 16 + col) * VSTR + (kg * 48 + kt * 16 + 4 * g) * 2);
+                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, al),
+                                                                              __builtin_bit_cast(short4v, pf[kt]), o[qt][dt], 0, 0, 0);
+                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, a),
+                                                                              __builtin_bit_cast(short4v, pl2[kt]), o[qt][dt], 0, 0, 0);
+                    }
                     o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, a),
                                                                           __builtin_bit_cast(short4v, pf[kt]), o[qt][dt], 0, 0, 0);
                 }
@@ -167,22 +200,44 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
         uint16_t* orow = out + (long)tok[qidx[qt]] * ldo + head * HD + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            uint2 w2 = make_uint2(f2bf2(o[qt][dt][0] * inv, o[qt][dt][1] * inv), f2bf2(o[qt][dt][2] * inv, o[qt][dt][3] * inv));
+            const float v0 = o[qt][dt][0] * inv, v1 = o[qt][dt][1] * inv, v2 = o[qt][dt][2] * inv, v3 = o[qt][dt][3] * inv;
+            const uint2 w2 = make_uint2(f2bf2(v0, v1), f2bf2(v2, v3));
             *reinterpret_cast<uint2*>(orow + dt * 16) = w2;
+            if constexpr (X3) {
+                const uint2 wl = make_uint2(f2bf2(v0 - __uint_as_float(w2.x << 16), v1 - __uint_as_float(w2.x & 0xffff0000u)),
+                                            f2bf2(v2 - __uint_as_float(w2.y << 16), v3 - __uint_as_float(w2.y & 0xffff0000u)));
+                *reinterpret_cast<uint2*>(orow + olo + dt * 16) = wl;
+            }
         }
     }
 }
 
 }  // namespace
 
-// bf16; N = T*wh*ww in {48, 96, 144, 192}; hd in {32, 64}.  Returns 1 when the shape is not covered (caller falls back).
+// bf16 (x3 = 0) or split-bf16 (x3 = 1: lo planes qlo / olo elements after the hi planes); N = T*wh*ww in {48, 96, 144,
+// 192}; hd in {32, 64}.  Returns 1 when the shape is not covered (caller falls back).
 int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int T, int H,
-                              int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st) {
+                              int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st, int x3, int qlo,
+                              int olo) {
     const int N = T * wh * ww, hd = C / heads;
     if (N % 48 != 0 || N > 192 || (hd != 32 && hd != 64)) return 1;
     if (ldqkv % 8 != 0 || ldo % 4 != 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7) || ((uintptr_t)bias & 15)) return 1;
+    if (x3 && (qlo % 8 != 0 || olo % 4 != 0)) return 1;
     const int grid = B * (H / wh) * (W / ww) * heads;
     const int nw = N / 48;
+    if (x3) {
+#define WAM3(HD_, NW_)                                                                                                    \
+    hipLaunchKernelGGL((window_attn_mfma_kernel<HD_, NW_, true>), dim3(grid), dim3(64 * NW_), 0, st, (const uint16_t*)qkv, \
+                       ldqkv, (uint16_t*)out, ldo, bias, T, H, W, C, heads, wh, ww, sh, sw, qlo, olo)
+        if (hd == 32) {
+            switch (nw) { case 1: WAM3(32, 1); break; case 2: WAM3(32, 2); break; case 3: WAM3(32, 3); break; default: WAM3(32, 4); }
+        } else {
+            switch (nw) { case 1: WAM3(64, 1); break; case 2: WAM3(64, 2); break; case 3: WAM3(64, 3); break; default: WAM3(64, 4); }
+        }
+#undef WAM3
+        PGT_LAUNCH_CHECK();
+        return 0;
+    }
 #define WAM(HD_, NW_)                                                                                             \
     hipLaunchKernelGGL((window_attn_mfma_kernel<HD_, NW_>), dim3(grid), dim3(64 * NW_), 0, st, (const uint16_t*)qkv, \
                        ldqkv, (uint16_t*)out, ldo, bias, T, H, W, C, heads, wh, ww, sh, sw)

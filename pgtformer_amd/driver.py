@@ -19,68 +19,148 @@ from . import parallel
 
 
 class WindowRunner:
-    """Runs the model on uint8 windows, `batch` independent 3-frame windows per forward; optional HIP-graph
-    replay (static shapes)."""
+    """Runs the model on uint8 clips, `batch` 3-frame windows per forward; optional HIP-graph replay (static shapes).
 
-    def __init__(self, model, w=1.0, use_graph=True, height=512, width=512, batch=1):
+    overlap=True (default): a forward takes the batch + 2 CONSECUTIVE frames its `batch` sliding windows cover and the
+    model computes everything per-frame (BiSeNet, the encoder up to its first temporal attention) once per frame
+    (PGTFormer.forward_nhwc(win=...)); overlap=False stacks the windows' 3 frames each (batch*3 frames, the reference's
+    per-window recomputation)."""
+
+    def __init__(self, model, w=1.0, use_graph=True, height=512, width=512, batch=1, overlap=True):
         self.model, self.w = model, w
         self.dev = model.dev
         self.t = model.t
         self.batch = batch
-        self.static_in = torch.zeros((batch * self.t, height, width, 3), dtype=torch.uint8, device=self.dev)
+        self.overlap = overlap
+        n_in = batch + self.t - 1 if overlap else batch * self.t
+        self.static_in = torch.zeros((n_in, height, width, 3), dtype=torch.uint8, device=self.dev)
+        self.static_out = torch.zeros((batch, height, width, 3), dtype=torch.uint8, device=self.dev)
+        self.win = None
+        if overlap:
+            self.win = (torch.arange(batch, dtype=torch.int32)[:, None] + torch.arange(self.t, dtype=torch.int32)[None, :]
+                        ).reshape(-1).to(self.dev)
         self.graph = None
-        self.static_out = None
+        self._pipe = None
         # per-shape kernel selection during the first eager passes (bf16 launches only); PGT_AUTOTUNE=0 keeps the
         # library's static heuristic, PGT_AUTOTUNE_CACHE=<file> reloads / stores the tuned table across processes
         cache = os.environ.get("PGT_AUTOTUNE_CACHE")
         tune = os.environ.get("PGT_AUTOTUNE", "1") != "0" and self.dev.type == "cuda"
         if tune:
             from . import ops
-            if cache and os.path.exists(cache):
-                ops.load_autotune(cache)
-            else:
+            if not (cache and os.path.exists(cache) and ops.load_autotune(cache)):
                 ops.enable_autotune()
         if use_graph:
             self._capture()
         elif tune:
-            self.model.restore_middle_u8(self.static_in, w=self.w)
+            self._forward(self.static_in)
             torch.cuda.synchronize(self.dev)
         if tune and cache and not os.path.exists(cache):
             ops.save_autotune(cache)
+
+    def _forward(self, frames_u8):
+        kw = {"win": self.win} if self.overlap else {}
+        return self.model.restore_middle_u8(frames_u8, w=self.w, out=self.static_out, **kw)
 
     def _capture(self):
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
-            for _ in range(2):  # warm-up: allocator pools, lazy module loading
-                self.model.restore_middle_u8(self.static_in, w=self.w)
+            for _ in range(2):  # warm-up: allocator pools, lazy module loading, kernel autotune
+                self._forward(self.static_in)
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.static_out = self.model.restore_middle_u8(self.static_in, w=self.w)
+            res = self._forward(self.static_in)
+        self.static_res = res
 
-    def run(self, windows_u8):
-        """windows_u8: (batch*3,H,W,3) uint8 device tensor (batch windows back to back) -> restored middle
-        frames (batch,H,W,3) uint8 ((H,W,3) when batch == 1).  Overwritten by the next call when graphs are on."""
+    def _launch(self):
+        """one forward on the frames currently in static_in -> (batch,H,W,3) uint8 (overwritten by the next launch)."""
         if self.graph is None:
-            return self.model.restore_middle_u8(windows_u8, w=self.w)
-        self.static_in.copy_(windows_u8, non_blocking=True)
-        self.graph.replay()
-        return self.static_out
+            res = self._forward(self.static_in)
+        else:
+            self.graph.replay()
+            res = self.static_res
+        return res.reshape(self.batch, *res.shape[-3:])
+
+    def run(self, frames_u8):
+        """frames_u8: uint8 device tensor, (batch+2,H,W,3) consecutive frames (overlap) or (batch*3,H,W,3) windows back to
+        back -> restored middle frames (batch,H,W,3) uint8 ((H,W,3) when batch == 1).  Overwritten by the next call."""
+        self.static_in.copy_(frames_u8, non_blocking=True)
+        res = self._launch()
+        return res[0] if self.batch == 1 else res
+
+    def _fill_static(self, padded, j, dst):
+        """copy the input frames of windows j .. j+batch-1 of the padded clip (device or pinned host) into dst (the
+        static input or a staging buffer of its shape).  Windows past the clip end (ragged tail batch) read whatever
+        dst held before; their outputs are discarded."""
+        n_pad, t, b = padded.shape[0], self.t, self.batch
+        if self.overlap:
+            k = min(b + t - 1, n_pad - j)
+            dst[:k].copy_(padded[j:j + k], non_blocking=True)
+        else:
+            k = min(b, n_pad - (t - 1) - j)
+            for i in range(k):
+                dst[i * t:(i + 1) * t].copy_(padded[j + i:j + i + t], non_blocking=True)
 
     def run_clip(self, padded, out):
         """padded: (n+2,H,W,3) u8 = [prev halo, n frames, next halo]; fills out (n,H,W,3) with the restored
-        frames, `batch` windows per forward (the tail batch is padded with repeats of the last window)."""
-        n, b, t = out.shape[0], self.batch, self.t
-        offs = torch.arange(t, device=padded.device)
+        frames, `batch` windows per forward (the windows of a ragged tail batch past the clip end are discarded).
+        A host-resident (pinned) clip is streamed: see _run_clip_pipelined."""
+        n, b = out.shape[0], self.batch
+        if padded.device.type == "cpu" and self.dev.type == "cuda":
+            return self._run_clip_pipelined(padded, out)
         for j in range(0, n, b):
-            idx = torch.arange(j, j + b, device=padded.device).clamp_(max=n - 1)
-            wins = padded[(idx[:, None] + offs[None, :]).reshape(-1)]        # (b*3,H,W,3) gather of u8 frames
-            res = self.run(wins)
             k = min(b, n - j)
-            out[j:j + k].copy_(res.reshape(b, *res.shape[-3:])[:k])
+            self._fill_static(padded, j, self.static_in)
+            out[j:j + k].copy_(self._launch()[:k])
         return out
+
+    def _run_clip_pipelined(self, padded_host, out_host):
+        """Host-resident (pinned) clip: uint8 frames cross PCIe in batch-sized chunks on a copy stream, double-buffered
+        on both sides, overlapped with the forward of the previous / next batch (the reference syncs every frame:
+        .cuda() ... .cpu(), inference.py:13-17)."""
+        n, b = out_host.shape[0], self.batch
+        dev = self.dev
+        if self._pipe is None:
+            self._pipe = {"cs": torch.cuda.Stream(device=dev),
+                          "in": [torch.empty_like(self.static_in) for _ in range(2)],
+                          "out": [torch.empty_like(self.static_out) for _ in range(2)]}
+        cs, stin, stout = self._pipe["cs"], self._pipe["in"], self._pipe["out"]
+        ms = torch.cuda.current_stream(dev)
+        ev_in = [torch.cuda.Event() for _ in range(2)]        # H2D of a batch landed in stin[i]
+        ev_used = [torch.cuda.Event() for _ in range(2)]      # the compute stream consumed stin[i]
+        ev_out = [torch.cuda.Event() for _ in range(2)]       # results of a batch are in stout[i]
+        ev_sent = [torch.cuda.Event() for _ in range(2)]      # D2H of stout[i] finished
+        starts = list(range(0, n, b))
+
+        def h2d(i):
+            with torch.cuda.stream(cs):
+                if i >= 2:
+                    cs.wait_event(ev_used[i % 2])
+                self._fill_static(padded_host, starts[i], stin[i % 2])
+                ev_in[i % 2].record(cs)
+
+        cs.wait_stream(ms)
+        h2d(0)
+        for i, j in enumerate(starts):
+            if i + 1 < len(starts):
+                h2d(i + 1)
+            k = min(b, n - j)
+            ms.wait_event(ev_in[i % 2])
+            self.static_in.copy_(stin[i % 2], non_blocking=True)
+            ev_used[i % 2].record(ms)
+            res = self._launch()
+            if i >= 2:
+                ms.wait_event(ev_sent[i % 2])
+            stout[i % 2].copy_(res, non_blocking=True)
+            ev_out[i % 2].record(ms)
+            with torch.cuda.stream(cs):
+                cs.wait_event(ev_out[i % 2])
+                out_host[j:j + k].copy_(stout[i % 2][:k], non_blocking=True)
+                ev_sent[i % 2].record(cs)
+        ms.wait_stream(cs)
+        return out_host
 
 
 def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True):
@@ -89,7 +169,7 @@ def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True):
     local = frames_u8.to(runner.dev, non_blocking=True)
     n_local = local.shape[0]
     padded = parallel.padded_local_clip(local, rank, world, group)   # one all_gather of boundary frames
-    out = runner.run_clip(padded, torch.empty_like(local))
+    out = runner.run_clip(padded, torch.empty_like(local)) if n_local else torch.empty_like(local)
     if world > 1 and gather:
         n_total = torch.tensor([n_local], device=runner.dev)
         torch.distributed.all_reduce(n_total, group=group)
@@ -97,49 +177,132 @@ def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True):
     return out
 
 
+def restore_clip_host(runner, padded_host, out_host, rank=0, world=1, group=None):
+    """Streaming form for host-resident clips.  padded_host: pinned uint8 (n_local+2,H,W,3) whose rows 1..n_local hold this
+    rank's own frames (rows 0 and -1 are filled here with the halo frames: one all_gather of boundary frames on the
+    device, replicate padding at the clip ends); out_host: pinned uint8 (n_local,H,W,3).  H2D / forward / D2H are
+    pipelined per batch (WindowRunner._run_clip_pipelined)."""
+    n_local = padded_host.shape[0] - 2
+    dev = runner.dev
+    edge = torch.stack([padded_host[1], padded_host[n_local]]).to(dev, non_blocking=True)    # first / last own frame
+    prev_halo, next_halo = parallel.exchange_halo(edge, rank, world, group)
+    padded_host[0].copy_(prev_halo, non_blocking=True)
+    padded_host[n_local + 1].copy_(next_halo, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()     # the two halo frames are on the host before the pipeline reads them
+    return runner.run_clip(padded_host, out_host)
+
+
 # ---- frame I/O (raw rgb24 files, or ffmpeg pipes with the reference's arguments) -----------------
-def read_frames(path, width, height):
+def probe_video(path):
+    """(width, height, fps) of a video file through ffprobe (the reference probes with cv2.VideoCapture,
+    inference.py:148-152)."""
+    fp = shutil.which("ffprobe")
+    if fp is None:
+        raise RuntimeError("probing %s needs ffprobe on PATH" % path)
+    out = subprocess.run([fp, "-v", "error", "-select_streams", "v:0", "-show_entries", "stream=width,height,r_frame_rate",
+                          "-of", "csv=p=0", path], stdout=subprocess.PIPE, check=True).stdout.decode().strip()
+    w, h, rate = out.split(",")[:3]
+    num, _, den = rate.partition("/")
+    return int(w), int(h), float(num) / float(den or 1)
+
+
+def iter_frames(path, width, height, chunk=32):
+    """Yield uint8 (k,H,W,3) chunks of a clip without buffering it: raw .rgb files are memory-mapped, anything else is
+    decoded by an ffmpeg pipe with the reference's arguments (inference.py:23-27), W*H*3 bytes per frame."""
+    fbytes = width * height * 3
     if path.endswith(".rgb"):
-        raw = np.fromfile(path, np.uint8)
-        return raw.reshape(-1, height, width, 3)
+        size = os.path.getsize(path)
+        if size % fbytes:
+            raise ValueError(f"{path}: {size} bytes is not a whole number of {width}x{height} rgb24 frames")
+        raw = np.memmap(path, np.uint8, "r").reshape(-1, height, width, 3)
+        for i in range(0, raw.shape[0], chunk):
+            yield np.ascontiguousarray(raw[i:i + chunk])
+        return
     ff = shutil.which("ffmpeg")
     if ff is None:
         raise RuntimeError("decoding %s needs an ffmpeg binary on PATH (or pass a raw .rgb file)" % path)
+    pw, ph, _ = probe_video(path)
+    if (pw, ph) != (width, height):
+        raise ValueError(f"{path} is {pw}x{ph}; the model takes {width}x{height} frames (resize the clip first)")
     cmd = [ff, "-i", path, "-f", "image2pipe", "-pix_fmt", "rgb24", "-vcodec", "rawvideo", "-"]
-    raw = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
-    return np.frombuffer(raw, np.uint8).reshape(-1, height, width, 3)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, bufsize=fbytes * 4)
+    try:
+        while True:
+            buf = proc.stdout.read(fbytes * chunk)
+            if len(buf) < fbytes:
+                break
+            k = len(buf) // fbytes
+            yield np.frombuffer(buf[:k * fbytes], np.uint8).reshape(k, height, width, 3)
+    finally:
+        proc.stdout.close()
+        proc.wait()
+
+
+def read_frames(path, width, height):
+    chunks = list(iter_frames(path, width, height))
+    if not chunks:
+        return np.zeros((0, height, width, 3), np.uint8)
+    return np.concatenate(chunks, 0)
+
+
+class FrameWriter:
+    """Streaming sink: raw .rgb file or an ffmpeg encoder pipe with the reference's arguments (libx265, crf 18, hvc1;
+    inference.py:29-35)."""
+
+    def __init__(self, path, width, height, fps=30):
+        self.proc, self.f = None, None
+        if path.endswith(".rgb"):
+            self.f = open(path, "wb")
+            return
+        ff = shutil.which("ffmpeg")
+        if ff is None:
+            raise RuntimeError("encoding %s needs an ffmpeg binary on PATH (or write a raw .rgb file)" % path)
+        cmd = [ff, "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{width}x{height}", "-r", str(fps), "-i", "-", "-an",
+               "-vcodec", "libx265", "-crf", "18", "-tag:v", "hvc1", path]
+        self.proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        self.f = self.proc.stdin
+
+    def write(self, frames):
+        self.f.write(np.ascontiguousarray(frames).tobytes())
+
+    def close(self):
+        self.f.close()
+        if self.proc is not None and self.proc.wait() != 0:
+            raise RuntimeError("ffmpeg encoder failed")
 
 
 def write_frames(path, frames, fps=30):
     frames = np.ascontiguousarray(frames)
-    if path.endswith(".rgb"):
-        frames.tofile(path)
-        return
-    ff = shutil.which("ffmpeg")
-    if ff is None:
-        raise RuntimeError("encoding %s needs an ffmpeg binary on PATH (or write a raw .rgb file)" % path)
-    h, w = frames.shape[1:3]
-    cmd = [ff, "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{w}x{h}", "-r", str(fps), "-i", "-", "-an",
-           "-vcodec", "libx265", "-crf", "18", "-tag:v", "hvc1", path]
-    subprocess.run(cmd, input=frames.tobytes(), stderr=subprocess.DEVNULL, check=True)
+    wr = FrameWriter(path, frames.shape[2], frames.shape[1], fps)
+    wr.write(frames)
+    wr.close()
 
 
-def load_architecture(precision="bf16", weights=None, device="cuda", seed=0):
-    """Counterpart of inference.py:109-121.  `weights`: a .safetensors / .pth (`params_ema` | `params` |
-    flat state dict) checkpoint of the reference model; None -> deterministic synthetic weights."""
+def load_architecture(precision="bf16x3", weights=None, device="cuda", seed=0, synthetic=False):
+    """Counterpart of inference.py:109-121.  `weights`: a directory with config.json + model.safetensors (the layout of
+    `PGTFormer.from_pretrained`), a hub id, or a .safetensors / .pth (`params_ema` | `params` | flat state dict)
+    checkpoint of the reference model.  Deterministic synthetic weights only on explicit request (`synthetic=True`)."""
     from . import PGTFormer, default_config
     from .manifest import pgtformer_manifest
     from .weightgen import generate_state_dict
 
+    if weights is None:
+        if not synthetic:
+            raise ValueError("no checkpoint given: pass weights=<dir | hub id | .safetensors | .pth>, or synthetic=True for "
+                             "random-init weights (benchmarks / tests only - the output is not a restoration)")
+        cfg = default_config()
+        model = PGTFormer(**cfg)
+        model.load_state_dict(generate_state_dict(pgtformer_manifest(cfg), cfg, seed=seed), strict=True)
+        return model.prepare(device, precision)
+    if os.path.isdir(weights) or not os.path.splitext(weights)[1]:
+        return PGTFormer.from_pretrained(weights, device=device, precision=precision)
     cfg = default_config()
     model = PGTFormer(**cfg)
-    if weights is None:
-        sd = generate_state_dict(pgtformer_manifest(cfg), cfg, seed=seed)
-    elif weights.endswith(".safetensors"):
+    if weights.endswith(".safetensors"):
         from safetensors.torch import load_file
         sd = load_file(weights)
     else:
-        sd = torch.load(weights, map_location="cpu")
+        sd = torch.load(weights, map_location="cpu", weights_only=True)
         for key in ("params_ema", "params"):
             if isinstance(sd, dict) and key in sd:
                 sd = sd[key]
@@ -153,16 +316,39 @@ def main(argv=None):
     ap.add_argument("-i", "--input_video", default="assets/inputdemovideo.mp4")
     ap.add_argument("-o", "--output_video", default="exp/output_demo.mp4")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--fps", type=int, default=30)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "mixed", "fp32"])
-    ap.add_argument("--weights", default=None)
-    ap.add_argument("--batch", type=int, default=16, help="independent windows per forward (<= 20: 2 GiB tensor limit)")
+    ap.add_argument("--fps", type=float, default=None, help="output frame rate (default: probed from the input, else 30)")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "mixed", "fp32"])
+    ap.add_argument("--weights", default=None, help="checkpoint: directory (config.json + model.safetensors), hub id, "
+                                                    ".safetensors or .pth")
+    ap.add_argument("--synthetic", action="store_true", help="random-init weights (smoke tests only)")
+    ap.add_argument("--batch", type=int, default=16, help="sliding windows per forward")
     args = ap.parse_args(argv)
-    frames = read_frames(args.input_video, args.size, args.size)
-    model = load_architecture(args.precision, args.weights)
+    if args.weights is None and not args.synthetic:
+        ap.error("--weights is required (the reference downloads kepeng/pgtformer-base; no network here). "
+                 "Use --synthetic only to exercise the pipeline with random weights.")
+    fps = args.fps
+    if fps is None:
+        try:
+            fps = probe_video(args.input_video)[2] if not args.input_video.endswith(".rgb") else 30
+        except Exception:
+            fps = 30
+    model = load_architecture(args.precision, args.weights, synthetic=args.synthetic)
     runner = WindowRunner(model, 1.0, True, args.size, args.size, batch=args.batch)
-    out = restore_clip(runner, torch.from_numpy(np.ascontiguousarray(frames)))
-    write_frames(args.output_video, out.cpu().numpy(), args.fps)
+    # the clip is decoded in chunks into one pinned buffer, restored by the pipelined host path and written out
+    chunks = list(iter_frames(args.input_video, args.size, args.size))
+    n = sum(c.shape[0] for c in chunks)
+    padded = torch.empty((n + 2, args.size, args.size, 3), dtype=torch.uint8).pin_memory()
+    o = 1
+    for c in chunks:
+        padded[o:o + c.shape[0]].copy_(torch.from_numpy(c))
+        o += c.shape[0]
+    out = torch.empty((n, args.size, args.size, 3), dtype=torch.uint8).pin_memory()
+    restore_clip_host(runner, padded, out)
+    torch.cuda.synchronize()
+    os.makedirs(os.path.dirname(os.path.abspath(args.output_video)), exist_ok=True)
+    wr = FrameWriter(args.output_video, args.size, args.size, fps)
+    wr.write(out.numpy())
+    wr.close()
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ import os
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpgt_hip.so")
 
-PGT_F32, PGT_BF16 = 0, 1
+PGT_F32, PGT_BF16, PGT_BF16X3 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_LEAKY02, ACT_SIGMOID = range(6)
 EPI_PLAIN, EPI_SFT = 0, 1
 
@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
                                    "pad_l", "Ho", "Wo", "Cout", "ldy", "act", "post_relu", "ldr", "epi",
                                    "ld_dec", "ld_shift")] + [("sft_w", f32)] + \
                [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue", "kernel", "splitk", "stages",
-                                   "orow_mul", "orow_xmul", "orow_off")]
+                                   "orow_mul", "orow_xmul", "orow_off", "x_lo", "y_lo", "r_lo")]
 
 
 # name -> argtypes (restype is int32 unless listed in _RESTYPES); must cover every symbol of pgt_hip.h
@@ -40,6 +40,13 @@ SIGNATURES = {
     "pgt_adain_affine": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
     "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pgt_mha": [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
+    "pgt_groupnorm_affine_x3": [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp],
+    "pgt_affine_act_x3": [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp],
+    "pgt_layernorm_x3": [vp, i32, i32, i32, i32, vp, vp, f32, vp, i32, i32, vp, i32, i32, vp, i32, i32, vp],
+    "pgt_window_attention_x3": [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "pgt_mha_x3": [vp, i32, i32, vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp],
+    "pgt_x3_split": [vp, i32, vp, i32, i32, i64, i32, vp],
+    "pgt_x3_merge": [vp, i32, i32, vp, i32, i64, i32, vp],
     "pgt_argmax_rows": [vp, i32, i32, i32, vp, vp],
     "pgt_rq_argmin": [vp, i32, vp, vp, i32, i32, vp, vp],
     "pgt_embed_rows": [i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp],
@@ -48,6 +55,7 @@ SIGNATURES = {
     "pgt_gate_add": [i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, vp],
     "pgt_resize_bilinear_ac": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
     "pgt_copy2d": [i32, vp, i32, i32, vp, i32, i64, i32, vp],
+    "pgt_gather_frames": [vp, i64, vp, i64, vp, i32, i64, i32, vp],
     "pgt_prep_input": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
     "pgt_nhwc_to_nchw_f32": [i32, vp, i32, i32, i32, i32, i32, vp, vp],
     "pgt_frame_to_u8": [i32, vp, i32, i32, i32, vp, vp],

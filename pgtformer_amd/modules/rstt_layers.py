@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import ACT_GELU, ACT_NONE, ACT_SILU
+from ..ops import ACT_GELU, ACT_NONE, ACT_SILU, X3
 
 
 class HipModule(nn.Module):
@@ -36,6 +36,18 @@ def prepare_tree(m, device, dtype):
         m._pack(device, dtype)
     for child in m.children():
         prepare_tree(child, device, dtype)
+
+
+def _is_x3(dtype):
+    return isinstance(dtype, str) and dtype == X3
+
+
+def _pack_matrix(w2d, taps, device, dtype):
+    """fp32 (Cout, taps*Cin) K-major weight -> kernel operand: a cast, or for split-bf16 modules the
+    [w_hi | w_hi | w_lo]-per-tap form (ops.pack_x3_weight)."""
+    if _is_x3(dtype):
+        return ops.pack_x3_weight(w2d.reshape(w2d.shape[0], taps, -1)).to(device)
+    return w2d.contiguous().to(device=device, dtype=dtype)
 
 
 def _f32(t, device):
@@ -65,21 +77,21 @@ class Conv2d(nn.Conv2d, HipModule):
         cout, cin, kh, kw = w.shape
         if self.cin_pad is not None and self.cin_pad > cin:
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, self.cin_pad - cin))
-        self.pw = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(device=device, dtype=dtype)
+        self.pw = _pack_matrix(w.permute(0, 2, 3, 1).reshape(cout, -1), kh * kw, device, dtype)
         self.pb = _f32(b, device)
 
     def run(self, x, **kw):
         return ops.conv2d(x, self.pw, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
-                          stride=self.stride[0], pad=self.pad4, **kw)
+                          stride=self.stride[0], pad=self.pad4, x3=_is_x3(self.dt), **kw)
 
 
 class Linear(nn.Linear, HipModule):
     def _pack(self, device, dtype):
-        self.pw = self.weight.detach().to(device=device, dtype=dtype).contiguous()
+        self.pw = _pack_matrix(self.weight.detach().float(), 1, device, dtype)
         self.pb = _f32(self.bias, device)
 
     def run(self, x, **kw):
-        return ops.linear(x, self.pw, self.pb, **kw)
+        return ops.linear(x, self.pw, self.pb, x3=_is_x3(self.dt), **kw)
 
 
 class GroupNorm(nn.GroupNorm, HipModule):
@@ -87,7 +99,7 @@ class GroupNorm(nn.GroupNorm, HipModule):
         self.pg, self.pbeta = _f32(self.weight, device), _f32(self.bias, device)
 
     def run(self, x, act=ACT_SILU, out=None):
-        return ops.groupnorm_act(x, self.pg, self.pbeta, act, self.num_groups, self.eps, out=out)
+        return ops.groupnorm_act(x, self.pg, self.pbeta, act, self.num_groups, self.eps, out=out, x3=_is_x3(self.dt))
 
 
 class LayerNorm(nn.LayerNorm, HipModule):
@@ -95,7 +107,7 @@ class LayerNorm(nn.LayerNorm, HipModule):
         self.pg, self.pbeta = _f32(self.weight, device), _f32(self.bias, device)
 
     def run(self, x, pos=None):
-        return ops.layernorm(x, self.pg, self.pbeta, self.eps, pos)
+        return ops.layernorm(x, self.pg, self.pbeta, self.eps, pos, x3=_is_x3(self.dt))
 
 
 def Normalize(in_channels):
@@ -166,7 +178,7 @@ class WindowAttention3D(HipModule):
 
     def _pack(self, device, dtype):
         # one fused (3C,C) projection [q | k | v]; dense per-head bias gathered once from the table
-        self.w_qkv = torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0).to(device=device, dtype=dtype).contiguous()
+        self.w_qkv = _pack_matrix(torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0).float(), 1, device, dtype)
         if self.q.bias is not None:
             self.b_qkv = _f32(torch.cat([self.q.bias.detach(), self.kv.bias.detach()], 0), device)
         else:
@@ -193,9 +205,10 @@ class VSTSREncoderTransformerBlock(HipModule):
         """xt: (B*D*H*W, C) tokens in (b,d,y,x) order; out: optional (rows, C) view receiving the result."""
         C = self.dim
         win, shift = get_window_size((H, W), self.window_size, self.shift_size)
+        x3 = _is_x3(self.dt)
         ln = self.norm1.run(xt)
-        qkv = ops.linear(ln, self.attn.w_qkv, self.attn.b_qkv)
-        ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift)
+        qkv = ops.linear(ln, self.attn.w_qkv, self.attn.b_qkv, x3=x3)
+        ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift, x3=x3)
         x1 = self.attn.proj.run(ao, res=xt)
         m = self.mlp.fc1.run(self.norm2.run(x1), act=ACT_GELU)
         return self.mlp.fc2.run(m, res=x1, out=out)

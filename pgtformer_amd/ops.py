@@ -11,7 +11,48 @@ import torch
 
 from . import hip
 from .hip import (ACT_GELU, ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU,  # noqa: F401
-                  EPI_PLAIN, EPI_SFT, PGT_BF16, PGT_F32)
+                  EPI_PLAIN, EPI_SFT, PGT_BF16, PGT_BF16X3, PGT_F32)
+
+# "dtype" tag of split-bf16 modules / tensors (include/pgt_hip.h: PGT_BF16X3).  A split tensor with C logical channels
+# is a torch.bfloat16 tensor whose last dim is 2C: [hi (C) | lo (C)], value = hi + lo.  The ops below take `x3=True` for
+# such operands; reshapes over the leading dims work unchanged, the hi plane `t[..., :C]` is a valid bf16 view of the
+# rounded tensor.
+X3 = "bf16x3"
+
+
+def pack_x3_weight(w3):
+    """w3: fp32 (Cout, taps, Cin) -> bf16 (Cout, taps*3*Cin) with [w_hi | w_hi | w_lo] per tap: the B operand matching the
+    kernels' K order [x_hi | x_lo | x_hi] (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo)."""
+    w3 = w3.float()
+    hi = w3.to(torch.bfloat16)
+    lo = (w3 - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, hi, lo], 2).reshape(w3.shape[0], -1).contiguous()
+
+
+def to_x3(x, out=None):
+    """fp32 (..., C) -> split-bf16 (..., 2C)."""
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    c = x.shape[-1]
+    x2 = x.reshape(-1, c) if x.is_contiguous() else None
+    if x2 is None:
+        assert x.dim() == 4
+        rows, lds = x.shape[0] * x.shape[1] * x.shape[2], _ld_img(x)
+    else:
+        rows, lds = x2.shape[0], c
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (2 * c,), device=x.device, dtype=torch.bfloat16)
+    assert out.is_contiguous() and out.shape[-1] == 2 * c
+    hip.check(hip.lib().pgt_x3_split(_p(x), lds, _p(out), 2 * c, c, rows, c, _stream()), "pgt_x3_split")
+    return out
+
+
+def from_x3(x):
+    """split-bf16 (..., 2C) -> fp32 (..., C)."""
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 2 == 0
+    c = x.shape[-1] // 2
+    out = torch.empty(tuple(x.shape[:-1]) + (c,), device=x.device, dtype=torch.float32)
+    hip.check(hip.lib().pgt_x3_merge(_p(x), 2 * c, c, _p(out), c, x.numel() // (2 * c), c, _stream()), "pgt_x3_merge")
+    return out
 
 
 # When set to a list, conv2d brackets each launch with events on the launch stream and appends
@@ -30,6 +71,10 @@ def _dt(t):
 def _dev(t):
     if not t.is_cuda:
         raise hip.PgtError("pgtformer_amd ops run on the GPU only (tensor is on %s); no CPU fallback" % t.device)
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the current device's stream: a tensor of another device would be a foreign pointer there
+        raise hip.PgtError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "call torch.cuda.set_device(model.dev) (one process per GPU)")
     return t
 
 
@@ -37,8 +82,11 @@ def _p(t):
     return None if t is None else C.c_void_p(_dev(t).data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t=None):
+    """HIP stream the launch goes to: the current stream of the tensor's device (ops assert elsewhere that the tensors of
+    one call live on one device); without a tensor, of the current device."""
+    dev = None if t is None else t.device
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _ld_img(x):
@@ -77,18 +125,33 @@ def enable_autotune(flag=True):
     AUTOTUNE = ({} if AUTOTUNE is None else AUTOTUNE) if flag else None
 
 
+def _tune_tag():
+    """library version + device architecture a tuned table is valid for (kernel variants / legality change with both)."""
+    arch = ""
+    if torch.cuda.is_available():
+        arch = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")
+    return {"pgt_version": hip.lib().pgt_version().decode(), "arch": arch}
+
+
 def save_autotune(path):
     """Write the tuned (signature -> kernel variant) table as JSON (reload with load_autotune to skip re-tuning)."""
     import json
+    rows = [[list(k[:9]) + [list(k[9])] + list(k[10:]), [v[0], list(v[1]), v[2]]] for k, v in (AUTOTUNE or {}).items()]
     with open(path, "w") as f:
-        json.dump([[list(k[:9]) + [list(k[9])] + list(k[10:]), [v[0], list(v[1]), v[2]]] for k, v in (AUTOTUNE or {}).items()], f)
+        json.dump({"tag": _tune_tag(), "table": rows}, f)
 
 
 def load_autotune(path):
+    """Load a saved table; returns False (and leaves tuning to start afresh) when the file was written by another library
+    version or for another GPU architecture."""
     import json
+    blob = json.load(open(path))
+    if not isinstance(blob, dict) or blob.get("tag") != _tune_tag():
+        return False
     enable_autotune()
-    for k, v in json.load(open(path)):
+    for k, v in blob["table"]:
         AUTOTUNE[tuple(k[:9]) + (tuple(k[9]),) + tuple(k[10:])] = (v[0], tuple(v[1]), v[2])
+    return True
 
 
 def _tune_conv(d, args, device, iters=4):
@@ -115,7 +178,7 @@ def _tune_conv(d, args, device, iters=4):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None):
+           out_parity=None, out_rows=None, x3=False):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout).
     out_parity=(py, px): write the (N,Ho,Wo,Cout) result to out[:, py::2, px::2, :] of a required (N,2Ho,2Wo,Cout) `out`
@@ -124,22 +187,28 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     (any (..., Cout) view; its pixel stride is the row pitch)."""
     n, h, wd, cin = x.shape
     cout = w.shape[0]
-    assert w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
+    if x3:   # split-bf16 operands: x (N,H,W,2*Cin) = [hi | lo], w (Cout, kh*kw*3*Cin), y (N,Ho,Wo,2*Cout) unless out_f32
+        assert x.dtype == torch.bfloat16 and cin % 2 == 0 and sft is None and not ups and out_rows is None and out_parity is None
+        cin //= 2
+        assert w.shape[1] == kh * kw * 3 * cin, (w.shape, kh, kw, cin)
+    else:
+        assert w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
     assert w.dtype == x.dtype and w.is_contiguous()
+    cst = cout if (out_f32 or not x3) else 2 * cout      # stored output channels
     if n > 1 and n * h * wd * _ld_img(x) * x.element_size() >= (1 << 31) and out_rows is None and out_parity is None:
         # the kernels take 32-bit byte offsets: run a >= 2 GiB input as frame chunks (frames are independent)
         hv0, wv0 = (h * 2, wd * 2) if ups else (h, wd)
         ho0 = (hv0 + pad[0] + pad[1] - kh) // stride + 1
         wo0 = (wv0 + pad[2] + pad[3] - kw) // stride + 1
         if out is None:
-            out = torch.empty((n, ho0, wo0, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+            out = torch.empty((n, ho0, wo0, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
         per = max(1, ((1 << 31) - 1) // (h * wd * _ld_img(x) * x.element_size()))
         for i in range(0, n, per):
             sl = slice(i, min(n, i + per))
             conv2d(x[sl], w, bias, kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, act=act,
                    res=None if res is None else res[sl], post_relu=post_relu,
                    sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
-                   tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages)
+                   tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3)
         return out
     hv, wv = (h * 2, wd * 2) if ups else (h, wd)
     ho = (hv + pad[0] + pad[1] - kh) // stride + 1
@@ -151,10 +220,10 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         assert out is not None and out.shape[-1] == cout and res is None and sft is None
     else:
         if out is None:
-            out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
-        assert tuple(out.shape) == (n, ho, wo, cout), (out.shape, (n, ho, wo, cout))
+            out = torch.empty((n, ho, wo, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+        assert tuple(out.shape) == (n, ho, wo, cst), (out.shape, (n, ho, wo, cst))
     d = hip.ConvDesc()
-    d.dtype = _dt(x)
+    d.dtype = PGT_BF16X3 if x3 else _dt(x)
     d.N, d.H, d.W, d.Cin, d.ldx, d.ups = n, h, wd, cin, _ld_img(x), int(ups)
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l = kh, kw, stride, pad[0], pad[2]
     d.Ho, d.Wo, d.Cout, d.ldy = ho, wo, cout, _ld_img(out)
@@ -174,19 +243,22 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         d.epi, d.ld_dec, d.ld_shift, d.sft_w = EPI_SFT, _ld_img(dec), _ld_img(shift), float(sw)
         assert dec.dtype == x.dtype and shift.dtype == x.dtype
     if res is not None:
-        assert res.dtype == x.dtype and tuple(res.shape) == tuple(out.shape)
+        assert res.dtype == x.dtype and tuple(res.shape[:-1]) == tuple(out.shape[:-1]) and res.shape[-1] == (2 * cout if x3 else cout)
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     L = hip.lib()
     if (AUTOTUNE is not None and kernel == 0 and tile == (0, 0) and splitk == 0 and not scalar_epi
-            and x.dtype == torch.bfloat16):
+            and x.dtype == torch.bfloat16 and not x3):
         key = (n, h, wd, cin, d.ldx, d.ups, kh, kw, stride, tuple(pad), cout, d.ldy, act, d.post_relu, d.ldr, d.epi,
                d.ld_dec, d.ld_shift, d.out_f32, bias is None, d.orow_mul, d.orow_xmul, d.orow_off)
         cfg = AUTOTUNE.get(key)
         if cfg is None and not torch.cuda.is_current_stream_capturing():
-            cfg = AUTOTUNE[key] = _tune_conv(d, (_p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out)), x.device)
+            if L.pgt_conv2d_workspace_bytes(C.byref(d)):
+                cfg = AUTOTUNE[key] = (0, (0, 0), 0)   # split-K layer: every candidate would time the same split-K path
+            else:
+                cfg = AUTOTUNE[key] = _tune_conv(d, (_p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out)), x.device)
         d.kernel, (d.force_bm, d.force_bn), d.stages = cfg if cfg is not None else (0, (0, 0), 0)
     ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None   # split-K scratch
@@ -197,29 +269,39 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         m = n * ho * wo
         es = x.element_size()
         prof.append({"kernel": "igemm", "flops": 2.0 * m * cout * kh * kw * cin,
-                     "bytes": float(n * h * wd * cin * es + m * cout * out.element_size() + w.numel() * es
-                                    + (m * cout * es if res is not None else 0)),
+                     "bytes": float(n * h * wd * x.shape[-1] * es + m * out.shape[-1] * out.element_size() + w.numel() * es
+                                    + (m * res.shape[-1] * es if res is not None else 0)),
                      "shape": (n, h, wd, cin, cout, kh, stride, int(ups)), "events": (e0, e1),
-                     "cfg": (d.kernel, d.force_bm, d.force_bn)})
+                     "cfg": (d.kernel, d.force_bm, d.force_bn), "x3": bool(x3)})
     return out
 
 
-def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False):
-    """x: (rows, Cin) -> (rows, Cout)."""
+def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False):
+    """x: (rows, Cin) -> (rows, Cout); x3: split-bf16 rows (rows, 2*Cin) -> (rows, 2*Cout) (or fp32 (rows, Cout))."""
     rows, cin = x.shape
     x4 = x.as_strided((1, 1, rows, cin), (0, 0, _ld_rows(x), 1))
+    cst = w.shape[0] * (2 if x3 and not out_f32 else 1)
     if out is None:
-        out = torch.empty((rows, w.shape[0]), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
-    o4 = out.as_strided((1, 1, rows, w.shape[0]), (0, 0, _ld_rows(out), 1))
-    r4 = None if res is None else res.as_strided((1, 1, rows, w.shape[0]), (0, 0, _ld_rows(res), 1))
-    conv2d(x4, w, bias, act=act, res=r4, out=o4, out_f32=out_f32)
+        out = torch.empty((rows, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    o4 = out.as_strided((1, 1, rows, cst), (0, 0, _ld_rows(out), 1))
+    r4 = None if res is None else res.as_strided((1, 1, rows, cst), (0, 0, _ld_rows(res), 1))
+    conv2d(x4, w, bias, act=act, res=r4, out=o4, out_f32=out_f32, x3=x3)
     return out
 
 
-def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6):
+def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6, x3=False):
     """GroupNorm statistics of x (N,H,W,C) folded with gamma/beta -> (scale, shift) fp32 (N,C)."""
     n, h, w, c = x.shape
     L = hip.lib()
+    if x3:
+        c //= 2
+        nbytes = L.pgt_groupnorm_workspace_bytes(n, h * w, c, groups)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        shift = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        hip.check(L.pgt_groupnorm_affine_x3(_p(x), _ld_img(x), c, n, h * w, c, groups, eps, _p(gamma), _p(beta),
+                                            _p(scale), _p(shift), _p(ws), nbytes, _stream()), "pgt_groupnorm_affine_x3")
+        return scale, shift
     nbytes = L.pgt_groupnorm_workspace_bytes(n, h * w, c, groups)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
@@ -229,24 +311,36 @@ def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6):
     return scale, shift
 
 
-def affine_act(x, scale, shift, act=ACT_NONE, out=None):
+def affine_act(x, scale, shift, act=ACT_NONE, out=None, x3=False):
     """y = act(x*scale[n,c] + shift[n,c]); x (N,H,W,C)."""
     n, h, w, c = x.shape
     if out is None:
         out = torch.empty((n, h, w, c), device=x.device, dtype=x.dtype)
+    if x3:
+        hip.check(hip.lib().pgt_affine_act_x3(_p(x), _ld_img(x), c // 2, _p(out), _ld_img(out), c // 2, n, h * w, c // 2,
+                                              _p(scale), _p(shift), act, _stream()), "pgt_affine_act_x3")
+        return out
     hip.check(hip.lib().pgt_affine_act(_dt(x), _p(x), _ld_img(x), _p(out), _ld_img(out), n, h * w, c, _p(scale),
                                        _p(shift), act, _stream()), "pgt_affine_act")
     return out
 
 
-def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6, out=None):
-    scale, shift = groupnorm_affine(x, gamma, beta, groups, eps)
-    return affine_act(x, scale, shift, act, out=out)
+def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6, out=None, x3=False):
+    scale, shift = groupnorm_affine(x, gamma, beta, groups, eps, x3=x3)
+    return affine_act(x, scale, shift, act, out=out, x3=x3)
 
 
-def layernorm(x, gamma, beta, eps=1e-5, pos=None):
+def layernorm(x, gamma, beta, eps=1e-5, pos=None, x3=False):
     """x (rows,C). Returns LN(x), or (LN(x), LN(x)+pos) when pos is given."""
     rows, c = x.shape
+    if x3:
+        c //= 2
+        y = torch.empty((rows, 2 * c), device=x.device, dtype=x.dtype)
+        y2 = torch.empty((rows, 2 * c), device=x.device, dtype=x.dtype) if pos is not None else None
+        hip.check(hip.lib().pgt_layernorm_x3(_p(x), _ld_rows(x), c, rows, c, _p(gamma), _p(beta), eps, _p(y), 2 * c, c,
+                                             _p(pos), _ld_rows(pos) if pos is not None else 0, c, _p(y2), 2 * c, c,
+                                             _stream()), "pgt_layernorm_x3")
+        return y if pos is None else (y, y2)
     y = torch.empty((rows, c), device=x.device, dtype=x.dtype)
     y2 = torch.empty((rows, c), device=x.device, dtype=x.dtype) if pos is not None else None
     hip.check(hip.lib().pgt_layernorm(_dt(x), _p(x), _ld_rows(x), rows, c, _p(gamma), _p(beta), eps, _p(y), c,
@@ -273,9 +367,16 @@ def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):
     return scale, shift
 
 
-def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift):
-    """qkv (B*T*H*W, 3C) -> (B*T*H*W, C)."""
+def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
+    """qkv (B*T*H*W, 3C) -> (B*T*H*W, C); x3: split-bf16 rows (.., 6C) = [hi q k v | lo q k v] -> (.., 2C)."""
     rows = B * T * H * W
+    if x3:
+        assert tuple(qkv.shape) == (rows, 6 * C_) and qkv.dtype == torch.bfloat16
+        out = torch.empty((rows, 2 * C_), device=qkv.device, dtype=qkv.dtype)
+        hip.check(hip.lib().pgt_window_attention_x3(_p(qkv), _ld_rows(qkv), 3 * C_, _p(out), 2 * C_, C_, _p(bias), B, T, H,
+                                                    W, C_, heads, win[0], win[1], shift[0], shift[1], _stream()),
+                  "pgt_window_attention_x3")
+        return out
     assert tuple(qkv.shape) == (rows, 3 * C_)
     out = torch.empty((rows, C_), device=qkv.device, dtype=qkv.dtype)
     hip.check(hip.lib().pgt_window_attention(_dt(qkv), _p(qkv), _ld_rows(qkv), _p(out), C_, _p(bias), B, T, H, W,
@@ -284,8 +385,15 @@ def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift):
     return out
 
 
-def mha(q, k, v, B, L, heads, hd, scale):
-    """q,k,v (B*L, heads*hd) views -> (B*L, heads*hd)."""
+def mha(q, k, v, B, L, heads, hd, scale, x3=None):
+    """q,k,v (B*L, heads*hd) views -> (B*L, heads*hd).  x3=(q_lo, k_lo, v_lo): q, k, v are the hi planes of split-bf16
+    rows whose lo planes start that many elements further; returns split rows (B*L, 2*heads*hd)."""
+    if x3 is not None:
+        e = heads * hd
+        out = torch.empty((B * L, 2 * e), device=q.device, dtype=q.dtype)
+        hip.check(hip.lib().pgt_mha_x3(_p(q), _ld_rows(q), x3[0], _p(k), _ld_rows(k), x3[1], _p(v), _ld_rows(v), x3[2],
+                                       _p(out), 2 * e, e, B, L, heads, hd, scale, _stream()), "pgt_mha_x3")
+        return out
     out = torch.empty((B * L, heads * hd), device=q.device, dtype=q.dtype)
     hip.check(hip.lib().pgt_mha(_dt(q), _p(q), _ld_rows(q), _p(k), _ld_rows(k), _p(v), _ld_rows(v), _p(out),
                                 heads * hd, B, L, heads, hd, scale, _stream()), "pgt_mha")
@@ -372,6 +480,30 @@ def cast(x, dtype):
         return x
     out = torch.empty(x.shape, device=x.device, dtype=dtype)
     return copy_into(x, out)
+
+
+def gather_frames(src, idx, out=None):
+    """out[i] = src[idx[i]] over the leading (frame) axis.  src: (F, ..., C) with a contiguous last dim and densely packed
+    leading dims over its row stride (a channel slice of a wider buffer is fine); idx: int32 device tensor (n,).
+    Returns (n, ..., C)."""
+    assert idx.dtype == torch.int32 and idx.is_contiguous()
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), device=src.device, dtype=src.dtype)
+    assert tuple(out.shape[1:]) == tuple(src.shape[1:]) and out.shape[0] == n and out.dtype == src.dtype
+    es = src.element_size()
+    if src.is_contiguous() and out.is_contiguous():
+        rows, row_bytes = 1, src[0].numel() * es      # whole frames (e.g. uint8 (F,H,W,3) clips)
+        while row_bytes >= (1 << 30):                 # keep the 32-bit row size: split a frame into equal rows
+            rows, row_bytes = rows * 2, row_bytes // 2
+        lds = ldd = row_bytes
+    else:
+        assert src.dim() == 4
+        rows, row_bytes = src.shape[1] * src.shape[2], src.shape[3] * es
+        lds, ldd = _ld_img(src) * es, _ld_img(out) * es
+    hip.check(hip.lib().pgt_gather_frames(_p(src), lds, _p(out), ldd, _p(idx), n, rows, row_bytes, _stream()),
+              "pgt_gather_frames")
+    return out
 
 
 def prep_input(src, dtype, want_raw=True, want_norm=True):

@@ -26,18 +26,36 @@ def needed_inputs(n_frames, rank, world):
 
 
 def exchange_halo(local_frames, rank, world, group=None):
-    """local_frames: (n_local, H, W, 3) uint8 — the frames of this rank's own output range only
-    (n_local >= 1 on every rank).  Returns (prev_halo, next_halo): the last frame of the previous rank
-    and the first frame of the next rank, replicate-padded at the clip ends (the reference driver's
-    first/last-frame duplication).  One all_gather of a (2,H,W,3) tensor per rank."""
-    assert local_frames.dim() == 4 and local_frames.shape[0] >= 1
-    mine = torch.stack([local_frames[0], local_frames[-1]])
+    """local_frames: (n_local, H, W, 3) uint8 - the frames of this rank's own output range only (n_local may be 0 when
+    the clip has fewer frames than ranks: such ranks still take part in the collective).  Returns (prev_halo, next_halo):
+    the last frame of the nearest non-empty previous rank and the first frame of the nearest non-empty next rank,
+    replicate-padded at the clip ends (the reference driver's first/last-frame duplication, inference.py:38-74);
+    (None, None) on an empty rank.  ONE all_gather per rank: [first frame | last frame | n_local as 8 bytes]."""
+    assert local_frames.dim() == 4 and local_frames.dtype == torch.uint8
+    n_local = local_frames.shape[0]
     if world == 1:
-        return local_frames[0], local_frames[-1]
+        return (local_frames[0], local_frames[-1]) if n_local else (None, None)
+    shape = tuple(local_frames.shape[1:])
+    fbytes = shape[0] * shape[1] * shape[2]
+    mine = torch.zeros(2 * fbytes + 8, dtype=torch.uint8, device=local_frames.device)
+    if n_local:
+        mine[:fbytes] = local_frames[0].reshape(-1)
+        mine[fbytes:2 * fbytes] = local_frames[-1].reshape(-1)
+    mine[2 * fbytes:] = torch.tensor([n_local], dtype=torch.int64).view(torch.uint8).to(local_frames.device)
     gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine.contiguous(), group=group)
-    prev_halo = gathered[rank - 1][1] if rank > 0 else local_frames[0]
-    next_halo = gathered[rank + 1][0] if rank < world - 1 else local_frames[-1]
+    dist.all_gather(gathered, mine, group=group)
+    if n_local == 0:
+        return None, None
+    counts = torch.stack([g[2 * fbytes:] for g in gathered]).cpu().view(torch.int64).reshape(-1).tolist()
+    prev_halo, next_halo = local_frames[0], local_frames[-1]
+    for r in range(rank - 1, -1, -1):
+        if counts[r]:
+            prev_halo = gathered[r][fbytes:2 * fbytes].reshape(shape)
+            break
+    for r in range(rank + 1, world):
+        if counts[r]:
+            next_halo = gathered[r][:fbytes].reshape(shape)
+            break
     return prev_halo, next_halo
 
 
@@ -45,6 +63,8 @@ def padded_local_clip(local_frames, rank, world, group=None):
     """(n_local+2, H, W, 3): [prev halo, own frames..., next halo]; window for local output j is
     rows j, j+1, j+2."""
     prev_halo, next_halo = exchange_halo(local_frames, rank, world, group)
+    if prev_halo is None:
+        return local_frames      # empty rank: nothing to restore
     return torch.cat([prev_halo.unsqueeze(0), local_frames, next_halo.unsqueeze(0)], 0)
 
 

@@ -27,6 +27,51 @@ def _act(v, act):
     return v
 
 
+def _merge(x):
+    """split-bf16 (..., 2C) -> fp32 (..., C)"""
+    c = x.shape[-1] // 2
+    return x[..., :c].float() + x[..., c:].float()
+
+
+def _split(v):
+    """fp32 (..., C) -> split-bf16 (..., 2C): hi = bf16(v), lo = bf16(v - hi)"""
+    hi = v.to(torch.bfloat16)
+    lo = (v - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], -1).contiguous()
+
+
+def _store_x3(val, out):
+    s = _split(val)
+    if out is None:
+        return s
+    out.copy_(s)
+    return out
+
+
+def _unpack_x3_weight(w, taps):
+    """(Cout, taps*3*Cin) [w_hi | w_hi | w_lo] per tap -> fp32 (Cout, taps*Cin) = w_hi + w_lo"""
+    cout = w.shape[0]
+    w4 = w.float().reshape(cout, taps, 3, -1)
+    assert torch.equal(w4[:, :, 0], w4[:, :, 1])
+    return (w4[:, :, 0] + w4[:, :, 2]).reshape(cout, -1)
+
+
+def to_x3(x, out=None):
+    return _store_x3(x.float(), out)
+
+
+def from_x3(x):
+    return _merge(x).contiguous()
+
+
+def gather_frames(src, idx, out=None):
+    r = src[idx.long()]
+    if out is None:
+        return r.contiguous()
+    out.copy_(r)
+    return out
+
+
 def _store(val, out, dtype):
     if out is None:
         return val.to(dtype).contiguous()
@@ -36,9 +81,15 @@ def _store(val, out, dtype):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None):
+           out_parity=None, out_rows=None, x3=False):
     n, h, wd, cin = x.shape
     cout = w.shape[0]
+    if x3:
+        assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and sft is None and not ups
+        cin //= 2
+        x = _merge(x)
+        w = _unpack_x3_weight(w, kh * kw)
+        res = None if res is None else _merge(res)
     assert w.shape[1] == kh * kw * cin and w.dtype == x.dtype
     xi = x.float().permute(0, 3, 1, 2)
     if ups:
@@ -66,17 +117,26 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         flat = out.as_strided((int(rows.max()) + 1, cout), (out.stride(-2), 1))
         flat[rows] = y.reshape(-1, cout).to(out.dtype)
         return out
+    if x3 and not out_f32:
+        return _store_x3(y, out)
     return _store(y, out, torch.float32 if out_f32 else x.dtype)
 
 
-def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False):
+def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False):
+    if x3:
+        x, w = _merge(x), _unpack_x3_weight(w, 1)
+        res = None if res is None else _merge(res)
     y = _act(F.linear(x.float(), w.float(), bias.float() if bias is not None else None), act)
     if res is not None:
         y = y + res.float()
+    if x3 and not out_f32:
+        return _store_x3(y, out)
     return _store(y, out, torch.float32 if out_f32 else x.dtype)
 
 
-def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6):
+def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6, x3=False):
+    if x3:
+        x = _merge(x)
     n, h, w, c = x.shape
     xf = x.float().reshape(n, h * w, groups, c // groups)
     mean = xf.mean(dim=(1, 3))
@@ -89,18 +149,23 @@ def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6):
     return scale.contiguous(), shift.contiguous()
 
 
-def affine_act(x, scale, shift, act=ACT_NONE, out=None):
+def affine_act(x, scale, shift, act=ACT_NONE, out=None, x3=False):
     n = x.shape[0]
-    y = _act(x.float() * scale.reshape(n, 1, 1, -1) + shift.reshape(n, 1, 1, -1), act)
-    return _store(y, out, x.dtype)
+    xf = _merge(x) if x3 else x.float()
+    y = _act(xf * scale.reshape(n, 1, 1, -1) + shift.reshape(n, 1, 1, -1), act)
+    return _store_x3(y, out) if x3 else _store(y, out, x.dtype)
 
 
-def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6, out=None):
-    s, b = groupnorm_affine(x, gamma, beta, groups, eps)
-    return affine_act(x, s, b, act, out=out)
+def groupnorm_act(x, gamma, beta, act=ACT_SILU, groups=32, eps=1e-6, out=None, x3=False):
+    s, b = groupnorm_affine(x, gamma, beta, groups, eps, x3=x3)
+    return affine_act(x, s, b, act, out=out, x3=x3)
 
 
-def layernorm(x, gamma, beta, eps=1e-5, pos=None):
+def layernorm(x, gamma, beta, eps=1e-5, pos=None, x3=False):
+    if x3:
+        xf = _merge(x)
+        y = F.layer_norm(xf, (xf.shape[-1],), gamma, beta, eps)
+        return _split(y) if pos is None else (_split(y), _split(y + _merge(pos)))
     y = F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps)
     if pos is None:
         return y.to(x.dtype)
@@ -118,8 +183,10 @@ def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):
     return scale, mean_s - mean_c * scale
 
 
-def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift):
+def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
     """Independent formulation: roll / partition with torch ops, dense mask from region labels."""
+    if x3:
+        return _split(window_attention(_merge(qkv), bias, B, T, H, W, C_, heads, win, shift))
     wh, ww = win
     sh, sw = shift
     hd = C_ // heads
@@ -150,7 +217,15 @@ def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift):
     return o.reshape(B * T * H * W, C_).to(qkv.dtype)
 
 
-def mha(q, k, v, B, L, heads, hd, scale):
+def mha(q, k, v, B, L, heads, hd, scale, x3=None):
+    if x3 is not None:   # q, k, v are hi-plane views of split rows; the lo planes start x3[i] elements further
+        e = heads * hd
+
+        def full(t, lo):
+            base = t.as_strided((t.shape[0], lo + e), (t.stride(0), 1), t.storage_offset())
+            return base[:, :e].float() + base[:, lo:lo + e].float()
+        return _split(mha(full(q, x3[0]), full(k, x3[1]), full(v, x3[2]), B, L, heads, hd, scale))
+
     def split(t):
         return t.float().reshape(B, L, heads, hd).permute(0, 2, 1, 3)
     attn = ((split(q) * scale) @ split(k).transpose(-2, -1)).softmax(-1)
@@ -237,7 +312,7 @@ def frame_to_u8(x, out=None):
 ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "layernorm", "channel_stats",
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
-       "frame_to_u8"]
+       "frame_to_u8", "to_x3", "from_x3", "gather_frames"]
 
 
 def install(monkeypatch):

@@ -30,8 +30,8 @@ def test_header_symbols_are_exported_and_bound():
         assert getattr(lib, name) is not None
     lib.pgt_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.pgt_version()
-    # ConvDesc mirrors pgt_conv_desc: 22 int32 + float + 7 int32
-    assert ctypes.sizeof(hip.ConvDesc) == 33 * 4
+    # ConvDesc mirrors pgt_conv_desc: 22 int32 + float + 13 int32
+    assert ctypes.sizeof(hip.ConvDesc) == 36 * 4
     fields = re.search(r"typedef struct pgt_conv_desc \{(.*?)\} pgt_conv_desc;", hdr, re.S).group(1)
     names = [n.strip() for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", fields) for n in decl.split(",")]
     assert names == [f[0] for f in hip.ConvDesc._fields_]
@@ -74,6 +74,10 @@ out = (padded[1:-1].to(torch.int16) + 100).to(torch.uint8)
 full = parallel.gather_outputs(out, n, rank, world)
 if rank == 0:
     assert full[:, 0, 0, 0].tolist() == [100 + i for i in range(n)], full[:, 0, 0, 0].tolist()
+# a clip shorter than the world: rank 1 owns nothing but still takes part in the halo all_gather
+s1, e1 = parallel.frame_range(1, rank, world)
+p1 = parallel.padded_local_clip(clip[s1:e1], rank, world)
+assert (p1[:, 0, 0, 0].tolist() == [0, 0, 0]) if rank == 0 else (p1.shape[0] == 0)
 dist.barrier()
 dist.destroy_process_group()
 print("OK", rank)

@@ -9,19 +9,24 @@ from pgtformer_amd import driver, parallel
 
 
 class StubModel:
-    """restore_middle_u8(windows) -> for each window: middle frame + (first frame idx encoded) so order is checkable."""
+    """restore_middle_u8(frames, win=...) -> for each window: middle frame + 100, and the frame triples it saw (the frame
+    index is encoded in the pixel values) so that order and window policy are checkable."""
     t = 3
     dev = torch.device("cpu")
 
     def __init__(self):
         self.seen = []
 
-    def restore_middle_u8(self, win, w=1.0):
-        b = win.shape[0] // 3
-        self.seen += [tuple(int(win[i * 3 + k, 0, 0, 0]) for k in range(3)) for i in range(b)]
-        mid = win.reshape(b, 3, *win.shape[1:])[:, 1]
-        out = (mid.to(torch.int16) + 100).clamp(max=255).to(torch.uint8)
-        return out[0] if b == 1 else out
+    def restore_middle_u8(self, frames, w=1.0, win=None, out=None):
+        wins = frames if win is None else frames[win.long()]          # window order: (B*3, H, W, 3)
+        b = wins.shape[0] // 3
+        self.seen += [tuple(int(wins[i * 3 + k, 0, 0, 0]) for k in range(3)) for i in range(b)]
+        mid = wins.reshape(b, 3, *wins.shape[1:])[:, 1]
+        res = (mid.to(torch.int16) + 100).clamp(max=255).to(torch.uint8)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res[0] if b == 1 else res
 
 
 def _clip(n, h=8, w=6):
@@ -35,9 +40,10 @@ def test_rgb24_roundtrip_and_window_policy(tmp_path):
     clip.numpy().tofile(path)
     frames = driver.read_frames(str(path), 6, 8)
     assert frames.shape == (n, 8, 6, 3) and frames.dtype == np.uint8
-    for batch in (1, 4):                        # 119 = 29*4 + 3 -> ragged tail batch
+    for batch, overlap in ((1, True), (4, True), (4, False), (1, False)):   # 119 = 29*4 + 3 -> ragged tail batch
         model = StubModel()
-        runner = driver.WindowRunner(model, 1.0, use_graph=False, height=8, width=6, batch=batch)
+        runner = driver.WindowRunner(model, 1.0, use_graph=False, height=8, width=6, batch=batch, overlap=overlap)
+        assert runner.static_in.shape[0] == (batch + 2 if overlap else 3 * batch)
         out = driver.restore_clip(runner, torch.from_numpy(np.ascontiguousarray(frames)))
         assert out.shape == (n, 8, 6, 3)
         assert out[:, 0, 0, 0].tolist() == [i + 100 for i in range(n)]
@@ -55,6 +61,35 @@ def test_single_and_two_frame_clips():
         out = driver.restore_clip(runner, _clip(n))
         assert out[:, 0, 0, 0].tolist() == [i + 100 for i in range(n)]
         assert set(O.window_triples(n)) <= set(model.seen)
+
+
+def test_streaming_reader_and_writer(tmp_path):
+    """iter_frames yields the clip in chunks without buffering it; FrameWriter appends; a file that is not a whole number
+    of frames is rejected (the reference probes the geometry with cv2, inference.py:148-152)."""
+    import pytest
+    clip = _clip(10)
+    path = tmp_path / "in.rgb"
+    clip.numpy().tofile(path)
+    chunks = list(driver.iter_frames(str(path), 6, 8, chunk=4))
+    assert [c.shape[0] for c in chunks] == [4, 4, 2]
+    assert np.array_equal(np.concatenate(chunks, 0), clip.numpy())
+    wr = driver.FrameWriter(str(tmp_path / "o.rgb"), 6, 8)
+    for c in chunks:
+        wr.write(c)
+    wr.close()
+    assert np.array_equal(np.fromfile(tmp_path / "o.rgb", np.uint8), clip.numpy().reshape(-1))
+    with open(path, "ab") as f:
+        f.write(b"xx")
+    with pytest.raises(ValueError):
+        list(driver.iter_frames(str(path), 6, 8))
+
+
+def test_cli_refuses_to_run_without_weights(tmp_path):
+    import pytest
+    with pytest.raises(SystemExit):
+        driver.main(["-i", str(tmp_path / "x.rgb"), "-o", str(tmp_path / "y.rgb")])
+    with pytest.raises(ValueError):
+        driver.load_architecture(weights=None)
 
 
 def test_padded_clip_layout():

@@ -5,7 +5,11 @@ Metrics are also written to gpurun_out/parity_model.json.
 
 Tolerances:  f32 path: max|d| <= 1e-3*max|ref| per module, whole-model PSNR(build, reference) >= 80 dB on
 the clamped middle frame and 100 % code agreement except tokens whose reference top-2 logit margin is
-< 1e-3; bf16 / mixed paths: reported (PSNR, code agreement), with loose sanity floors.
+< 1e-3.  bf16x3 (the default / benchmarked mode: split-bf16 code branch, bf16 decoder): the SAME code criterion
+(every code equal to the reference's except where the reference's own top-2 margin is < 1e-3), logits within 2e-3,
+PSNR(build, reference) >= 35 dB on the clamped sub-sampled output and >= 34.5 dB on the 128x128 middle crop.
+mixed: as bf16x3.  Pure bf16 (opt-in speed mode): reported, plus a teacher-forced decoder check (reference codes fed
+in: PSNR >= 30 dB) and bit-equality of the in-place concat path with the copying path.
 """
 import json
 import os
@@ -50,7 +54,7 @@ def models(cfg, full_sd):
     from pgtformer_amd import PGTFormer
 
     out = {}
-    for prec in ("fp32", "bf16", "mixed"):
+    for prec in ("fp32", "bf16", "mixed", "bf16x3"):
         m = PGTFormer(**cfg)
         m.load_state_dict(full_sd, strict=True)
         out[prec] = m.prepare(DEV, prec)
@@ -151,26 +155,123 @@ def test_whole_model_f32_matches_reference(models, golden_window):
     assert (u8.int() - want.int()).abs().max() <= 1
 
 
-@pytest.mark.parametrize("prec", ["bf16", "mixed"])
-def test_whole_model_reduced_precision_report(models, golden_window, prec):
-    g = np.load(os.path.join(GOLD, "full_golden.npz"))
-    x, _, gt = golden_window
-    out, logits, lq, codes = _full(models, prec, x)
-    assert torch.isfinite(out).all()
+def _reduced_record(out, logits, lq, codes, g, gt):
     ref_crop = torch.from_numpy(g["out_mid_crop"])
     crop = out[1, :, 192:320, 192:320]
     f16 = torch.from_numpy(g["out_f16"].astype(np.float32))
     gt_t = torch.from_numpy(gt[:3]).permute(0, 3, 1, 2)[:, :, ::4, ::4]
-    rec = {"code_agreement": float((codes == g["codes"]).mean()),
-           "psnr_mid_crop_clamped_db": psnr(crop.clamp(0, 1), ref_crop.clamp(0, 1)),
-           "psnr_full_sub4_clamped_db": psnr(out[:, :, ::4, ::4].clamp(0, 1), f16.clamp(0, 1)),
-           "psnr_build_vs_gt_db": psnr(out[:, :, ::4, ::4].clamp(0, 1), gt_t),
-           "psnr_ref_vs_gt_db": psnr(f16.clamp(0, 1), gt_t),
-           "lq_feat_err": float(np.abs(lq[:, 12:20, 12:20, :].numpy() - g["lq_feat_crop"]).max())}
+    mism = codes != g["codes"]
+    margin = g["logit_margin"].reshape(codes.shape)
+    return {"code_agreement": float(1 - mism.mean()), "n_mismatch": int(mism.sum()),
+            "mismatch_margins": [float(v) for v in margin[mism][:16]],
+            "max_mismatch_margin": float(margin[mism].max()) if mism.any() else 0.0,
+            "logits_err": float(np.abs(logits[:, :2, :2].numpy() - g["logits_tok0"]).max()),
+            "psnr_mid_crop_clamped_db": psnr(crop.clamp(0, 1), ref_crop.clamp(0, 1)),
+            "psnr_full_sub4_clamped_db": psnr(out[:, :, ::4, ::4].clamp(0, 1), f16.clamp(0, 1)),
+            "psnr_build_vs_gt_db": psnr(out[:, :, ::4, ::4].clamp(0, 1), gt_t),
+            "psnr_ref_vs_gt_db": psnr(f16.clamp(0, 1), gt_t),
+            "lq_feat_err": float(np.abs(lq[:, 12:20, 12:20, :].numpy() - g["lq_feat_crop"]).max())}
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "mixed"])
+def test_whole_model_default_mode_matches_reference(models, golden_window, prec):
+    """The benchmarked mode reproduces the reference: every arg-max code (archs/pgtformer_arch.py:663) equals the fp32
+    reference's except where the reference's own top-2 logit margin is < 1e-3, logits / lq_feat to fp32-class error, and
+    the restored frames to >= 35 dB (bf16 decoder arithmetic on identical codes)."""
+    g = np.load(os.path.join(GOLD, "full_golden.npz"))
+    x, _, gt = golden_window
+    out, logits, lq, codes = _full(models, prec, x)
+    assert out.shape == (3, 3, 512, 512) and logits.shape == (3, 32, 32, 1, 1024) and lq.shape == (3, 32, 32, 512)
+    assert torch.isfinite(out).all()
+    rec = _reduced_record(out, logits, lq, codes, g, gt)
     _LOG[f"whole/{prec}"] = rec
-    assert rec["lq_feat_err"] < (0.5 if prec == "bf16" else 1e-3)
-    if prec == "mixed":
-        assert rec["code_agreement"] >= 0.999
+    assert rec["max_mismatch_margin"] < 1e-3, rec
+    assert rec["code_agreement"] >= 0.997, rec
+    assert rec["logits_err"] < 2e-3 and rec["lq_feat_err"] < 1e-3, rec
+    assert rec["psnr_full_sub4_clamped_db"] >= 35.0 and rec["psnr_mid_crop_clamped_db"] >= 34.5, rec
+    assert abs(rec["psnr_build_vs_gt_db"] - rec["psnr_ref_vs_gt_db"]) <= 1e-3, rec
+    out2, _, _, codes2 = _full(models, prec, x)                      # run-to-run determinism
+    assert torch.equal(out, out2) and np.array_equal(codes, codes2)
+
+
+def test_whole_model_pure_bf16_report(models, golden_window):
+    """Pure bf16 (opt-in speed mode) is reported, not a parity mode: with random-init weights ~2 % of the codes flip."""
+    g = np.load(os.path.join(GOLD, "full_golden.npz"))
+    x, _, gt = golden_window
+    out, logits, lq, codes = _full(models, "bf16", x)
+    assert torch.isfinite(out).all()
+    rec = _reduced_record(out, logits, lq, codes, g, gt)
+    _LOG["whole/bf16"] = rec
+    assert rec["lq_feat_err"] < 0.5 and rec["code_agreement"] > 0.9
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_teacher_forced_decoder_and_concat_paths(models, golden_window, prec):
+    """Decoder-side arithmetic separated from code flips: the reference's codes are fed in (forward_nhwc(codes=...)), so
+    quantiser gather -> AdaIN -> decoder -> SFT fusion (incl. the in-place [enc | dec | fut] concat writes of the bf16
+    decoder, archs/pgtformer_arch.py:460-484, :684-710) must reproduce the reference output; and the in-place concat path
+    must equal the copying path bit for bit (same kernels, same values, different destinations)."""
+    g = np.load(os.path.join(GOLD, "full_golden.npz"))
+    x, win_u8, _ = golden_window
+    m = models[prec]
+    codes = torch.from_numpy(g["codes"].astype(np.int64))
+    frames = torch.from_numpy(win_u8).to(DEV)
+    out_d, _, _ = m.forward_nhwc(frames, w=1.0, codes=codes)
+    out_c, _, _ = m.forward_nhwc(frames, w=1.0, codes=codes, direct=False)
+    torch.cuda.synchronize()
+    assert torch.equal(m.last_codes.cpu().reshape(-1), codes.reshape(-1).to(torch.int32))
+    same = torch.equal(out_d, out_c)
+    dmax = float((out_d.float() - out_c.float()).abs().max())
+    out = out_d.float().cpu().permute(0, 3, 1, 2)
+    ref_crop = torch.from_numpy(g["out_mid_crop"])
+    f16 = torch.from_numpy(g["out_f16"].astype(np.float32))
+    rec = {"direct_equals_copying_path": bool(same), "direct_vs_copy_max_abs": dmax,
+           "psnr_mid_crop_clamped_db": psnr(out[1, :, 192:320, 192:320].clamp(0, 1), ref_crop.clamp(0, 1)),
+           "psnr_full_sub4_clamped_db": psnr(out[:, :, ::4, ::4].clamp(0, 1), f16.clamp(0, 1))}
+    _LOG[f"teacher_forced/{prec}"] = rec
+    assert same, rec
+    floor = 35.0 if prec == "bf16x3" else 30.0
+    assert rec["psnr_full_sub4_clamped_db"] >= floor, rec
+
+
+def test_overlap_aware_windows_equal_stacked_windows(models):
+    """Per-frame work once per unique frame (forward_nhwc(win=...)) == the stacked-windows forward: bit-equal in fp32 and in
+    the default mode (the per-frame operators act on each frame independently; reference inference.py:47-74)."""
+    from pgtformer_amd.synth import make_clip
+
+    lq, _ = make_clip(4, 512, seed=5)
+    frames = torch.from_numpy(lq).to(DEV)
+    for prec in ("fp32", "bf16x3"):
+        m = models[prec]
+        win = m.window_index(2, 3, DEV)
+        a, la, _ = m.forward_nhwc(frames, w=1.0, win=win)
+        b, lb, _ = m.forward_nhwc(frames[win.long()].contiguous(), w=1.0)
+        torch.cuda.synchronize()
+        d_out, d_log = float((a.float() - b.float()).abs().max()), float((la - lb).abs().max())
+        _LOG[f"overlap_vs_stacked/{prec}"] = {"out_max_abs": d_out, "logits_max_abs": d_log}
+        assert d_log <= 1e-4 and d_out <= (2e-3 if prec == "fp32" else 0.1), (prec, d_out, d_log)
+
+
+def test_parsing_map_and_public_paths_match_host_oracle(models, cfg, full_sd, golden_window):
+    """BiSeNet parsing map (the `cond` tap) against the reference golden; forward(code_only=True); w=0 (no fusion) with
+    adain=False against the CPU oracle run with the same switches (reference: pgtformer_arch.py:651-653, :670, :699)."""
+    from oracle import pgt_oracle as O
+
+    g = np.load(os.path.join(GOLD, "full_golden.npz"))
+    x, _, _ = golden_window
+    m = models["fp32"]
+    logits, lq = m(x.to(DEV), code_only=True)
+    par = m.last_parsing.float().cpu()[..., :57].permute(0, 3, 1, 2)
+    cond_err = float((par - torch.from_numpy(g["cond_f16"].astype(np.float32))).abs().max())
+    assert cond_err <= 2e-3 * max(1.0, float(np.abs(g["cond_f16"]).max())), cond_err
+    assert float(np.abs(logits.cpu()[:, :2, :2].numpy() - g["logits_tok0"]).max()) < 5e-3
+    out, logits2, _ = m(x.to(DEV), w=0, adain=False)
+    o_out, o_logits, _ = O.pgtformer_forward(full_sd, cfg, x, w=0, adain_on=False)
+    rec = {"cond_max_abs_err": cond_err, "w0_noadain_out_err": float((out.cpu() - o_out).abs().max()),
+           "code_only_logits_equal": bool(torch.equal(logits, logits2))}
+    _LOG["public_paths/fp32"] = rec
+    assert rec["code_only_logits_equal"]
+    assert rec["w0_noadain_out_err"] < 2e-3 * max(1.0, float(o_out.abs().max())), rec
 
 
 def test_oracle_on_this_host_matches_build_f32(models, cfg, full_sd, golden_window):

@@ -1,0 +1,190 @@
+"""GPU parity tests of the split-bf16 ("bf16x3", include/pgt_hip.h: PGT_BF16X3) kernels, operator level, through the
+C-ABI: every x3 kernel against the fp32 torch-CPU emulation (tests/emu_ops.py) of the same operator on the same
+seeded inputs.
+
+Tolerance (written here, per the parity contract): a split operand carries 16 significand bits, products are
+hi*hi + lo*hi + hi*lo with fp32 accumulation, so results must agree with the fp32 emulation (which sees the same
+split inputs, exactly) to  max|got - want| <= 1e-4 * max(1, max|want|)  - 400x tighter than the bf16 tolerance (4e-2)
+and loose enough for accumulation-order differences; outputs are compared after merging hi + lo.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import emu_ops as E
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+_LOG = []
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_log():
+    yield
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_x3.json", "w") as f:
+        json.dump(_LOG, f, indent=1)
+
+
+def ops():
+    import pgtformer_amd.ops as O
+    return O
+
+
+def rnd(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((scale * g.standard_normal(shape)).astype(np.float32))
+
+
+def g(t):
+    return None if t is None else t.to(DEV)
+
+
+def check(name, got, want, tol=TOL):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    ref = max(1.0, want.abs().max().item())
+    _LOG.append({"name": name, "max_abs_err": err, "ref_absmax": ref, "tol": tol * ref, "ok": bool(err <= tol * ref)})
+    assert np.isfinite(err) and err <= tol * ref, f"{name}: max err {err:.3e} > tol {tol * ref:.3e}"
+
+
+def test_split_merge_roundtrip():
+    x = rnd((3, 7, 5, 64), 1, 3.0)
+    xs = ops().to_x3(g(x))
+    assert xs.shape == (3, 7, 5, 128) and xs.dtype == torch.bfloat16
+    assert torch.equal(xs.cpu(), E.to_x3(x))                     # bit-exact split: hi = bf16(v), lo = bf16(v - hi)
+    back = ops().from_x3(xs).cpu()
+    assert torch.equal(back, E.from_x3(E.to_x3(x)))
+    assert (back - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+    # strided fp32 source (a channel slice of a wider buffer)
+    wide = g(rnd((2, 4, 4, 128), 2))
+    assert torch.equal(ops().to_x3(wide[..., 64:]).cpu(), E.to_x3(wide[..., 64:].cpu()))
+
+
+X3_CONV = [
+    # name, N,H,W,Cin,Cout,k,stride,pad4
+    ("x3_c3x3_256", 3, 16, 16, 256, 256, 3, 1, (1, 1, 1, 1)),
+    ("x3_c3x3_128_256", 2, 12, 20, 128, 256, 3, 1, (1, 1, 1, 1)),
+    ("x3_c3x3_s2_asym", 3, 16, 16, 256, 256, 3, 2, (0, 1, 0, 1)),
+    ("x3_c1x1_nin", 3, 16, 16, 128, 256, 1, 1, (0, 0, 0, 0)),
+    ("x3_c3x3_512_ragged", 1, 9, 7, 512, 200, 3, 1, (1, 1, 1, 1)),
+    ("x3_c3x3_cout128", 2, 24, 24, 64, 128, 3, 1, (1, 1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", X3_CONV, ids=[c[0] for c in X3_CONV])
+@pytest.mark.parametrize("bn", [0, 128, 256])
+def test_conv2d_x3(case, bn):
+    name, n, h, w_, cin, cout, k, stride, pad4 = case
+    x = rnd((n, h, w_, cin), 10)
+    wt = rnd((cout, k * k * cin), 11, 1.0 / np.sqrt(k * k * cin))
+    wt[:, 0] += torch.arange(cout, dtype=torch.float32) * 0.01           # asymmetric in n
+    b = rnd((cout,), 12, 0.1)
+    xs, ws = E.to_x3(x), ops().pack_x3_weight(wt.reshape(cout, k * k, cin))
+    kw = dict(kh=k, kw=k, stride=stride, pad=pad4, x3=True)
+    want = E.from_x3(E.conv2d(xs, ws, b, act=E.ACT_SILU, **kw))
+    got = ops().conv2d(g(xs), g(ws), g(b), act=E.ACT_SILU, tile=(0, bn), **kw)
+    assert got.dtype == torch.bfloat16 and got.shape[-1] == 2 * cout
+    check(f"{name}_bn{bn}", ops().from_x3(got), want)
+    # against the exact fp32 conv of the un-split operands: the split type's own error
+    exact = E.conv2d(x, wt, b, act=E.ACT_SILU, kh=k, kw=k, stride=stride, pad=pad4)
+    check(f"{name}_bn{bn}_vs_fp32", ops().from_x3(got), exact, 2e-4)
+    # residual + fp32 output forms
+    res = E.to_x3(rnd(tuple(want.shape), 13))
+    got = ops().conv2d(g(xs), g(ws), g(b), res=g(res), tile=(0, bn), **kw)
+    check(f"{name}_bn{bn}_res", ops().from_x3(got), E.from_x3(E.conv2d(xs, ws, b, res=res, **kw)))
+    got = ops().conv2d(g(xs), g(ws), None, out_f32=True, tile=(0, bn), **kw)
+    assert got.dtype == torch.float32 and got.shape[-1] == cout
+    check(f"{name}_bn{bn}_f32out", got, E.conv2d(xs, ws, None, out_f32=True, **kw))
+    again = ops().conv2d(g(xs), g(ws), None, out_f32=True, tile=(0, bn), **kw)
+    assert torch.equal(got, again)                                         # deterministic
+
+
+@pytest.mark.parametrize("shape", [(1000, 256, 768), (333, 512, 1024), (777, 1024, 512), (3072, 512, 512)])
+def test_linear_x3(shape):
+    m, k, n = shape
+    x, wt, b = rnd((m, k), 20), rnd((n, k), 21, 1.0 / np.sqrt(k)), rnd((n,), 22, 0.1)
+    res = E.to_x3(rnd((m, n), 23))
+    xs, ws = E.to_x3(x), ops().pack_x3_weight(wt.reshape(n, 1, k))
+    want = E.from_x3(E.linear(xs, ws, b, act=E.ACT_GELU, res=res, x3=True))
+    got = ops().linear(g(xs), g(ws), g(b), act=E.ACT_GELU, res=g(res), x3=True)
+    check(f"linear_x3{shape}", ops().from_x3(got), want)
+    got32 = ops().linear(g(xs), g(ws), None, out_f32=True, x3=True)
+    check(f"linear_x3_f32out{shape}", got32, E.linear(xs, ws, None, out_f32=True, x3=True))
+
+
+@pytest.mark.parametrize("shape", [(3, 24, 24, 256), (2, 9, 7, 512), (3, 16, 16, 128)])
+def test_groupnorm_silu_x3(shape):
+    x = rnd(shape, 30) * 1.5 + 0.4
+    gam, bet = 1 + 0.1 * rnd((shape[3],), 31), 0.1 * rnd((shape[3],), 32)
+    xs = E.to_x3(x)
+    want = E.from_x3(E.groupnorm_act(xs, gam, bet, x3=True))
+    got = ops().groupnorm_act(g(xs), g(gam), g(bet), x3=True)
+    check(f"gn_silu_x3{shape}", ops().from_x3(got), want)
+    s_w, b_w = E.groupnorm_affine(xs, gam, bet, x3=True)
+    s_g, b_g = ops().groupnorm_affine(g(xs), g(gam), g(bet), x3=True)
+    check(f"gn_scale_x3{shape}", s_g, s_w, 1e-3)
+    check(f"gn_shift_x3{shape}", b_g, b_w, 1e-3)
+
+
+@pytest.mark.parametrize("c", [256, 512])
+def test_layernorm_x3(c):
+    x, pos = rnd((77, c), 40) * 2 + 0.3, rnd((77, c), 41)
+    gam, bet = 1 + 0.1 * rnd((c,), 42), 0.1 * rnd((c,), 43)
+    xs, ps = E.to_x3(x), E.to_x3(pos)
+    y_w, y2_w = E.layernorm(xs, gam, bet, 1e-5, ps, x3=True)
+    y_g, y2_g = ops().layernorm(g(xs), g(gam), g(bet), 1e-5, g(ps), x3=True)
+    check(f"ln_x3_{c}", ops().from_x3(y_g), E.from_x3(y_w))
+    check(f"ln_pos_x3_{c}", ops().from_x3(y2_g), E.from_x3(y2_w))
+    check(f"ln_nopos_x3_{c}", ops().from_x3(ops().layernorm(g(xs), g(gam), g(bet), x3=True)),
+          E.from_x3(E.layernorm(xs, gam, bet, x3=True)))
+
+
+WA_CASES = [(1, 3, 8, 12, 256, (4, 4), (0, 0)), (1, 3, 8, 12, 256, (4, 4), (2, 2)), (2, 3, 8, 8, 512, (4, 4), (2, 2)),
+            (1, 3, 16, 16, 256, (4, 4), (2, 2)), (1, 3, 8, 8, 512, (4, 4), (0, 0)), (1, 3, 16, 16, 512, (8, 8), (4, 4))]
+
+
+@pytest.mark.parametrize("case", WA_CASES)
+def test_window_attention_x3(case):
+    b, t, h, w_, c, win, shift = case
+    heads = 8
+    n = t * win[0] * win[1]
+    qkv = E.to_x3(rnd((b * t * h * w_, 3 * c), 60))
+    bias = rnd((heads, n, n), 61, 0.5)
+    want = E.from_x3(E.window_attention(qkv, bias, b, t, h, w_, c, heads, win, shift, x3=True))
+    got = ops().window_attention(g(qkv), g(bias), b, t, h, w_, c, heads, win, shift, x3=True)
+    check(f"winattn_x3{case}", ops().from_x3(got), want)
+
+
+@pytest.mark.parametrize("L", [192, 200, 3072])
+def test_mha_x3(L):
+    b, heads, hd = (2, 8, 64) if L < 1000 else (1, 8, 64)
+    e = heads * hd
+    qk = rnd((b * L, 2 * e), 70)
+    qk[5, :64] *= 6.0   # a spiky query row: exercises the online-softmax rescale
+    v = rnd((b * L, e), 71)
+    qks, vs = E.to_x3(qk), E.to_x3(v)            # (rows, 4E) = [hi q k | lo q k], (rows, 2E)
+    want = E.from_x3(E.mha(qks[:, :e], qks[:, e:2 * e], vs[:, :e], b, L, heads, hd, 0.125, x3=(2 * e, 2 * e, e)))
+    qd, vd = g(qks), g(vs)
+    got = ops().mha(qd[:, :e], qd[:, e:2 * e], vd[:, :e], b, L, heads, hd, 0.125, x3=(2 * e, 2 * e, e))
+    check(f"mha_x3_{L}", ops().from_x3(got), want)
+
+
+def test_gather_frames():
+    src = g(rnd((5, 6, 4, 64), 90)).to(torch.bfloat16)
+    idx = torch.tensor([0, 1, 2, 1, 2, 3, 4, 4], dtype=torch.int32, device=DEV)
+    got = ops().gather_frames(src, idx)
+    assert torch.equal(got, src[idx.long()])
+    # strided source (hi plane of a split map) into a channel slice of a wider buffer
+    wide = torch.zeros((8, 6, 4, 160), device=DEV, dtype=torch.bfloat16)
+    ops().gather_frames(src[..., :32], idx, out=wide[..., 64:96])
+    assert torch.equal(wide[..., 64:96], src[idx.long()][..., :32]) and wide[..., :64].abs().max().item() == 0
+    u8 = torch.arange(5 * 8 * 8 * 3, dtype=torch.int32).reshape(5, 8, 8, 3).to(torch.uint8).to(DEV)
+    assert torch.equal(ops().gather_frames(u8, idx), u8[idx.long()])
+    f32 = g(rnd((5, 3, 3, 8), 91))
+    assert torch.equal(ops().gather_frames(f32, idx), f32[idx.long()])

@@ -133,3 +133,50 @@ def test_fuse_block_bf16_restructuring_matches_fp32_path(monkeypatch):
     got = blk(enc.to(torch.bfloat16), dec.to(torch.bfloat16), w=0.7).float()
     rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     assert rel < 3e-2, rel
+
+
+@pytest.mark.slow
+def test_whole_model_bf16x3_host_logic_and_numerics(cfg, full_sd, golden_window, monkeypatch):
+    """bf16x3 mode through the CPU emulation (split-bf16 tensors = hi + lo, weights [w_hi | w_hi | w_lo], fp32
+    accumulation): the host plumbing of the split type AND its numerical sufficiency - the arg-max codes must equal the
+    fp32 reference's everywhere (the plain bf16 mode flips ~2 % of them), the decoder runs in bf16."""
+    from pgtformer_amd import PGTFormer
+
+    emu_ops.install(monkeypatch)
+    m = PGTFormer(**cfg)
+    m.load_state_dict(full_sd, strict=True)
+    m.prepare("cpu", "bf16x3")
+    g = np.load(os.path.join(GOLD, "full_golden.npz"))
+    x, _, _ = golden_window
+    out, logits, lq = m(x, w=1.0)
+    codes = m.last_codes.reshape(3, 32, 32, 1).numpy().astype(np.int16)
+    mism = codes != g["codes"]
+    margin = g["logit_margin"].reshape(codes.shape)
+    lerr = np.abs(logits[:, :2, :2].numpy() - g["logits_tok0"]).max()
+    print("bf16x3 emu: code agreement", 1 - mism.mean(), "logits err", lerr,
+          "lq err", np.abs(lq[:, 12:20, 12:20, :].numpy() - g["lq_feat_crop"]).max())
+    assert (margin[mism] < 1e-3).all(), f"{int(mism.sum())} code flips, margins {margin[mism][:8]}"
+    assert lerr < 2e-3
+    assert np.abs(lq[:, 12:20, 12:20, :].numpy() - g["lq_feat_crop"]).max() < 1e-3
+    crop = out[1, :, 192:320, 192:320].clamp(0, 1)
+    ref = torch.from_numpy(g["out_mid_crop"]).clamp(0, 1)
+    psnr = -10.0 * np.log10(float(((crop.double() - ref.double()) ** 2).mean()))
+    print("bf16x3 emu: PSNR(build, reference) mid crop", psnr)
+    assert psnr >= 30.0
+
+
+@pytest.mark.slow
+def test_overlap_aware_windows_equal_stacked_windows(cpu_model, monkeypatch):
+    """forward_nhwc(frames, win=...) - per-frame work once per UNIQUE frame, gathered to window order at the first
+    temporal attention - equals the forward on the stacked windows (reference driver semantics, inference.py:47-74)."""
+    from pgtformer_amd.synth import make_clip
+
+    emu_ops.install(monkeypatch)
+    lq, _ = make_clip(4, 512, seed=5)
+    frames = torch.from_numpy(lq)                                   # 4 frames -> windows (0,1,2), (1,2,3)
+    win = cpu_model.window_index(2, 3, "cpu")
+    assert win.tolist() == [0, 1, 2, 1, 2, 3]
+    a, la, qa = cpu_model.forward_nhwc(frames, w=1.0, win=win)
+    b, lb, qb = cpu_model.forward_nhwc(frames[win.long()].contiguous(), w=1.0)
+    assert a.shape == b.shape == (6, 512, 512, 3)
+    assert torch.equal(la, lb) and torch.equal(qa, qb) and torch.equal(a, b)
