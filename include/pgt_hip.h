@@ -33,7 +33,7 @@ typedef void* pgt_stream_t; /* hipStream_t */
  * formed as hi*hi + lo*hi + hi*lo on the bf16 MFMA with fp32 accumulation (16 significand bits instead of 8): the
  * code-prediction branch runs in this type so that the arg-max codes reproduce the fp32 reference
  * (archs/pgtformer_arch.py:638-664) at bf16-MFMA speed. */
-enum { PGT_F32 = 0, PGT_BF16 = 1, PGT_BF16X3 = 2 };
+enum { PGT_F32 = 0, PGT_BF16 = 1, PGT_BF16X3 = 2, PGT_F16 = 3 /* IEEE half storage: pgt_window_attention3d only */ };
 enum { PGT_ACT_NONE = 0, PGT_ACT_RELU = 1, PGT_ACT_GELU = 2, PGT_ACT_SILU = 3, PGT_ACT_LEAKY02 = 4, PGT_ACT_SIGMOID = 5 };
 enum { PGT_EPI_PLAIN = 0, PGT_EPI_SFT = 1 };
 
@@ -130,6 +130,15 @@ int pgt_window_attention(int32_t dtype, const void* qkv, int32_t ldqkv, void* ou
                          const float* bias, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C,
                          int32_t heads, int32_t wh, int32_t ww, int32_t sh, int32_t sw,
                          pgt_stream_t stream);
+/* Video-Swin form of the same attention (modules/swin.py: WindowAttention3D :85-167 + window_partition/reverse :38-64 +
+ * the 3-axis torch.roll of SwinTransformerBlock3D.forward_part1 :212-246 + compute_mask :311-323): windows (wd,wh,ww) of
+ * the (D,H,W) token grid, cyclic shift (sd,sh,sw), 27-region mask.  qkv: (B*D*H*W, 3C) rows in (b,d,y,x) order
+ * (the fused `qkv` Linear's output, columns [q | k | v]); bias dense (heads, N, N) fp32, N = wd*wh*ww (multiple of 48,
+ * <= 192: e.g. 3x8x8).  dtype PGT_BF16 or PGT_F16 (fp16 MFMA, BASELINE.json configs[4]). */
+int pgt_window_attention3d(int32_t dtype, const void* qkv, int32_t ldqkv, void* out, int32_t ldo,
+                           const float* bias, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                           int32_t heads, int32_t wd, int32_t wh, int32_t ww, int32_t sd, int32_t sh,
+                           int32_t sw, pgt_stream_t stream);
 /* global multi-head attention, flash style (nn.MultiheadAttention inside TransformerSALayer,
  * codeformer_arch.py:105,129): per batch b, softmax(q k^T * scale) v over L tokens.
  * q,k,v: (B*L, heads*hd) row-major with row strides ldq/ldk/ldv. */
@@ -173,6 +182,25 @@ int pgt_argmax_rows(const float* logits, int32_t ld, int32_t rows, int32_t K, in
  * VectorQuantizer.forward distance+argmin, archs/vqgan_arch.py:48-54) */
 int pgt_rq_argmin(const float* dot, int32_t ld, const float* xnorm, const float* enorm, int32_t rows,
                   int32_t K, int32_t* codes, pgt_stream_t stream);
+/* The same look-up with the arg-min inside the distance GEMM (no Ntok x K matrix in HBM): x (rows, D) and codebook
+ * (K, D) in bf16, |x|^2 / |e|^2 fp32, D in {64,128,256,512}.  Same association and first-index tie rule; the dot
+ * products are bit-identical to pgt_conv2d(out_f32) + pgt_rq_argmin on the same operands. */
+int pgt_rq_nearest(int32_t dtype, const void* x, int32_t ldx, const void* codebook, const float* xnorm,
+                   const float* enorm, int32_t rows, int32_t K, int32_t D, int32_t* codes, pgt_stream_t stream);
+/* soft codes of the quantiser: soft[r, j] = softmax_j(-dist[r, j] / temp), codes[r] = argmin_j dist[r, j]
+ * (RQBottleneck.get_soft_codes with stochastic=False, tdcrqvae3_arch.py:429-457) */
+int pgt_rq_soft_codes(const float* dot, int32_t ld, const float* xnorm, const float* enorm, int32_t rows,
+                      int32_t K, float temp, float* soft, int32_t* codes, pgt_stream_t stream);
+/* commitment loss term: loss[0] (+)= scale * mean((x - q)^2) over rows x cols (one depth of
+ * RQBottleneck.compute_commitment_loss :340-352; scale = 1/depth, accumulate = 1 from the second depth on); fp32 result
+ * in device memory; deterministic two-stage reduction in a caller-owned workspace of pgt_commit_loss_workspace_bytes() */
+size_t pgt_commit_loss_workspace_bytes(void);
+int pgt_commit_loss(int32_t dtype, const void* x, int32_t ldx, const void* q, int32_t ldq, int64_t rows,
+                    int32_t cols, float* loss, float scale, int32_t accumulate, void* workspace,
+                    size_t workspace_bytes, pgt_stream_t stream);
+/* y = x + (q - x): the value of the straight-through estimator in RQBottleneck.forward (:336), same fp32 order */
+int pgt_straight_through(int32_t dtype, const void* x, int32_t ldx, const void* q, int32_t ldq, void* y,
+                         int32_t ldy, int64_t rows, int32_t cols, pgt_stream_t stream);
 /* out[r,:] (+)= codebook[codes[r],:] ; optionally resid[r,:] -= codebook[codes[r],:]
  * (VQEmbedding.embed :201-203, RQBottleneck.embed_code :355-368, quantize loop :318-325).
  * codebook fp32 (K+1, D); out/resid dtype = `dtype`. accumulate: 0 = overwrite, 1 = add */

@@ -479,10 +479,147 @@ def tdcrqvae3_forward(sd, cfg, x):
     z, _ = encoder_forward(sd, dd, x.reshape(bt // t, t, c, h, w))
     z_e = _conv(sd, "quant_conv", z).permute(0, 2, 3, 1).contiguous()
     depth = cfg["code_shape"][-1]
-    agg, codes = rq_quantize(sd, z_e, depth, cfg.get("shared_codebook", False))
-    loss = (z_e - agg).pow(2.0).mean() if depth == 1 else None
-    z_q = _conv(sd, "post_quant_conv", agg.permute(0, 3, 1, 2).contiguous())
+    z_q, loss, codes = rq_forward(sd, z_e, depth, cfg.get("shared_codebook", False))
+    z_q = _conv(sd, "post_quant_conv", z_q.permute(0, 3, 1, 2).contiguous())
     return decoder_forward(sd, dd, z_q, t), loss, codes
+
+
+def rq_forward(sd, x, depth, shared=True):
+    """RQBottleneck.forward in eval mode (reference: tdcrqvae3_arch.py:330-352; code/latent shapes coincide for
+    PGTFormer): (x + (quant - x), mean_i mean((x - agg_i)^2), codes)."""
+    resid = x.clone()
+    agg = torch.zeros_like(x)
+    codes, losses = [], []
+    for i in range(depth):
+        q, idx = _nearest(sd, resid, 0 if shared else i)
+        resid = resid - q
+        agg = agg + q
+        losses.append((x - agg).pow(2.0).mean())
+        codes.append(idx.unsqueeze(-1))
+    return x + (agg - x), torch.mean(torch.stack(losses)), torch.cat(codes, -1)
+
+
+def _distances(sd, flat, book_idx):
+    """VQEmbedding.compute_distances (reference :100-117): addmm(|x|^2 + |e|^2, x, e^T, alpha=-2), padding row excluded."""
+    cb_t = sd[f"quantizer.codebooks.{book_idx}.weight"][:-1].t()
+    return torch.addmm(flat.pow(2.0).sum(1, keepdim=True) + cb_t.pow(2.0).sum(0, keepdim=True), flat, cb_t, alpha=-2.0)
+
+
+def _nearest(sd, resid, book_idx):
+    dist = _distances(sd, resid.reshape(-1, resid.shape[-1]), book_idx)
+    idx = dist.argmin(-1).reshape(resid.shape[:-1])
+    return F.embedding(idx, sd[f"quantizer.codebooks.{book_idx}.weight"]), idx
+
+
+def rq_soft_codes(sd, x, depth, shared=True, temp=1.0):
+    """RQBottleneck.get_soft_codes, stochastic=False (reference :429-457): (soft (B,h,w,d,K), codes (B,h,w,d))."""
+    resid = x.clone()
+    softs, codes = [], []
+    for i in range(depth):
+        bi = 0 if shared else i
+        dist = _distances(sd, resid.reshape(-1, resid.shape[-1]), bi).reshape(*resid.shape[:-1], -1)
+        soft = F.softmax(-dist / temp, dim=-1)
+        code = dist.argmin(-1)
+        resid = resid - F.embedding(code, sd[f"quantizer.codebooks.{bi}.weight"])
+        codes.append(code.unsqueeze(-1))
+        softs.append(soft.unsqueeze(-2))
+    return torch.cat(softs, -2), torch.cat(codes, -1)
+
+
+def vector_quantizer(weight, z, beta=0.25):
+    """VectorQuantizer.forward in eval mode (reference: archs/vqgan_arch.py:42-84): z (B,C,H,W), codebook `weight`
+    (K,C).  Distances are formed as |z|^2 + |e|^2 - 2 z.e^T (this association, not addmm), the nearest code by
+    topk(k=1, largest=False).  Returns (z_q (B,C,H,W), loss, indices (B*H*W,1), mean distance)."""
+    zp = z.permute(0, 2, 3, 1).contiguous()
+    flat = zp.view(-1, weight.shape[1])
+    d = (flat ** 2).sum(dim=1, keepdim=True) + (weight ** 2).sum(1) - 2 * torch.matmul(flat, weight.t())
+    scores, idx = torch.topk(d, 1, dim=1, largest=False)
+    onehot = torch.zeros(idx.shape[0], weight.shape[0]).to(zp)
+    onehot.scatter_(1, idx, 1)
+    z_q = torch.matmul(onehot, weight).view(zp.shape)
+    loss = torch.mean((z_q - zp) ** 2) + beta * torch.mean((z_q - zp) ** 2)
+    z_q = zp + (z_q - zp)
+    return z_q.permute(0, 3, 1, 2).contiguous(), loss, idx, torch.mean(d)
+
+
+# ----------------------------------------------------------------------------------------------
+# Video-Swin window attention (reference: modules/swin.py) - BASELINE.json configs[4]
+# ----------------------------------------------------------------------------------------------
+def swin_window_partition(x, ws):
+    """(B,D,H,W,C) -> (B*nW, wd*wh*ww, C) (reference: swin.py:38-49)."""
+    b, d, h, w, c = x.shape
+    x = x.view(b, d // ws[0], ws[0], h // ws[1], ws[1], w // ws[2], ws[2], c)
+    return x.permute(0, 1, 3, 5, 2, 4, 6, 7).contiguous().view(-1, ws[0] * ws[1] * ws[2], c)
+
+
+def swin_window_reverse(win, ws, b, d, h, w):
+    """inverse of swin_window_partition (reference: swin.py:52-64)."""
+    x = win.view(b, d // ws[0], h // ws[1], w // ws[2], ws[0], ws[1], ws[2], -1)
+    return x.permute(0, 1, 4, 2, 5, 3, 6, 7).contiguous().view(b, d, h, w, -1)
+
+
+def swin_compute_mask(d, h, w, ws, ss):
+    """27-region shift mask (nW, N, N) in {0, -100} (reference: swin.py:311-323)."""
+    img = torch.zeros((1, d, h, w, 1))
+    cnt = 0
+    for ds in (slice(-ws[0]), slice(-ws[0], -ss[0]), slice(-ss[0], None)):
+        for hs in (slice(-ws[1]), slice(-ws[1], -ss[1]), slice(-ss[1], None)):
+            for wsl in (slice(-ws[2]), slice(-ws[2], -ss[2]), slice(-ss[2], None)):
+                img[:, ds, hs, wsl, :] = cnt
+                cnt += 1
+    mw = swin_window_partition(img, ws).squeeze(-1)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return am.masked_fill(am != 0, float(-100.0)).masked_fill(am == 0, float(0.0))
+
+
+def swin_relative_position_index(ws):
+    """(N, N) int64 index into the (2wd-1)(2wh-1)(2ww-1)-row bias table (reference: swin.py:103-116)."""
+    coords = torch.stack(torch.meshgrid(torch.arange(ws[0]), torch.arange(ws[1]), torch.arange(ws[2]), indexing="ij"))
+    cf = torch.flatten(coords, 1)
+    rel = (cf[:, :, None] - cf[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws[0] - 1
+    rel[:, :, 1] += ws[1] - 1
+    rel[:, :, 2] += ws[2] - 1
+    rel[:, :, 0] *= (2 * ws[1] - 1) * (2 * ws[2] - 1)
+    rel[:, :, 1] *= (2 * ws[2] - 1)
+    return rel.sum(-1)
+
+
+def swin_window_attention(p, xw, heads, ws, mask=None):
+    """WindowAttention3D.forward (reference: swin.py:128-167).  p: dict with qkv.weight [, qkv.bias], proj.weight,
+    proj.bias, relative_position_bias_table; xw (B_, N, C)."""
+    b_, n, c = xw.shape
+    qkv = F.linear(xw, p["qkv.weight"], p.get("qkv.bias")).reshape(b_, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    q = q * (c // heads) ** -0.5
+    attn = q @ k.transpose(-2, -1)
+    idx = swin_relative_position_index(ws)
+    bias = p["relative_position_bias_table"][idx[:n, :n].reshape(-1)].reshape(n, n, -1).permute(2, 0, 1).contiguous()
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nw = mask.shape[0]
+        attn = attn.view(b_ // nw, nw, heads, n, n) + mask.unsqueeze(1).unsqueeze(0)
+        attn = attn.view(-1, heads, n, n)
+    attn = attn.softmax(-1)
+    x = (attn @ v).transpose(1, 2).reshape(b_, n, c)
+    return F.linear(x, p["proj.weight"], p["proj.bias"])
+
+
+def swin_block_part1(p, x, heads, ws, ss):
+    """SwinTransformerBlock3D.forward_part1 for feature maps that are multiples of the window (reference: swin.py:212-246):
+    norm1 -> cyclic shift on (D,H,W) -> partition -> attention (+ mask when shifted) -> reverse -> shift back."""
+    b, d, h, w, c = x.shape
+    x = F.layer_norm(x, (c,), p["norm1.weight"], p["norm1.bias"], 1e-5)
+    shifted = any(i > 0 for i in ss)
+    if shifted:
+        x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+    mask = swin_compute_mask(d, h, w, ws, ss) if shifted else None
+    attn_p = {k[len("attn."):]: v for k, v in p.items() if k.startswith("attn.")}
+    aw = swin_window_attention(attn_p, swin_window_partition(x, ws), heads, ws, mask)
+    x = swin_window_reverse(aw.view(-1, ws[0], ws[1], ws[2], c), ws, b, d, h, w)
+    if shifted:
+        x = torch.roll(x, shifts=(ss[0], ss[1], ss[2]), dims=(1, 2, 3))
+    return x
 
 
 # ----------------------------------------------------------------------------------------------

@@ -83,10 +83,17 @@ class VQEmbedding(nn.Embedding, HipModule):
         self.book_t = w[:-1].to(device=device, dtype=dtype).contiguous()   # (K, D) distance GEMM operand
         self.enorm = w[:-1].pow(2.0).sum(1).to(device).contiguous()  # |e_j|^2 (reference :111)
 
+    def distances_dot(self, x2d):
+        """(rows, K) fp32 dot products x.e_j and |x|^2 (the two terms compute_distances combines, reference :100-117)."""
+        return ops.linear(x2d, self.book_t, None, out_f32=True), ops.row_sumsq(x2d)
+
     def find_nearest_embedding(self, x2d):
-        """x2d (rows, D) -> int32 codes: argmin_j |x|^2 + |e_j|^2 - 2 x.e_j (reference: :100-126)."""
-        dot = ops.linear(x2d, self.book_t, None, out_f32=True)
-        return ops.rq_argmin(dot, ops.row_sumsq(x2d), self.enorm)
+        """x2d (rows, D) -> int32 codes: argmin_j |x|^2 + |e_j|^2 - 2 x.e_j (reference: :100-126).  bf16: one kernel with
+        the arg-min inside the distance GEMM (no rows x K matrix in HBM); fp32: distance GEMM + row arg-min."""
+        if x2d.dtype == torch.bfloat16 and x2d.shape[1] in (64, 128, 256, 512):
+            return ops.rq_nearest(x2d, self.book_t, ops.row_sumsq(x2d), self.enorm)
+        dot, xn = self.distances_dot(x2d)
+        return ops.rq_argmin(dot, xn, self.enorm)
 
 
 class RQBottleneck(HipModule):
@@ -125,6 +132,47 @@ class RQBottleneck(HipModule):
             ops.embed_rows(book.book, c, x.dtype, out=agg, accumulate=i > 0, resid=resid if depth > 1 else None)
             codes.append(c)
         return agg.reshape(b, h, w, d), torch.stack(codes, -1).reshape(b, h, w, depth)
+
+    def forward(self, x):
+        """x (B,h,w,D) -> (quants (B,h,w,D), commitment loss fp32 device scalar, codes int32 (B,h,w,d)) as
+        RQBottleneck.forward in eval mode (reference :330-352): the loss is the mean over depths of
+        mean((x - aggregated_quant_i)^2); the returned features are x + (quant - x) (the straight-through value)."""
+        b, h, w, d = x.shape
+        depth = self.code_shape[-1]
+        rows = b * h * w
+        x2 = x.reshape(rows, d)
+        resid = x2 if depth == 1 else x2.clone()
+        agg = torch.empty((rows, d), device=x.device, dtype=x.dtype)
+        codes, loss = [], None
+        for i in range(depth):
+            book = self.codebooks[i]
+            c = book.find_nearest_embedding(resid)
+            ops.embed_rows(book.book, c, x.dtype, out=agg, accumulate=i > 0, resid=resid if depth > 1 else None)
+            loss = ops.commit_loss(x2, agg, out=loss, scale=1.0 / depth)      # mean over depths of mean((x - agg_i)^2)
+            codes.append(c)
+        quants = ops.straight_through(x2, agg)
+        return quants.reshape(b, h, w, d), loss, torch.stack(codes, -1).reshape(b, h, w, depth)
+
+    def get_soft_codes(self, x, temp=1.0, stochastic=False):
+        """soft codes softmax(-dist / temp) (B,h,w,d,K) fp32 and hard codes (B,h,w,d) (reference :429-457)."""
+        if stochastic:
+            raise NotImplementedError("stochastic code sampling (torch.multinomial) is a training / sampling-side feature")
+        b, h, w, d = x.shape
+        depth = self.code_shape[-1]
+        rows = b * h * w
+        resid = x.reshape(rows, d).clone()
+        softs, codes = [], []
+        for i in range(depth):
+            book = self.codebooks[i]
+            dot, xn = book.distances_dot(resid)
+            soft, c = ops.rq_soft_codes(dot, xn, book.enorm, temp)
+            if i + 1 < depth:
+                scratch = torch.empty_like(resid)
+                ops.embed_rows(book.book, c, x.dtype, out=scratch, resid=resid)
+            softs.append(soft)
+            codes.append(c)
+        k = softs[0].shape[1]
+        return (torch.stack(softs, 1).reshape(b, h, w, depth, k), torch.stack(codes, -1).reshape(b, h, w, depth))
 
     def embed_code(self, code, dtype=torch.float32):
         """codes (B,h,w,d) int -> summed embeddings (B,h,w,D) (reference: :355-368)."""
@@ -450,6 +498,8 @@ class TDCRQVAE3(HubMixin, HipModule):
         """(B*T,3,H,W) fp32 in [0,1] or uint8 (B*T,H,W,3) -> raw / ImageNet-normalised (B*T,H,W,8)."""
         self._check_ready()
         x = x.to(self.dev)
+        if x.dim() == 5:                      # the reference's (b, t, c, h, w) clips (tdcrqvae3_arch.py:760-764)
+            x = x.reshape(-1, *x.shape[2:])
         return ops.prep_input(x.contiguous(), self.in_dt)
 
     def encode(self, x):
@@ -463,9 +513,9 @@ class TDCRQVAE3(HubMixin, HipModule):
 
     @torch.no_grad()
     def forward(self, input, code_only=False):
+        """(out | z_q, commitment loss (fp32 device scalar), codes) - reference :760-772 in eval mode."""
         z_e = self.encode(input)
-        z_q, codes = self.quantizer.quantize(z_e)
-        quant_loss = None  # commitment loss is a training quantity (reference :340-352)
+        z_q, quant_loss, codes = self.quantizer(z_e)
         if code_only:
             return z_q, quant_loss, codes.long()
         return self.decode(z_q), quant_loss, codes.long()
@@ -473,6 +523,17 @@ class TDCRQVAE3(HubMixin, HipModule):
     @torch.no_grad()
     def get_codes(self, input):
         return self.quantizer.quantize(self.encode(input))[1].long()
+
+    @torch.no_grad()
+    def get_codesbt(self, xs):
+        """xs (b,t,c,h,w) (reference :797-802)."""
+        b, t, c, h, w = xs.shape
+        return self.get_codes(xs.reshape(b * t, c, h, w))
+
+    @torch.no_grad()
+    def get_soft_codes(self, xs, temp=1.0, stochastic=False):
+        soft, code = self.quantizer.get_soft_codes(self.encode(xs), temp=temp, stochastic=stochastic)
+        return soft, code.long()
 
     @torch.no_grad()
     def decode_code(self, code):

@@ -260,8 +260,8 @@ extern "C" int pgt_window_attention(int32_t dtype, const void* qkv, int32_t ldqk
     const int hd = C / heads;
     PGT_CHECK(C % heads == 0 && (hd == 32 || hd == 64), "window_attention: head_dim=%d unsupported (32, 64)", hd);
     if (dtype == PGT_BF16) {
-        const int rc = pgt_window_attn_mfma_bf16(qkv, ldqkv, out, ldo, bias, B, T, H, W, C, heads, wh, ww, sh, sw,
-                                                 (hipStream_t)stream);
+        const int rc = pgt_window_attn_mfma(0, qkv, ldqkv, out, ldo, bias, B, T, H, W, C, heads, T, wh, ww, 0, sh, sw,
+                                            (hipStream_t)stream);
         if (rc <= 0) return rc;   // 0 = launched, < 0 = error, 1 = shape not covered by the MFMA kernel
     }
     PGT_CHECK(N <= 64, "window_attention: %d tokens per window needs the bf16 MFMA kernel (N %% 48 == 0, <= 192); "
@@ -316,8 +316,8 @@ extern "C" int pgt_window_attention_x3(const void* qkv, int32_t ldqkv, int32_t q
     PGT_CHECK(sh >= 0 && sh < wh && sw >= 0 && sw < ww, "window_attention_x3: shift must be in [0, window)");
     PGT_CHECK(C % heads == 0 && qkv_lo >= 3 * C && ldqkv >= qkv_lo + 3 * C && out_lo >= C && ldo >= out_lo + C,
               "window_attention_x3: planes do not fit the rows (ldqkv=%d qkv_lo=%d ldo=%d out_lo=%d C=%d)", ldqkv, qkv_lo, ldo, out_lo, C);
-    const int rc = pgt_window_attn_mfma_bf16(qkv, ldqkv, out, ldo, bias, B, T, H, W, C, heads, wh, ww, sh, sw,
-                                             (hipStream_t)stream, 1, qkv_lo, out_lo);
+    const int rc = pgt_window_attn_mfma(1, qkv, ldqkv, out, ldo, bias, B, T, H, W, C, heads, T, wh, ww, 0, sh, sw,
+                                        (hipStream_t)stream, qkv_lo, out_lo);
     PGT_CHECK(rc != 1, "window_attention_x3: shape not covered by the MFMA kernel (N = T*wh*ww multiple of 48 up to 192, "
               "head_dim 32 or 64, 16-byte aligned rows)");
     return rc;
@@ -329,4 +329,22 @@ extern "C" int pgt_mha_x3(const void* q, int32_t ldq, int32_t q_lo, const void* 
     PGT_CHECK(q && k && v && out, "mha_x3: null argument");
     PGT_CHECK(hd == 64, "mha_x3: head_dim=%d unsupported (64)", hd);
     return pgt_mha_mfma_bf16(q, ldq, k, ldk, v, ldv, out, ldo, B, L, heads, scale, (hipStream_t)stream, 1, q_lo, k_lo, v_lo, out_lo);
+}
+
+// Video-Swin form (modules/swin.py): windows along the depth axis too.  bf16 / fp16 on the MFMA kernel.
+extern "C" int pgt_window_attention3d(int32_t dtype, const void* qkv, int32_t ldqkv, void* out, int32_t ldo,
+                                      const float* bias, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                                      int32_t heads, int32_t wd, int32_t wh, int32_t ww, int32_t sd, int32_t sh,
+                                      int32_t sw, pgt_stream_t stream) {
+    PGT_CHECK(qkv && out && bias, "window_attention3d: null argument");
+    PGT_CHECK(dtype == PGT_BF16 || dtype == PGT_F16, "window_attention3d: dtype must be PGT_BF16 or PGT_F16 (got %d)", dtype);
+    PGT_CHECK(wd > 0 && wh > 0 && ww > 0 && D % wd == 0 && H % wh == 0 && W % ww == 0,
+              "window_attention3d: (D,H,W)=(%d,%d,%d) not multiples of the window (%d,%d,%d)", D, H, W, wd, wh, ww);
+    PGT_CHECK(sd >= 0 && sd < wd && sh >= 0 && sh < wh && sw >= 0 && sw < ww, "window_attention3d: shift must be in [0, window)");
+    PGT_CHECK(C % heads == 0, "window_attention3d: C=%d not divisible by heads=%d", C, heads);
+    const int rc = pgt_window_attn_mfma(dtype == PGT_F16 ? 2 : 0, qkv, ldqkv, out, ldo, bias, B, D, H, W, C, heads, wd, wh, ww,
+                                        sd, sh, sw, (hipStream_t)stream);
+    PGT_CHECK(rc != 1, "window_attention3d: shape not covered (tokens per window = wd*wh*ww must be a multiple of 48 up to "
+              "192, head_dim 32 or 64, 16-byte aligned rows)");
+    return rc;
 }

@@ -245,6 +245,70 @@ __global__ __launch_bounds__(256) void x3_merge_kernel(const bf16_t* __restrict_
     *reinterpret_cast<float4*>(dst + r * ldd + c + 4) = *reinterpret_cast<const float4*>(f + 4);
 }
 
+// ---- stage-I quantiser extras (reference: archs/tdcrqvae3_arch.py:330-352, :429-457) --------------------------------
+// partial sums of (x - q)^2 over a flat chunk of elements (fp32 accumulation, fixed order inside a block)
+template <typename T>
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ q, int ldq,
+                                                             long rows, int cols, float* __restrict__ part) {
+    __shared__ float sm[4];
+    const long total = rows * cols;
+    const long per = (total + gridDim.x - 1) / gridDim.x;
+    const long i0 = (long)blockIdx.x * per, i1 = min(total, i0 + per);
+    float s = 0.f;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const long r = i / cols;
+        const int c = (int)(i % cols);
+        const float d = ldf(x + r * ldx + c) - ldf(q + r * ldq + c);
+        s += d * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ void sum_mean_kernel(const float* __restrict__ part, int n, double count, float* __restrict__ out, float scale,
+                                int accumulate) {
+    if (threadIdx.x || blockIdx.x) return;
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) a += (double)part[i];   // fixed order: deterministic
+    const float v = scale * (float)(a / count);
+    out[0] = accumulate ? out[0] + v : v;
+}
+// straight-through value of RQBottleneck.forward: x + (q - x), evaluated in that order in fp32 (reference :336)
+template <typename T>
+__global__ void straight_through_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ q, int ldq, T* __restrict__ y,
+                                        int ldy, long rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    const float xv = ldf(x + r * ldx + c);
+    stf(y + r * ldy + c, xv + (ldf(q + r * ldq + c) - xv));
+}
+// soft codes: softmax_j(-dist[r, j] / temp) with dist as in rq_argmin_kernel, plus the hard arg-min (one wave per row)
+__global__ __launch_bounds__(256) void rq_soft_codes_kernel(const float* __restrict__ dot, int ld, const float* __restrict__ xn,
+                                                            const float* __restrict__ en, int rows, int K, float inv_temp,
+                                                            float* __restrict__ soft, int* __restrict__ codes) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* dr = dot + (long)row * ld;
+    const float x2 = xn[row];
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < K; j += 64) {
+        const float v = (x2 + en[j]) - 2.0f * dr[j];
+        if (v < best || bi == 0x7fffffff) { best = v; bi = j; }
+    }
+    wave_argext<true>(best, bi);          // best = min distance -> max logit = -best * inv_temp
+    float sum = 0.f;
+    for (int j = lane; j < K; j += 64) sum += expf(-((x2 + en[j]) - 2.0f * dr[j]) * inv_temp - (-best * inv_temp));
+    sum = wave_sum(sum);
+    float* so = soft + (long)row * K;
+    for (int j = lane; j < K; j += 64) so[j] = expf(-((x2 + en[j]) - 2.0f * dr[j]) * inv_temp - (-best * inv_temp)) / sum;
+    if (lane == 0) codes[row] = bi;
+}
+
 inline dim3 grid1d(long n, int blk = 256) { return dim3((unsigned)((n + blk - 1) / blk)); }
 
 }  // namespace
@@ -412,6 +476,47 @@ extern "C" int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float*
               ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "x3_merge: bad argument / alignment");
     hipLaunchKernelGGL(x3_merge_kernel, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, lds, src_lo, dst, ldd, (long)rows, cols / 8);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t pgt_commit_loss_workspace_bytes(void) { return 1024 * sizeof(float); }
+
+extern "C" int pgt_commit_loss(int32_t dtype, const void* x, int32_t ldx, const void* q, int32_t ldq, int64_t rows,
+                               int32_t cols, float* loss, float scale, int32_t accumulate, void* workspace,
+                               size_t workspace_bytes, pgt_stream_t stream) {
+    PGT_CHECK(x && q && loss && workspace && workspace_bytes >= 1024 * sizeof(float), "commit_loss: bad argument / workspace");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)rows * cols;
+    const int nb = (int)(total < 1024L * 4096 ? (total + 4095) / 4096 : 1024);
+    float* part = (float*)workspace;
+    if (dtype == PGT_F32)
+        hipLaunchKernelGGL((sqdiff_partial_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, ldx, (const float*)q, ldq, (long)rows, cols, part);
+    else if (dtype == PGT_BF16)
+        hipLaunchKernelGGL((sqdiff_partial_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)q, ldq, (long)rows, cols, part);
+    else
+        PGT_CHECK(false, "commit_loss: bad dtype %d", dtype);
+    PGT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_mean_kernel, dim3(1), dim3(64), 0, st, part, nb, (double)total, loss, scale, accumulate);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_straight_through(int32_t dtype, const void* x, int32_t ldx, const void* q, int32_t ldq, void* y,
+                                    int32_t ldy, int64_t rows, int32_t cols, pgt_stream_t stream) {
+    PGT_CHECK(x && q && y, "straight_through: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g = grid1d((long)rows * cols);
+    DT_DISPATCH(dtype, "straight_through",
+                hipLaunchKernelGGL((straight_through_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, (const float*)q, ldq, (float*)y, ldy, (long)rows, cols),
+                hipLaunchKernelGGL((straight_through_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)q, ldq, (bf16_t*)y, ldy, (long)rows, cols));
+}
+
+extern "C" int pgt_rq_soft_codes(const float* dot, int32_t ld, const float* xnorm, const float* enorm, int32_t rows,
+                                 int32_t K, float temp, float* soft, int32_t* codes, pgt_stream_t stream) {
+    PGT_CHECK(dot && xnorm && enorm && soft && codes && K > 0 && temp > 0.f, "rq_soft_codes: bad argument");
+    hipLaunchKernelGGL(rq_soft_codes_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dot, ld, xnorm, enorm,
+                       rows, K, 1.0f / temp, soft, codes);
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -11,10 +11,11 @@ int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void
 // igemm2.hip: LDS-DMA implicit GEMM (bf16, Cin % 64 == 0, 16-byte epilogue legal). `conv_p` is a ConvP.
 int pgt_igemm2_launch(const void* conv_p, int bn, int stages, hipStream_t st);
 
-// window_attn_mfma.hip: bf16 MFMA window attention; returns 1 if the shape is not covered (fall back)
-int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int T, int H,
-                              int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st, int x3 = 0,
-                              int qlo = 0, int olo = 0);
+// window_attn_mfma.hip: MFMA window attention, mode 0 bf16 / 1 split-bf16 / 2 fp16; (wd, wh, ww) windows with shift
+// (sd, sh, sw) on a (B, D, H, W) token grid; returns 1 if the shape is not covered
+int pgt_window_attn_mfma(int mode, const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int D, int H,
+                         int W, int C, int heads, int wd, int wh, int ww, int sd, int sh, int sw, hipStream_t st,
+                         int qlo = 0, int olo = 0);
 
 // igemm3.hip: large-tile LDS-DMA implicit GEMM (bf16, stride 1, no up-sampling, Cin % 64 == 0); 1 = combination not built
 int pgt_igemm3_launch(const void* conv_p, int bm, int bn, int stages, hipStream_t st);

@@ -1,0 +1,137 @@
+// Nearest-code look-up of the residual quantiser with the arg-min INSIDE the distance GEMM (K10 of SURVEY.md §2.3;
+// reference: VQEmbedding.compute_distances / find_nearest_embedding, archs/tdcrqvae3_arch.py:100-126, and the same
+// distance + arg-min of VectorQuantizer.forward, archs/vqgan_arch.py:48-54).
+//
+//   codes[t] = first argmin_j ( (|x_t|^2 + |e_j|^2) - 2 <x_t, e_j> )        (addmm(alpha=-2) association, lowest index on ties)
+//
+// The two-kernel form (distance GEMM with fp32 output -> row arg-min) writes and re-reads an Ntok x K fp32 matrix
+// (1.07 GB at Ntok = 262144, K = 1024) for 0.27 GB of algorithmic traffic.  Here the dot products never leave the
+// accumulators.  Swapped formulation, as in the attention kernels, so that a token lives in ONE lane column:
+//   S^T[code, token] = E . X^T      v_mfma_f32_32x32x16_bf16, A = 32 codebook rows from LDS, B = the wave's 32 tokens,
+//                                   held in registers for the whole kernel (D/16 fragments of 16 bytes per lane)
+// In the 32x32 accumulator layout lane l owns column (l & 31) = one token and 16 of the 32 codes of the block (rows
+// (e&3) + 8(e>>2) + 4(l>>5)), so the running (distance, index) minimum is a per-lane scalar pair updated in ascending
+// code order (strict <: the lowest index wins ties); the only cross-lane step is one lane <-> lane+32 exchange at the
+// very end.  Workgroup = 4 waves x 32 tokens; the codebook (K x D bf16, L2-resident) streams through LDS in blocks of
+// 32 codes, the next block prefetched into registers while the current one is multiplied.  The k order of the
+// contraction (ascending 16-element steps, fp32 accumulation) is that of the implicit-GEMM kernels, so the dot
+// products - and therefore the codes - are bit-identical to the two-kernel form.
+#include "common.h"
+#include "pgt_internal.h"
+
+namespace {
+
+template <int D>
+__global__ __launch_bounds__(256) void rq_nearest_mfma_kernel(const uint16_t* __restrict__ x, int ldx,
+                                                              const uint16_t* __restrict__ book /* (K, D) bf16 */,
+                                                              const float* __restrict__ xnorm, const float* __restrict__ enorm,
+                                                              int rows, int K, int* __restrict__ codes) {
+    constexpr int KS = D / 16;                  // k-steps of the 32x32x16 MFMA
+    constexpr int RSTR = D * 2 + 16;            // LDS row stride in bytes (+16: conflict-free ds_read_b128 down a column)
+    constexpr int CPT = 32 * (D / 8) / 256;     // 16-byte chunks of a 32-code block staged per thread
+    static_assert(D % 64 == 0 && CPT >= 1, "embedding dim");
+    __shared__ __attribute__((aligned(16))) char Es[32 * RSTR];
+    __shared__ __attribute__((aligned(16))) float en_s[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5;
+    const int t = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool tok_ok = t < rows;
+
+    // X^T fragments (B operand): this lane's token, k-step s covers dims 16s + 8h .. +7
+    uint4 xf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        xf[s] = make_uint4(0, 0, 0, 0);
+        if (tok_ok) xf[s] = *reinterpret_cast<const uint4*>(x + (long)t * ldx + s * 16 + h * 8);
+    }
+    const float x2 = tok_ok ? xnorm[t] : 0.f;
+
+    // staging roles: chunk c = tid + 256 i of the block: code row c / (D/8), 16-byte column c % (D/8)
+    uint4 re[CPT];
+    auto gload = [&](int cb) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 256 * i;
+            const int r = c / (D / 8), cc = c % (D / 8);
+            const int code = cb * 32 + r;
+            re[i] = make_uint4(0, 0, 0, 0);
+            if (code < K) re[i] = *reinterpret_cast<const uint4*>(book + (long)code * D + cc * 8);
+        }
+    };
+    auto sstore = [&](int cb) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<uint4*>(Es + (c / (D / 8)) * RSTR + (c % (D / 8)) * 16) = re[i];
+        }
+        if (tid < 32) en_s[tid] = (cb * 32 + tid < K) ? enorm[cb * 32 + tid] : INFINITY;   // codes >= K never win
+    };
+
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    const int nb = (K + 31) / 32;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    const char* e_rd = Es + (lane & 31) * RSTR + h * 16;
+    for (int cb = 0; cb < nb; ++cb) {
+        const bool more = cb + 1 < nb;
+        if (more) gload(cb + 1);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const uint4 a = *reinterpret_cast<const uint4*>(e_rd + s * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xf[s]),
+                                                          acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 en4 = *reinterpret_cast<const float4*>(en_s + 8 * g4 + 4 * h);
+            const float en[4] = {en4.x, en4.y, en4.z, en4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // the reference's association: (|x|^2 + |e|^2) + (-2) * <x, e>
+                const float v = (x2 + en[r]) - 2.0f * acc[4 * g4 + r];
+                const int j = cb * 32 + 8 * g4 + 4 * h + r;
+                if (v < best) { best = v; bi = j; }   // ascending j per lane: strict < keeps the first minimum
+            }
+        }
+        __syncthreads();
+        if (more) {
+            sstore(cb + 1);
+            __syncthreads();
+        }
+    }
+    // the two lane halves hold disjoint code subsets of the same token
+    const float ob = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(bi, 32, 64);
+    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    if (tok_ok && h == 0) codes[t] = bi;
+}
+
+}  // namespace
+
+// bf16 tokens x (rows, D) and codebook (K, D) bf16; xnorm / enorm fp32.  D in {64, 128, 256, 512}.
+extern "C" int pgt_rq_nearest(int32_t dtype, const void* x, int32_t ldx, const void* book, const float* xnorm,
+                              const float* enorm, int32_t rows, int32_t K, int32_t D, int32_t* codes, pgt_stream_t stream) {
+    PGT_CHECK(x && book && xnorm && enorm && codes && rows > 0 && K > 0, "rq_nearest: bad argument");
+    PGT_CHECK(dtype == PGT_BF16, "rq_nearest: the fused kernel takes bf16 operands (fp32: distance GEMM + pgt_rq_argmin)");
+    PGT_CHECK(ldx % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)book)) & 15) == 0, "rq_nearest: rows must be 16-byte aligned");
+    const dim3 grid((rows + 127) / 128), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define RQN(D_)                                                                                                   \
+    hipLaunchKernelGGL((rq_nearest_mfma_kernel<D_>), grid, blk, 0, st, (const uint16_t*)x, ldx, (const uint16_t*)book, \
+                       xnorm, enorm, rows, K, codes)
+    switch (D) {
+        case 64: RQN(64); break;
+        case 128: RQN(128); break;
+        case 256: RQN(256); break;
+        case 512: RQN(512); break;
+        default: PGT_CHECK(false, "rq_nearest: D=%d unsupported (64, 128, 256, 512)", D);
+    }
+#undef RQN
+    PGT_LAUNCH_CHECK();
+    return 0;
+}

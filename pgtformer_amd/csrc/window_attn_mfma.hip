@@ -18,15 +18,42 @@
 namespace {
 
 typedef short short4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+// 16-bit element type of the kernel: bf16 (F16 = false) or IEEE half (F16 = true; BASELINE.json configs[4]: "fp16 MFMA")
+template <bool F16> struct El {
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        if constexpr (F16) {
+            const half2v v = {(_Float16)lo, (_Float16)hi};
+            return __builtin_bit_cast(uint32_t, v);
+        } else {
+            return f2bf2(lo, hi);
+        }
+    }
+    static __device__ __forceinline__ f32x4 mma32(const uint4& a, const uint4& b, f32x4 c) {   // 16x16x32
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, a), __builtin_bit_cast(half8v, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mma16(const uint2& a, const uint2& b, f32x4 c) {   // 16x16x16
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4v, a), __builtin_bit_cast(half4v, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, a), __builtin_bit_cast(short4v, b), c, 0, 0, 0);
+    }
+};
 
 // X3: qkv and out are split-bf16 rows (hi plane at the usual columns, lo plane qlo / olo elements further): every
 // product is taken as hi*hi + lo*hi + hi*lo (S^T from q, k; O^T from P, V with P split in registers after the exp).
-template <int HD, int NW, bool X3 = false>
+// Windows are (wd, wh, ww) blocks of the (D, H, W) token grid with a cyclic shift (sd, sh, sw) and the 27-region mask of
+// modules/swin.py:311-323; the PGTFormer layers use wd = D, sd = 0 (all frames of a spatial window in one group).
+template <int HD, int NW, bool X3 = false, bool F16 = false>
 __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_t* __restrict__ qkv, int ldqkv,
                                                                    uint16_t* __restrict__ out, int ldo,
                                                                    const float* __restrict__ bias, int T_, int H, int W,
                                                                    int C, int heads, int wh, int ww, int sh, int sw,
-                                                                   int qlo = 0, int olo = 0) {
+                                                                   int qlo, int olo, int wd, int sd) {
+    static_assert(!(X3 && F16), "the split type is bf16");
+    typedef El<F16> EL;
     constexpr int N = 48 * NW;
     constexpr int VSTR = N * 2 + 8;   // V^T row stride in bytes (keys contiguous, 8-byte pad)
     constexpr int KS = HD / 32;       // k-steps of the S^T MFMA
@@ -43,20 +70,24 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
     int bid = blockIdx.x;
     const int head = bid % heads; bid /= heads;
     const int wx = bid % nwx; bid /= nwx;
-    const int wy = bid % nwy;
-    const int b = bid / nwy;
-    const bool shifted = (sh > 0) || (sw > 0);
+    const int wy = bid % nwy; bid /= nwy;
+    const int nwz = T_ / wd;
+    const int wz = bid % nwz;
+    const int b = bid / nwz;
+    const bool shifted = (sh > 0) || (sw > 0) || (sd > 0);
 
     for (int i = tid; i < N; i += 64 * NW) {
         const int s = i % ww;
         const int r = (i / ww) % wh;
-        const int d = i / (ww * wh);
-        const int ys = wy * wh + r, xs = wx * ww + s;             // coordinates in the rolled frame
-        const int y = (ys + sh) % H, x = (xs + sw) % W;           // source pixel (roll by -shift)
+        const int dd = i / (ww * wh);
+        const int ds = wz * wd + dd, ys = wy * wh + r, xs = wx * ww + s;      // coordinates in the rolled volume
+        const int d = (ds + sd) % T_, y = (ys + sh) % H, x = (xs + sw) % W;   // source token (roll by -shift)
         tok[i] = ((b * T_ + d) * H + y) * W + x;
-        const int rh = ys < H - wh ? 0 : (ys < H - sh ? 1 : 2);   // img_mask regions (rstt_layers.py:552-563)
+        // img_mask regions (rstt_layers.py:552-563; swin.py:313-318): only equality inside one window matters
+        const int rd = ds < T_ - wd ? 0 : (ds < T_ - sd ? 1 : 2);
+        const int rh = ys < H - wh ? 0 : (ys < H - sh ? 1 : 2);
         const int rw = xs < W - ww ? 0 : (xs < W - sw ? 1 : 2);
-        reg[i] = rh * 3 + rw;
+        reg[i] = (rd * 3 + rh) * 3 + rw;
     }
     __syncthreads();
     // ---- V^T image: work item = (key pair, 8-channel chunk); dword = {V[2kp][d], V[2kp+1][d]}
@@ -129,13 +160,10 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if constexpr (X3) {   // small terms first
-                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kl[kt][ks]),
-                                                                        __builtin_bit_cast(bf16x8, qf[qt][ks]), s[kt], 0, 0, 0);
-                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[kt][ks]),
-                                                                        __builtin_bit_cast(bf16x8, ql[qt][ks]), s[kt], 0, 0, 0);
+                        s[kt] = EL::mma32(kl[kt][ks], qf[qt][ks], s[kt]);
+                        s[kt] = EL::mma32(kf[kt][ks], ql[qt][ks], s[kt]);
                     }
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[kt][ks]),
-                                                                    __builtin_bit_cast(bf16x8, qf[qt][ks]), s[kt], 0, 0, 0);
+                    s[kt] = EL::mma32(kf[kt][ks], qf[qt][ks], s[kt]);
                 }
                 const float4 bv = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + kg * 48 + kt * 16 + 4 * g);
                 const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -163,7 +191,7 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
                     p[r] = __builtin_amdgcn_exp2f(s[kt][r] - mnew);
                     lsum += p[r];
                 }
-                pf[kt] = make_uint2(f2bf2(p[0], p[1]), f2bf2(p[2], p[3]));
+                pf[kt] = make_uint2(EL::pack2(p[0], p[1]), EL::pack2(p[2], p[3]));
                 if constexpr (X3) {
                     const float r0 = p[0] - __uint_as_float(pf[kt].x << 16), r1 = p[1] - __uint_as_float(pf[kt].x & 0xffff0000u);
                     const float r2 = p[2] - __uint_as_float(pf[kt].y << 16), r3 = p[3] - __uint_as_float(pf[kt].y & 0xffff0000u);
@@ -180,13 +208,10 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
                     const uint2 a = *reinterpret_cast<const uint2*>(vt + (dt * 16 + col) * VSTR + (kg * 48 + kt * 16 + 4 * g) * 2);
                     if constexpr (X3) {
                         const uint2 al = *reinterpret_cast<const uint2*>(vt + HD * VSTR + (dt * 16 + col) * VSTR + (kg * 48 + kt * 16 + 4 * g) * 2);
-                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, al),
-                                                                              __builtin_bit_cast(short4v, pf[kt]), o[qt][dt], 0, 0, 0);
-                        o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, a),
-                                                                              __builtin_bit_cast(short4v, pl2[kt]), o[qt][dt], 0, 0, 0);
+                        o[qt][dt] = EL::mma16(al, pf[kt], o[qt][dt]);
+                        o[qt][dt] = EL::mma16(a, pl2[kt], o[qt][dt]);
                     }
-                    o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, a),
-                                                                          __builtin_bit_cast(short4v, pf[kt]), o[qt][dt], 0, 0, 0);
+                    o[qt][dt] = EL::mma16(a, pf[kt], o[qt][dt]);
                 }
             }
         }
@@ -201,7 +226,7 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const float v0 = o[qt][dt][0] * inv, v1 = o[qt][dt][1] * inv, v2 = o[qt][dt][2] * inv, v3 = o[qt][dt][3] * inv;
-            const uint2 w2 = make_uint2(f2bf2(v0, v1), f2bf2(v2, v3));
+            const uint2 w2 = make_uint2(EL::pack2(v0, v1), EL::pack2(v2, v3));
             *reinterpret_cast<uint2*>(orow + dt * 16) = w2;
             if constexpr (X3) {
                 const uint2 wl = make_uint2(f2bf2(v0 - __uint_as_float(w2.x << 16), v1 - __uint_as_float(w2.x & 0xffff0000u)),
@@ -214,38 +239,35 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
 
 }  // namespace
 
-// bf16 (x3 = 0) or split-bf16 (x3 = 1: lo planes qlo / olo elements after the hi planes); N = T*wh*ww in {48, 96, 144,
-// 192}; hd in {32, 64}.  Returns 1 when the shape is not covered (caller falls back).
-int pgt_window_attn_mfma_bf16(const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int T, int H,
-                              int W, int C, int heads, int wh, int ww, int sh, int sw, hipStream_t st, int x3, int qlo,
-                              int olo) {
-    const int N = T * wh * ww, hd = C / heads;
-    if (N % 48 != 0 || N > 192 || (hd != 32 && hd != 64)) return 1;
+// mode 0: bf16, 1: split-bf16 (lo planes qlo / olo elements after the hi planes), 2: fp16.  Windows (wd, wh, ww) with shift
+// (sd, sh, sw) on a (B, D, H, W) token grid; N = wd*wh*ww in {48, 96, 144, 192}; hd in {32, 64}.
+// Returns 1 when the shape is not covered (caller falls back or reports).
+int pgt_window_attn_mfma(int mode, const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int D, int H,
+                         int W, int C, int heads, int wd, int wh, int ww, int sd, int sh, int sw, hipStream_t st, int qlo,
+                         int olo) {
+    const int N = wd * wh * ww, hd = C / heads;
+    if (N % 48 != 0 || N > 192 || (hd != 32 && hd != 64) || wd <= 0 || D % wd != 0) return 1;
     if (ldqkv % 8 != 0 || ldo % 4 != 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7) || ((uintptr_t)bias & 15)) return 1;
-    if (x3 && (qlo % 8 != 0 || olo % 4 != 0)) return 1;
-    const int grid = B * (H / wh) * (W / ww) * heads;
+    if (mode == 1 && (qlo % 8 != 0 || olo % 4 != 0)) return 1;
+    const int grid = B * (D / wd) * (H / wh) * (W / ww) * heads;
     const int nw = N / 48;
-    if (x3) {
-#define WAM3(HD_, NW_)                                                                                                    \
-    hipLaunchKernelGGL((window_attn_mfma_kernel<HD_, NW_, true>), dim3(grid), dim3(64 * NW_), 0, st, (const uint16_t*)qkv, \
-                       ldqkv, (uint16_t*)out, ldo, bias, T, H, W, C, heads, wh, ww, sh, sw, qlo, olo)
-        if (hd == 32) {
-            switch (nw) { case 1: WAM3(32, 1); break; case 2: WAM3(32, 2); break; case 3: WAM3(32, 3); break; default: WAM3(32, 4); }
-        } else {
-            switch (nw) { case 1: WAM3(64, 1); break; case 2: WAM3(64, 2); break; case 3: WAM3(64, 3); break; default: WAM3(64, 4); }
-        }
-#undef WAM3
-        PGT_LAUNCH_CHECK();
-        return 0;
-    }
-#define WAM(HD_, NW_)                                                                                             \
-    hipLaunchKernelGGL((window_attn_mfma_kernel<HD_, NW_>), dim3(grid), dim3(64 * NW_), 0, st, (const uint16_t*)qkv, \
-                       ldqkv, (uint16_t*)out, ldo, bias, T, H, W, C, heads, wh, ww, sh, sw)
-    if (hd == 32) {
-        switch (nw) { case 1: WAM(32, 1); break; case 2: WAM(32, 2); break; case 3: WAM(32, 3); break; default: WAM(32, 4); }
-    } else {
-        switch (nw) { case 1: WAM(64, 1); break; case 2: WAM(64, 2); break; case 3: WAM(64, 3); break; default: WAM(64, 4); }
-    }
+#define WAM(HD_, NW_, X3_, F16_)                                                                                              \
+    hipLaunchKernelGGL((window_attn_mfma_kernel<HD_, NW_, X3_, F16_>), dim3(grid), dim3(64 * NW_), 0, st, (const uint16_t*)qkv, \
+                       ldqkv, (uint16_t*)out, ldo, bias, D, H, W, C, heads, wh, ww, sh, sw, qlo, olo, wd, sd)
+#define WAM_ALL(X3_, F16_)                                                                                                    \
+    do {                                                                                                                      \
+        if (hd == 32) {                                                                                                       \
+            switch (nw) { case 1: WAM(32, 1, X3_, F16_); break; case 2: WAM(32, 2, X3_, F16_); break;                          \
+                          case 3: WAM(32, 3, X3_, F16_); break; default: WAM(32, 4, X3_, F16_); }                              \
+        } else {                                                                                                              \
+            switch (nw) { case 1: WAM(64, 1, X3_, F16_); break; case 2: WAM(64, 2, X3_, F16_); break;                          \
+                          case 3: WAM(64, 3, X3_, F16_); break; default: WAM(64, 4, X3_, F16_); }                              \
+        }                                                                                                                     \
+    } while (0)
+    if (mode == 1) WAM_ALL(true, false);
+    else if (mode == 2) WAM_ALL(false, true);
+    else WAM_ALL(false, false);
+#undef WAM_ALL
 #undef WAM
     PGT_LAUNCH_CHECK();
     return 0;

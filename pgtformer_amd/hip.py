@@ -9,7 +9,7 @@ import os
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpgt_hip.so")
 
-PGT_F32, PGT_BF16, PGT_BF16X3 = 0, 1, 2
+PGT_F32, PGT_BF16, PGT_BF16X3, PGT_F16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_LEAKY02, ACT_SIGMOID = range(6)
 EPI_PLAIN, EPI_SFT = 0, 1
 
@@ -39,6 +39,7 @@ SIGNATURES = {
     "pgt_channel_stats": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
     "pgt_adain_affine": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
     "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "pgt_window_attention3d": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pgt_mha": [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
     "pgt_groupnorm_affine_x3": [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp],
     "pgt_affine_act_x3": [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp],
@@ -49,6 +50,11 @@ SIGNATURES = {
     "pgt_x3_merge": [vp, i32, i32, vp, i32, i64, i32, vp],
     "pgt_argmax_rows": [vp, i32, i32, i32, vp, vp],
     "pgt_rq_argmin": [vp, i32, vp, vp, i32, i32, vp, vp],
+    "pgt_rq_nearest": [i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp],
+    "pgt_rq_soft_codes": [vp, i32, vp, vp, i32, i32, f32, vp, vp, vp],
+    "pgt_commit_loss_workspace_bytes": [],
+    "pgt_commit_loss": [i32, vp, i32, vp, i32, i64, i32, vp, f32, i32, vp, sz, vp],
+    "pgt_straight_through": [i32, vp, i32, vp, i32, vp, i32, i64, i32, vp],
     "pgt_embed_rows": [i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp],
     "pgt_row_sumsq": [i32, vp, i32, i32, i32, vp, vp],
     "pgt_maxpool3x3s2": [i32, vp, i32, i32, i32, i32, vp, vp],
@@ -61,6 +67,7 @@ SIGNATURES = {
     "pgt_frame_to_u8": [i32, vp, i32, i32, i32, vp, vp],
 }
 _RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz,
+             "pgt_commit_loss_workspace_bytes": sz,
              "pgt_conv2d_workspace_bytes": sz}
 
 

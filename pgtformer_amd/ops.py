@@ -385,6 +385,19 @@ def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
     return out
 
 
+def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift):
+    """Video-Swin window attention (modules/swin.py): qkv (B*D*H*W, 3C) bf16 or fp16 -> (B*D*H*W, C); win = (wd, wh, ww),
+    shift = (sd, sh, sw)."""
+    rows = B * D * H * W
+    assert tuple(qkv.shape) == (rows, 3 * C_) and qkv.dtype in (torch.bfloat16, torch.float16)
+    out = torch.empty((rows, C_), device=qkv.device, dtype=qkv.dtype)
+    dt = hip.PGT_F16 if qkv.dtype == torch.float16 else PGT_BF16
+    hip.check(hip.lib().pgt_window_attention3d(dt, _p(qkv), _ld_rows(qkv), _p(out), C_, _p(bias), B, D, H, W, C_, heads,
+                                               win[0], win[1], win[2], shift[0], shift[1], shift[2], _stream()),
+              "pgt_window_attention3d")
+    return out
+
+
 def mha(q, k, v, B, L, heads, hd, scale, x3=None):
     """q,k,v (B*L, heads*hd) views -> (B*L, heads*hd).  x3=(q_lo, k_lo, v_lo): q, k, v are the hi planes of split-bf16
     rows whose lo planes start that many elements further; returns split rows (B*L, 2*heads*hd)."""
@@ -415,6 +428,49 @@ def rq_argmin(dot, xnorm, enorm):
     hip.check(hip.lib().pgt_rq_argmin(_p(dot), _ld_rows(dot), _p(xnorm), _p(enorm), rows, k, _p(codes), _stream()),
               "pgt_rq_argmin")
     return codes
+
+
+def rq_nearest(x, book, xnorm, enorm):
+    """Fused nearest-code look-up (distance GEMM + arg-min in one kernel, bf16): x (rows, D), book (K, D) -> int32 codes."""
+    rows, d = x.shape
+    assert x.dtype == torch.bfloat16 and book.dtype == torch.bfloat16 and book.is_contiguous() and book.shape[1] == d
+    codes = torch.empty((rows,), dtype=torch.int32, device=x.device)
+    hip.check(hip.lib().pgt_rq_nearest(PGT_BF16, _p(x), _ld_rows(x), _p(book), _p(xnorm), _p(enorm), rows, book.shape[0], d,
+                                       _p(codes), _stream()), "pgt_rq_nearest")
+    return codes
+
+
+def rq_soft_codes(dot, xnorm, enorm, temp=1.0):
+    rows, k = dot.shape
+    soft = torch.empty((rows, k), dtype=torch.float32, device=dot.device)
+    codes = torch.empty((rows,), dtype=torch.int32, device=dot.device)
+    hip.check(hip.lib().pgt_rq_soft_codes(_p(dot), _ld_rows(dot), _p(xnorm), _p(enorm), rows, k, float(temp), _p(soft),
+                                          _p(codes), _stream()), "pgt_rq_soft_codes")
+    return soft, codes
+
+
+def commit_loss(x, q, out=None, scale=1.0):
+    """out[0] (+)= scale * mean((x - q)^2) over two (rows, C) matrices; out: fp32 device scalar (1,) (None: new, overwritten)."""
+    rows, c = x.shape
+    assert q.shape == x.shape and q.dtype == x.dtype
+    L = hip.lib()
+    nbytes = L.pgt_commit_loss_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    hip.check(L.pgt_commit_loss(_dt(x), _p(x), _ld_rows(x), _p(q), _ld_rows(q), rows, c, _p(out), float(scale), int(acc),
+                                _p(ws), nbytes, _stream()), "pgt_commit_loss")
+    return out
+
+
+def straight_through(x, q):
+    """x + (q - x) element-wise over (rows, C) matrices (the reference's straight-through value, same fp32 order)."""
+    rows, c = x.shape
+    out = torch.empty((rows, c), device=x.device, dtype=x.dtype)
+    hip.check(hip.lib().pgt_straight_through(_dt(x), _p(x), _ld_rows(x), _p(q), _ld_rows(q), _p(out), c, rows, c, _stream()),
+              "pgt_straight_through")
+    return out
 
 
 def embed_rows(codebook, codes, dtype, out=None, accumulate=False, resid=None):

@@ -217,6 +217,44 @@ def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
     return o.reshape(B * T * H * W, C_).to(qkv.dtype)
 
 
+def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift):
+    """Video-Swin form: (wd,wh,ww) windows, 3-axis roll, 27-region mask from region labels (independent formulation)."""
+    wd, wh, ww = win
+    sd, sh, sw = shift
+    hd = C_ // heads
+    x = qkv.float().reshape(B, D, H, W, 3 * C_)
+    shifted = bool(sd or sh or sw)
+    if shifted:
+        x = torch.roll(x, shifts=(-sd, -sh, -sw), dims=(1, 2, 3))
+
+    def part(t):   # (B,D,H,W,ch) -> (B*nW, N, ch)
+        ch = t.shape[-1]
+        t = t.reshape(B, D // wd, wd, H // wh, wh, W // ww, ww, ch).permute(0, 1, 3, 5, 2, 4, 6, 7)
+        return t.reshape(-1, wd * wh * ww, ch)
+    nW = (D // wd) * (H // wh) * (W // ww)
+    N = wd * wh * ww
+    xw = part(x).reshape(B * nW, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = xw[0] * (hd ** -0.5), xw[1], xw[2]
+    attn = q @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if shifted:
+        img = torch.zeros(1, D, H, W, 1)
+        cnt = 0
+        for ds in (slice(0, D - wd), slice(D - wd, D - sd), slice(D - sd, D)):
+            for hs in (slice(0, H - wh), slice(H - wh, H - sh), slice(H - sh, H)):
+                for ws_ in (slice(0, W - ww), slice(W - ww, W - sw), slice(W - sw, W)):
+                    img[:, ds, hs, ws_, :] = cnt
+                    cnt += 1
+        mw = part(img.expand(B, D, H, W, 1))[:nW, :, 0]
+        am = mw.unsqueeze(1) - mw.unsqueeze(2)
+        am = torch.where(am != 0, torch.full_like(am, -100.0), torch.zeros_like(am))
+        attn = (attn.reshape(B, nW, heads, N, N) + am.unsqueeze(1).unsqueeze(0)).reshape(-1, heads, N, N)
+    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(B, D // wd, H // wh, W // ww, wd, wh, ww, C_)
+    o = o.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, C_)
+    if shifted:
+        o = torch.roll(o, shifts=(sd, sh, sw), dims=(1, 2, 3))
+    return o.reshape(B * D * H * W, C_).to(qkv.dtype)
+
+
 def mha(q, k, v, B, L, heads, hd, scale, x3=None):
     if x3 is not None:   # q, k, v are hi-plane views of split rows; the lo planes start x3[i] elements further
         e = heads * hd
@@ -238,6 +276,24 @@ def argmax_rows(logits):
 
 def rq_argmin(dot, xnorm, enorm):
     return ((xnorm.unsqueeze(1) + enorm.unsqueeze(0)) - 2.0 * dot).argmin(-1).to(torch.int32)
+
+
+def rq_nearest(x, book, xnorm, enorm):
+    return rq_argmin(linear(x, book, None, out_f32=True), xnorm, enorm)
+
+
+def rq_soft_codes(dot, xnorm, enorm, temp=1.0):
+    dist = (xnorm.unsqueeze(1) + enorm.unsqueeze(0)) - 2.0 * dot
+    return F.softmax(-dist / temp, dim=-1), dist.argmin(-1).to(torch.int32)
+
+
+def commit_loss(x, q, out=None, scale=1.0):
+    v = scale * (x.float() - q.float()).pow(2.0).mean().reshape(1)
+    return v if out is None else out + v
+
+
+def straight_through(x, q):
+    return (x.float() + (q.float() - x.float())).to(x.dtype)
 
 
 def embed_rows(codebook, codes, dtype, out=None, accumulate=False, resid=None):
@@ -312,7 +368,8 @@ def frame_to_u8(x, out=None):
 ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "layernorm", "channel_stats",
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
-       "frame_to_u8", "to_x3", "from_x3", "gather_frames"]
+       "frame_to_u8", "to_x3", "from_x3", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
+       "straight_through"]
 
 
 def install(monkeypatch):

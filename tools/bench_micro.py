@@ -32,6 +32,25 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def window_attention3d(iters):
+    """BASELINE.json configs[4]: Video-Swin windows 3x8x8 (N = 192), C = 512, fp16 and bf16 MFMA, shifted / un-shifted,
+    nW sweep (modules/swin.py parametrisation: pgt_window_attention3d)."""
+    heads, c, win = 8, 512, (3, 8, 8)
+    n = win[0] * win[1] * win[2]
+    for dt in (torch.float16, torch.bfloat16):
+        for (d, h, w) in [(3, 64, 64), (3, 128, 128), (3, 256, 256), (6, 128, 128)]:
+            nw = (d // win[0]) * (h // win[1]) * (w // win[2])
+            qkv = torch.randn((d * h * w, 3 * c), device="cuda").to(dt)
+            bias = (0.02 * torch.randn((heads, n, n), device="cuda")).float()
+            for shift in ((0, 0, 0), (0, 4, 4)) + (((1, 4, 4),) if d > 3 else ()):
+                us = timeit(lambda: ops.window_attention3d(qkv, bias, 1, d, h, w, c, heads, win, shift), iters)
+                byts = d * h * w * c * 2 * 4
+                flops = 4.0 * n * n * c * nw
+                print(json.dumps({"bench": "window_attention3d", "dtype": str(dt).replace("torch.", ""), "nW": nw, "N": n, "C": c,
+                                  "shift": list(shift), "us": round(us, 1), "GBps": round(byts / us / 1e3, 1),
+                                  "hbm_frac": round(byts / us / 1e3 / 8000, 3), "TFLOPs": round(flops / us / 1e6, 1)}))
+
+
 def window_attention(iters):
     dt = torch.bfloat16
     heads = 8
@@ -62,22 +81,30 @@ def rq_lookup(iters):
             x = torch.randn((ntok, 512), device="cuda").to(dt)
             x[5] = book[700].to(dt)
             for depth in (1, 4):
-                def run():
-                    resid = x.clone() if depth > 1 else x
-                    agg = torch.empty_like(x)
-                    codes = None
-                    for i in range(depth):
-                        dot = ops.linear(resid, book_t, None, out_f32=True)
-                        codes = ops.rq_argmin(dot, ops.row_sumsq(resid), enorm)
-                        ops.embed_rows(book, codes, dt, out=agg, accumulate=i > 0, resid=resid if depth > 1 else None)
-                    return codes
-                us = timeit(run, max(2, iters // (1 + ntok // 65536)))
-                codes = run() if depth == 1 else None
-                tie_ok = bool(codes[5].item() == 13) if codes is not None else None
-                flops = 2.0 * ntok * 1024 * 512 * depth
-                print(json.dumps({"bench": "rq_lookup", "dtype": str(dt).replace("torch.", ""), "Ntok": ntok, "depth": depth,
-                                  "us": round(us, 1), "Mtok_per_s": round(ntok / us, 2), "TFLOPs": round(flops / us / 1e6, 1),
-                                  "lowest_index_tie": tie_ok}))
+                for fused in ((True, False) if dt == torch.bfloat16 else (False,)):
+                    def run():
+                        resid = x.clone() if depth > 1 else x
+                        agg = torch.empty_like(x)
+                        codes = None
+                        for i in range(depth):
+                            if fused:      # arg-min inside the distance GEMM (csrc/rq_nearest.hip)
+                                codes = ops.rq_nearest(resid, book_t, ops.row_sumsq(resid), enorm)
+                            else:          # distance GEMM with fp32 output + row arg-min
+                                dot = ops.linear(resid, book_t, None, out_f32=True)
+                                codes = ops.rq_argmin(dot, ops.row_sumsq(resid), enorm)
+                            ops.embed_rows(book, codes, dt, out=agg, accumulate=i > 0, resid=resid if depth > 1 else None)
+                        return codes
+                    us = timeit(run, max(2, iters // (1 + ntok // 65536)))
+                    codes = run() if depth == 1 else None
+                    tie_ok = bool(codes[5].item() == 13) if codes is not None else None
+                    flops = 2.0 * ntok * 1024 * 512 * depth
+                    # algorithmic HBM bytes: x in + quantised out (+ residual r/w at depth > 1) + codes + codebook
+                    es = 2 if dt == torch.bfloat16 else 4
+                    byts = depth * (ntok * 512 * es * (2 if depth == 1 else 4) + ntok * 4) + 1024 * 512 * es
+                    print(json.dumps({"bench": "rq_lookup", "dtype": str(dt).replace("torch.", ""), "Ntok": ntok, "depth": depth,
+                                      "fused_argmin": fused, "us": round(us, 1), "Mtok_per_s": round(ntok / us, 2),
+                                      "TFLOPs": round(flops / us / 1e6, 1), "mfma_frac": round(flops / us / 1e6 / (2500 if es == 2 else 157.3), 3),
+                                      "algorithmic_GBps": round(byts / us / 1e3, 1), "lowest_index_tie": tie_ok}))
 
 
 if __name__ == "__main__":
@@ -85,4 +112,5 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     window_attention(a.iters)
+    window_attention3d(a.iters)
     rq_lookup(a.iters)

@@ -3,7 +3,10 @@
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/fetch -o r -- python bench.py --steps 2 --warmup 1 --no-graph ...
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/write -o r -- python bench.py --steps 2 --warmup 1 --no-graph ...
-  python tools/pmc_traffic.py out/fetch/r_results.db out/write/r_results.db profiles/r1_igemm_traffic_pmc.json
+  python tools/pmc_traffic.py out/fetch/r_results.db out/write/r_results.db profiles/r2_igemm_traffic_pmc.json [precision B]
+
+`precision` and `B` (windows per forward) of the profiled command are stored in the file: bench.py quotes the measurement
+as `roofline.traffic` only for the matching configuration.
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 counts 128-byte requests as 64 B for wide (16 B/lane) coalesced reads, so the read side is doubled.
@@ -27,7 +30,7 @@ def per_kernel(db, counter, likes):
     return tot, n
 
 
-def main(fetch_db, write_db, out):
+def main(fetch_db, write_db, out, precision=None, windows_per_forward=None):
     f_kib, nf = per_kernel(fetch_db, "FETCH_SIZE", FAMILY)
     w_kib, nw = per_kernel(write_db, "WRITE_SIZE", FAMILY)
     res = {"kernel": "conv/linear family: igemm*_kernel (igemm, igemm3, igemm4, igemm5) + conv3x3_c64_kernel (igemm6)", "launches": nf,
@@ -37,9 +40,12 @@ def main(fetch_db, write_db, out):
            "hbm_bytes_per_launch": (2 * f_kib * 1024) / max(nf, 1) + w_kib * 1024 / max(nw, 1),
            "note": "read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE under-count for 16 B/lane streams); "
                    "Infinity-Cache hits are included in these L2 fabric counters"}
+    if precision is not None:
+        res["precision"] = precision
+        res["windows_per_forward"] = int(windows_per_forward)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])

@@ -2,9 +2,11 @@
 """Summarise a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel trace into a per-kernel stats CSV.
 
     rocprofv3 --kernel-trace --stats -d <dir> -o <name> -- python bench.py ...
-    python tools/rocpd_stats.py <dir>/<name>_results.db profiles/<tag>_kernel_stats.csv [windows]
+    python tools/rocpd_stats.py <dir>/<name>_results.db profiles/<tag>_kernel_stats.csv [windows | @B]
 
 Columns: kernel, calls, total_us, avg_us, min_us, max_us, pct, us_per_window (if `windows` given).
+`@B` derives the window count from the trace itself: argmax_rows_kernel runs exactly once per forward, so
+windows = (its call count) x B windows per forward - no hand-counted warm-up / replay bookkeeping.
 """
 import csv
 import sqlite3
@@ -32,5 +34,15 @@ def main(db, out, windows=None):
     print(f"{out}: {len(rows)} kernels, {total / 1e3:.2f} ms of GPU time")
 
 
+def windows_from_trace(db, per_forward):
+    c = sqlite3.connect(db)
+    n = c.execute("select count(*) from kernels where name like '%argmax_rows_kernel%'").fetchone()[0]
+    print(f"{n} forwards in the trace x {per_forward} windows per forward")
+    return float(n * per_forward) if n else None
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else None)
+    win = None
+    if len(sys.argv) > 3:
+        win = windows_from_trace(sys.argv[1], int(sys.argv[3][1:])) if sys.argv[3].startswith("@") else float(sys.argv[3])
+    main(sys.argv[1], sys.argv[2], win)
