@@ -52,7 +52,7 @@ def parse():
                     help="independent 3-frame windows batched into one forward (reference semantics: B separate calls)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = physical cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, physical cores))")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -100,6 +100,7 @@ def live_roofline(runner, frames, precision, nwin):
                 traffic, tsrc = round(tj["hbm_bytes_per_launch"] / 1e9, 4), f"profiles/{name} (GB per launch)"
                 break
     x3 = [r for r in recs if r.get("x3")]
+    executed = flops + 2.0 * sum(r["flops"] for r in x3)        # split-bf16 launches issue 3 bf16 MFMA products per product
     return {"bound": "mfma", "kernel": "igemm family (implicit-GEMM conv/linear: igemm_kernel, igemm3/4/5, conv3x3_c64)",
             "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
@@ -108,6 +109,8 @@ def live_roofline(runner, frames, precision, nwin):
             "algorithmic_gflop_per_launch": round(flops / n / 1e9, 3), "avg_launch_us": round(t_ms * 1e3 / n, 2),
             "algorithmic_gb_per_window": round(byts / nwin / 1e9, 3), "igemm_ms_per_window": round(t_ms / nwin, 3),
             "split_bf16_launches": len(x3),
+            "executed_mfma_tflops": round(executed / (t_ms * 1e-3) / 1e12, 2),
+            "executed_mfma_frac": round(executed / (t_ms * 1e-3) / 1e12 / peak, 4),
             "split_bf16_note": "algorithmic FLOPs count every product once; split-bf16 launches execute 3 MFMAs per product",
             "split_bf16_algorithmic_tflops": round(sum(r["flops"] for r in x3) / max(1e-9, sum(
                 r["events"][0].elapsed_time(r["events"][1]) for r in x3) * 1e-3) / 1e12, 2) if x3 else None,
@@ -140,7 +143,10 @@ def cpu_baseline(cfg, sd, window_u8, budget_s=30.0, threads=0):
     physical cores, 2 warm-up windows, then the median of up to 5 timed windows - bounded by `budget_s` of CPU work
     (slow hosts get fewer timed windows; the count is reported)."""
     from oracle import pgt_oracle as O      # reported CPU baseline only (never on the product path)
-    cores = threads or _physical_cores()
+    # measured on the GPU box's 2 x 64-core EPYC 9575F (tools/cpu_threads_probe.py, profiles/r2_cpu_threads.jsonl): 32 torch
+    # threads run the eager fp32 oracle 2.7x faster than all 128 physical cores (9.0 s vs 24.3 s per window): the many
+    # small ops of the graph do not scale across two sockets.  The baseline uses the fastest setting found.
+    cores = threads or min(32, _physical_cores())
     torch.set_num_threads(cores)
     x = torch.from_numpy(window_u8.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
     times, warm = [], []

@@ -79,6 +79,14 @@ typedef struct pgt_conv_desc {
      * each), matching the K order [x_hi | x_lo | x_hi].  y is split as well unless out_f32.  Kernel 4 only (bf16 MFMA,
      * Cin % 64 == 0); no SFT epilogue.                                                                              */
     int32_t x_lo, y_lo, r_lo;
+    /* GroupNorm statistics of the output from the conv epilogue (pgt_conv2d_gn): gn_groups > 0 asks every workgroup tile
+     * to write the per-group sum / sum of squares of its outputs (fp32, before the store rounding) into the caller's
+     * statistics workspace - the input of pgt_groupnorm_from_partials, which replaces the separate statistics pass of the
+     * following GroupNorm (TDResnetBlock: conv -> GroupNorm, modules/rstt_layers.py:875-904).  A tensor written by
+     * several launches (the four sub-pixel convolutions of Upsample) uses gn_nsub sub-ranges, this launch being gn_sub.
+     * Needs Cout % 8 == 0, Ho*Wo a multiple of the kernel's tile rows (<= 512), kernels 0, 1, 4, 5, 6, no split-K.      */
+    int32_t gn_groups, gn_sub, gn_nsub;
+    int32_t gn_img0, gn_nimg;   /* this call covers images gn_img0 .. gn_img0+N-1 of a gn_nimg-image tensor (0, 0 = all N) */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -93,6 +101,13 @@ int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* w, const fl
                   const void* residual, const void* sft_dec, const void* sft_shift, void* y,
                   void* workspace, size_t workspace_bytes, pgt_stream_t stream);
 
+/* pgt_conv2d_ws + epilogue GroupNorm statistics (see pgt_conv_desc::gn_groups).  gn_workspace: fp32, 16-byte aligned,
+ * pgt_conv_gn_workspace_bytes(N, nsub, Ho*Wo of one launch, groups) bytes, shared by the gn_nsub launches of a tensor. */
+size_t pgt_conv_gn_workspace_bytes(int32_t N, int32_t nsub, int32_t HWsub, int32_t groups);
+int pgt_conv2d_gn(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
+                  const void* residual, const void* sft_dec, const void* sft_shift, void* y,
+                  float* gn_workspace, void* workspace, size_t workspace_bytes, pgt_stream_t stream);
+
 /* ---- normalisation ---------------------------------------------------------------------------
  * GroupNorm(groups, eps) statistics -> per-(n,c) affine so that GN(x) = x*scale + shift
  * (Normalize(), rstt_layers.py:754-755; normalize(), pgtformer_arch.py:406-407).  Deterministic
@@ -102,6 +117,11 @@ int pgt_groupnorm_affine(int32_t dtype, const void* x, int32_t ldx, int32_t N, i
                          int32_t groups, float eps, const float* gamma, const float* beta,
                          float* scale, float* shift, void* workspace, size_t workspace_bytes,
                          pgt_stream_t stream);
+/* The same per-(n,c) affine from the statistics a producing conv left in `gn_workspace` (pgt_conv2d_gn): fixed-order
+ * reduction in double, no pass over the tensor.  HWsub = output pixels per image of ONE producing launch, nsub launches. */
+int pgt_groupnorm_from_partials(const float* gn_workspace, int32_t N, int32_t nsub, int32_t HWsub, int32_t C,
+                                int32_t groups, float eps, const float* gamma, const float* beta, float* scale,
+                                float* shift, pgt_stream_t stream);
 /* y = act(x * scale[n,c] + shift[n,c])  (GN apply + SiLU/swish, AdaIN apply, eval-BN apply) */
 int pgt_affine_act(int32_t dtype, const void* x, int32_t ldx, void* y, int32_t ldy, int32_t N,
                    int32_t HW, int32_t C, const float* scale, const float* shift, int32_t act,

@@ -227,9 +227,9 @@ class ResBlock(HipModule):
             hbuf = torch.empty((n, hh, ww, self.cpad), device=x_in.device, dtype=x_in.dtype)
             hbuf[..., self.in_channels:].zero_()                     # only the pad channels need the zeros
             self.norm1.run(x_in[..., :self.in_channels], ACT_SILU, out=hbuf[..., :self.in_channels])
-            h = self.conv1.run(hbuf)
+            h = self.conv1.run(hbuf, gn=32)          # norm2's statistics from conv1's epilogue
         else:
-            h = self.conv1.run(self.norm1.run(x_in, ACT_SILU))
+            h = self.conv1.run(self.norm1.run(x_in, ACT_SILU), gn=32)
         h = self.norm2.run(h, ACT_SILU)
         sc = self.conv_out.run(x_in) if self.in_channels != self.out_channels else x_in
         return self.conv2.run(h, res=sc)

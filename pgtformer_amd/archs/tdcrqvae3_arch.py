@@ -48,12 +48,16 @@ class Upsample(HipModule):
 
     def forward(self, x):
         if self.sub_w is None:
-            return self.conv.run(x, ups=True)
+            return self.conv.run(x, ups=True, gn=32)
         n, h, w, _ = x.shape
-        out = torch.empty((n, 2 * h, 2 * w, self.conv.out_channels), device=x.device, dtype=x.dtype)
-        for (py, px), w2 in self.sub_w.items():
-            ops.conv2d(x, w2, self.conv.pb, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, out_parity=(py, px))
-        return out
+        cout = self.conv.out_channels
+        out = torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=x.dtype)
+        # a TDResnetBlock's GroupNorm follows: the four launches share one statistics workspace (4 sub-ranges)
+        st = ops.GnStats(n, 4, h * w, cout, 32, x.device) if (ops.USE_EPILOGUE_GN and ops.gn_ok(n, h * w, cout)) else None
+        for i, ((py, px), w2) in enumerate(self.sub_w.items()):
+            ops.conv2d(x, w2, self.conv.pb, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, out_parity=(py, px),
+                       gn=None if st is None else (st, i))
+        return out if st is None else st.bind(out, cout)
 
 
 class Downsample(HipModule):
@@ -65,7 +69,7 @@ class Downsample(HipModule):
         self.conv = Conv2d(in_channels, in_channels, 3, stride=2, padding=0, pad4=(0, 1, 0, 1))
 
     def forward(self, x):
-        return self.conv.run(x)
+        return self.conv.run(x, gn=32)      # a TDResnetBlock (GroupNorm first) follows every Downsample
 
 
 class VQEmbedding(nn.Embedding, HipModule):
@@ -229,14 +233,11 @@ class Encoder(HipModule):
         return self.num_resolutions
 
     def prepare_split(self, device):
-        """bf16x3 mode: the levels below the first temporal attention (64 / 128 channels at 512^2 / 256^2: HBM-bound, and
-        computed once per FRAME by the overlap-aware driver) stay in exact fp32; from the first attention level on
-        (C >= 256: MFMA-bound) every module runs on split-bf16 operands."""
-        fa = self.first_attn_level()
+        """bf16x3 mode: conv_in (3 input channels: no 64-channel K blocks for the LDS-DMA kernel) stays in exact fp32;
+        every level, the middle blocks and conv_out run on split-bf16 operands (the levels below the first temporal
+        attention are computed once per FRAME by the overlap-aware driver)."""
         prepare_tree(self.conv_in, device, torch.float32)
-        for i, lvl in enumerate(self.down):
-            prepare_tree(lvl, device, torch.float32 if i < fa else X3)
-        for m in (self.mid, self.norm_out, self.conv_out):
+        for m in (self.down, self.mid, self.norm_out, self.conv_out):
             prepare_tree(m, device, X3)
         self.dev, self.dt = device, X3
 
@@ -263,7 +264,8 @@ class Encoder(HipModule):
         Feature maps of split-bf16 levels are returned as their hi planes (bf16 views)."""
         feats = []
         cur = self.conv_in.dt
-        h = self.conv_in.run(x)
+        # (the level-0 block starts with a GroupNorm: statistics from conv_in's epilogue unless a dtype conversion intervenes)
+        h = self.conv_in.run(x, gn=32 if self.down[0].block[0].dt == cur else None)
         per_frame = win is not None
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]
@@ -272,14 +274,18 @@ class Encoder(HipModule):
             h = self._convert(h, cur, lvl.block[0].dt)
             cur = lvl.block[0].dt
             in_place = dst is not None and not _is_x3(cur) and dst.dtype == cur     # the producer can write dst itself
+            top = i_level == self.num_resolutions - 1          # no Downsample after it: mid.block_1 (GroupNorm) follows
             for i_block in range(self.num_res_blocks):
                 last = in_place and i_block == self.num_res_blocks - 1
-                h = lvl.block[i_block](h, out=dst if last and not has_attn and not per_frame else None)
+                fin = i_block == self.num_res_blocks - 1
+                gn_after = not fin or top                        # next op is a TDResnetBlock (another block / mid.block_1)
+                h = lvl.block[i_block](h, out=dst if last and not has_attn and not per_frame else None,
+                                       gn_next=gn_after and not has_attn and not per_frame)
                 if has_attn:
                     if per_frame:
                         h = ops.gather_frames(h, win)
                         per_frame = False
-                    h = lvl.attn[i_block](h, out=dst if last else None)
+                    h = lvl.attn[i_block](h, out=dst if last else None, gn_next=gn_after)
             wanted = return_multi_res_feats and (want_feats is None or i_level in want_feats)
             if not wanted:
                 feats.append(None)
@@ -297,7 +303,7 @@ class Encoder(HipModule):
         if per_frame:
             h = ops.gather_frames(h, win)
         h = self._convert(h, cur, self.mid.block_1.dt)
-        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h), gn_next=True), gn_next=True)
         h = self.conv_out.run(self.norm_out.run(h, ACT_SILU))
         return (h, feats) if return_multi_res_feats else h
 
@@ -344,17 +350,21 @@ class Decoder(HipModule):
         fuse_dst(f_size:str) -> (B*T,h,w,C) view or None: where the level's last block writes the feature map that
         goes into `fuse` (the `dec` slice of the fusion block's concat buffer: no copy later)."""
         self.last_z_shape = z.shape
-        h = self.conv_in.run(z)
-        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        h = self.conv_in.run(z, gn=32)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h), gn_next=True), gn_next=True)
         for i_level in reversed(range(self.num_resolutions)):
             lvl = self.up[i_level]
             dst = None if fuse_dst is None else fuse_dst(str(h.shape[2]))
             for i_block in range(self.num_res_blocks + 1):
-                last = dst is not None and i_block == self.num_res_blocks
+                fin = i_block == self.num_res_blocks
+                last = dst is not None and fin
                 has_attn = len(lvl.attn) > 0
-                h = lvl.block[i_block](h, out=dst if last and not has_attn else None)
+                # a GroupNorm follows unless this is the level's last block (then: fusion / up-sampling conv), except at the
+                # full-resolution level whose last block feeds norm_out
+                gn_after = (not fin) or (i_level == 0 and not self.give_pre_end)
+                h = lvl.block[i_block](h, out=dst if last and not has_attn else None, gn_next=gn_after and not has_attn)
                 if has_attn:
-                    h = lvl.attn[i_block](h, out=dst if last else None)
+                    h = lvl.attn[i_block](h, out=dst if last else None, gn_next=gn_after)
             if fuse is not None:
                 h = fuse(str(h.shape[2]), h)
             if i_level != 0:

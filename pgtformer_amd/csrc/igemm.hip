@@ -220,6 +220,10 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
         const T* res = reinterpret_cast<const T*>(p.res);
         const T* dec = reinterpret_cast<const T*>(p.dec);
         const T* shf = reinterpret_cast<const T*>(p.shift);
+        const bool gn = p.gn_part != nullptr;   // epilogue GroupNorm statistics (uniform)
+        float gs[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gs[e] = 0.f;
         for (int pass = 0; pass < 2; ++pass) {
             if (wm == pass) {
 #pragma unroll
@@ -263,11 +267,16 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     }
                 }
+                if (gn) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gs[8 + e] += v[e] * v[e]; }
+                }
                 if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + out_row(p, m) * p.ldy + n, v);
                 else store8<T>(reinterpret_cast<T*>(p.y) + out_row(p, m) * p.ldy + n, v);
             }
             __syncthreads();
         }
+        if (gn) gn_tile_reduce<BN / 8, 4>(p, gs, stage, tid, m0, n0, BM);
         return;
     }
     T* y = reinterpret_cast<T*>(p.y);
@@ -306,6 +315,9 @@ template <typename T, int BM, int BN> int launch(const ConvP& p0, hipStream_t st
     ConvP p = p0;
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.Cout + BN - 1) / BN;
+    if (p.gn_part)
+        PGT_CHECK(p.vec_epi && p.splitk <= 1 && p.gn_hw % BM == 0 && BN % p.gn_cpg == 0,
+                  "pgt_conv2d: GroupNorm statistics need the 16-byte epilogue, no split-K and HW %% %d == 0 (HW=%d)", BM, p.gn_hw);
     if (p.splitk > 1) {
         if constexpr (BM == 64 && BN == 64)
             hipLaunchKernelGGL((igemm_kernel<T, BM, BN, true>), dim3(p.nbm * p.nbn * p.splitk), dim3(kThreads), 0, st, p);
@@ -392,13 +404,16 @@ template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm,
 
 // number of K slices pgt_conv2d_ws would use for this layer (1 = single pass)
 static int planned_splitk(const pgt_conv_desc* d) {
-    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_BF16X3) return 1;
+    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_BF16X3 || d->gn_groups > 0) return 1;
     const long M = (long)d->N * d->Ho * d->Wo;
     const int K = d->KH * d->KW * d->Cin;
     const int bk = d->dtype == PGT_F32 ? 32 : 64;
     if (d->splitk > 1) return d->splitk <= 16 && (K + bk - 1) / bk >= d->splitk ? d->splitk : 1;
     return choose_splitk(M, d->Cout, K, bk);
 }
+
+// statistics workspace of the call in flight on this thread (set by pgt_conv2d_gn around pgt_conv2d_ws)
+static thread_local float* g_gn_ws = nullptr;
 
 extern "C" size_t pgt_conv2d_workspace_bytes(const pgt_conv_desc* d) {
     if (!d) return 0;
@@ -434,6 +449,24 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.ld_shift = d->ld_shift; p.sft_w = d->sft_w; p.out_f32 = d->out_f32;
     p.M = d->N * d->Ho * d->Wo;
     p.K = d->KH * d->KW * d->Cin * (x3 ? 3 : 1);
+    p.gn_part = nullptr; p.gn_hdr = nullptr; p.gn_cpg = p.gn_G = p.gn_maxblk = p.gn_hw = 0;
+    if (d->gn_groups > 0) {
+        PGT_CHECK(g_gn_ws != nullptr, "pgt_conv2d: gn_groups set without a statistics workspace (use pgt_conv2d_gn)");
+        PGT_CHECK(d->Cout % d->gn_groups == 0 && d->Cout % 8 == 0 && d->gn_nsub >= 1 && d->gn_nsub <= 8 && d->gn_sub >= 0 &&
+                  d->gn_sub < d->gn_nsub, "pgt_conv2d: bad GroupNorm statistics request (Cout=%d groups=%d sub=%d/%d)", d->Cout,
+                  d->gn_groups, d->gn_sub, d->gn_nsub);
+        PGT_CHECK(d->kernel != 2 && d->kernel != 3, "pgt_conv2d: kernels 2 and 3 have no statistics epilogue");
+        const int hw = d->Ho * d->Wo;
+        PGT_CHECK(hw % 64 == 0, "pgt_conv2d: GroupNorm statistics need Ho*Wo %% 64 == 0 (got %d)", hw);
+        p.gn_cpg = d->Cout / d->gn_groups;
+        p.gn_G = d->gn_groups;
+        p.gn_maxblk = hw / 64;
+        p.gn_hw = hw;
+        const int nimg = d->gn_nimg > 0 ? d->gn_nimg : d->N;
+        PGT_CHECK(d->gn_img0 >= 0 && d->gn_img0 + d->N <= nimg, "pgt_conv2d: gn_img0=%d + N=%d exceeds gn_nimg=%d", d->gn_img0, d->N, nimg);
+        p.gn_hdr = g_gn_ws + d->gn_sub;
+        p.gn_part = g_gn_ws + 8 + ((long)d->gn_sub * nimg + d->gn_img0) * p.gn_maxblk * p.gn_G * 2;
+    }
     p.x3 = x3 ? 1 : 0;
     p.xlo = d->x_lo ? d->x_lo : d->Cin;
     p.ylo = d->y_lo ? d->y_lo : d->Cout;
@@ -528,7 +561,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         PGT_CHECK(rc != 1, "pgt_conv2d: kernel=3 tile %dx%d with %d stages is not built", d->force_bm, d->force_bn, d->stages);
         return rc;
     }
-    if (v2_legal && !placed && d->kernel != 1) {
+    if (v2_legal && !placed && d->kernel != 1 && !p.gn_part) {
         const int bn = (d->force_bn == 64 || (d->force_bn == 0 && d->Cout <= 64)) ? 64 : 128;
         const long blocks = (long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
         if (d->kernel == 2 || (d->kernel == 0 && d->force_bm == 0 && d->force_bn == 0 && blocks >= kV2MinBlocks && p.K >= kV2MinK))
@@ -541,4 +574,18 @@ extern "C" int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, 
                           const void* residual, const void* sft_dec, const void* sft_shift, void* y,
                           pgt_stream_t stream) {
     return pgt_conv2d_ws(d, x, w, bias, residual, sft_dec, sft_shift, y, nullptr, 0, stream);
+}
+
+extern "C" size_t pgt_conv_gn_workspace_bytes(int32_t N, int32_t nsub, int32_t HWsub, int32_t groups) {
+    return (8 + (size_t)nsub * N * (HWsub / 64 > 0 ? HWsub / 64 : 1) * groups * 2) * sizeof(float);
+}
+
+extern "C" int pgt_conv2d_gn(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
+                             const void* residual, const void* sft_dec, const void* sft_shift, void* y,
+                             float* gn_workspace, void* workspace, size_t workspace_bytes, pgt_stream_t stream) {
+    PGT_CHECK(d && d->gn_groups > 0 && gn_workspace && (((uintptr_t)gn_workspace) & 15) == 0, "pgt_conv2d_gn: needs gn_groups > 0 and a 16-byte aligned statistics workspace");
+    g_gn_ws = gn_workspace;
+    const int rc = pgt_conv2d_ws(d, x, w, bias, residual, sft_dec, sft_shift, y, workspace, workspace_bytes, stream);
+    g_gn_ws = nullptr;
+    return rc;
 }

@@ -60,7 +60,7 @@ constexpr int lds_bytes4(int wr, int wc) {
     return stages > epi ? stages : epi;
 }
 
-template <int WR, int WC, bool UPS, bool X3 = false>
+template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false>
 __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     static_assert(WR * WC == 8, "8 waves");
     constexpr int BM = WR * 128, BN = WC * 64;
@@ -315,11 +315,11 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     return;
 #endif
 
-    epilogue_128x64<WR, WC, X3>(p, acc, smem, m0, n0, tid, lane, wr, wc);
+    epilogue_128x64<WR, WC, X3, GN>(p, acc, smem, m0, n0, tid, lane, wr, wc);
     PGT_STAMP(3);
 }
 
-template <int WR, int WC, bool UPS, bool X3 = false> int launch4(const ConvP& p0, hipStream_t st) {
+template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false> int launch4(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     constexpr int BM = WR * 128, BN = WC * 64, bytes = lds_bytes4(WR, WC);
     const bool pow2 = (p.Wo & (p.Wo - 1)) == 0 && (p.Ho & (p.Ho - 1)) == 0;
@@ -327,17 +327,18 @@ template <int WR, int WC, bool UPS, bool X3 = false> int launch4(const ConvP& p0
     p.ho_shift = pow2 ? __builtin_ctz(p.Ho) : -1;
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.Cout + BN - 1) / BN;
+    if (GN) PGT_CHECK(p.gn_hw % BM == 0 && BN % p.gn_cpg == 0, "igemm4: GroupNorm statistics need HW %% %d == 0 (HW=%d) and whole groups per tile", BM, p.gn_hw);
     // the attribute is per device and per function: set it once per (device, instantiation), thread-safe
     static std::atomic<unsigned long long> attr_set{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS, X3>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS, X3, GN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { pgt_set_error("igemm4: cannot reserve %d B of LDS: %s", bytes, hipGetErrorString(e)); return -12; }
         attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS, X3>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
+    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS, X3, GN>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -350,8 +351,19 @@ int pgt_igemm4_launch(const void* pv, int bn, hipStream_t st) {
     const ConvP& p = *reinterpret_cast<const ConvP*>(pv);
     if (p.x3) {   // split-bf16 operands (no up-sampled inputs on that path)
         if (p.ups) return 1;
+        if (p.gn_part) {
+            if (bn == 256) return launch4<2, 4, false, true, true>(p, st);
+            if (bn == 128) return launch4<4, 2, false, true, true>(p, st);
+            return 1;
+        }
         if (bn == 256) return launch4<2, 4, false, true>(p, st);
         if (bn == 128) return launch4<4, 2, false, true>(p, st);
+        return 1;
+    }
+    if (p.gn_part) {   // epilogue statistics: plain (not up-sampled) inputs
+        if (p.ups) return 1;
+        if (bn == 256) return launch4<2, 4, false, false, true>(p, st);
+        if (bn == 128) return launch4<4, 2, false, false, true>(p, st);
         return 1;
     }
     if (bn == 256) return p.ups ? launch4<2, 4, true>(p, st) : launch4<2, 4, false>(p, st);

@@ -39,7 +39,52 @@ struct ConvP {
     int orow_mul, orow_xmul, orow_off;   // output row of pixel m (orow_mul = 0: m), see pgt_conv_desc
     int x3;                     // split-bf16 operands: x = [hi | lo] planes, K runs over [x_hi | x_lo | x_hi] per tap
     int xlo, ylo, rlo;          // element offset of the lo plane inside a pixel row of x / y / residual
+    // GroupNorm statistics of the OUTPUT from the epilogue (gn_part != nullptr): every workgroup tile writes the sum and
+    // sum of squares of its outputs per channel group to gn_part[((img * gn_maxblk + k) * gn_G + g) * 2 + {0, 1}], k = the
+    // tile's row block inside the image (gn_hw output pixels per image in this launch, a multiple of the tile rows);
+    // thread 0 of workgroup 0 records the tile rows in *gn_hdr for the finalising kernel (norms.hip).
+    float* gn_part;
+    float* gn_hdr;
+    int gn_cpg, gn_G, gn_maxblk, gn_hw;
 };
+
+// Cross-thread part of the epilogue statistics.  Every thread holds s[0..7] / s[8..15] = sum / sum of squares of the 8
+// channels of ITS chunk column over the tile rows it finished; threads whose (tid % NCOL) agree share a column.
+// `red`: >= NWAVES * NCOL * 16 floats of LDS nobody else uses any more (the epilogue stage after a barrier).
+template <int NCOL, int NWAVES>
+__device__ __forceinline__ void gn_tile_reduce(const ConvP& p, float (&s)[16], float* red, int tid, int m0, int n0, int bm) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off >= NCOL; off >>= 1)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] += __shfl_xor(s[e], off, 64);
+    __syncthreads();
+    if (lane < NCOL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[(wave * NCOL + lane) * 16 + e] = s[e];
+    }
+    __syncthreads();
+    const int cpg = p.gn_cpg;
+    const int ngl = (NCOL * 8) / cpg;                      // channel groups of this tile
+    if (tid < ngl) {
+        const int c0 = tid * cpg;
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < NWAVES; ++w)                   // fixed order: deterministic
+            for (int c = c0; c < c0 + cpg; ++c) {
+                const float* r = red + (w * NCOL + (c >> 3)) * 16 + (c & 7);
+                a += r[0];
+                b += r[8];
+            }
+        if (n0 + c0 < p.Cout) {
+            const int img = m0 / p.gn_hw;
+            const int k = (m0 - img * p.gn_hw) / bm;
+            float* o = p.gn_part + (((long)img * p.gn_maxblk + k) * p.gn_G + (n0 + c0) / cpg) * 2;
+            o[0] = a;
+            o[1] = b;
+        }
+    }
+    if (tid == 0 && blockIdx.x == 0) *p.gn_hdr = (float)bm;
+}
 
 // row index of output pixel m in y (dense, or the sub-pixel placement of pgt_conv_desc::orow_*)
 __device__ __forceinline__ long out_row(const ConvP& p, int m) {

@@ -9,7 +9,8 @@ template <int WR, int WC> constexpr int epi_stage_bytes() { return WR * 64 * (WC
 
 // smem: at least epi_stage_bytes<WR, WC>() bytes, no DMA in flight, all waves past their last fragment read.
 // X3: split-bf16 output (hi at n, lo at n + p.ylo) and split residual (p.rlo); plain epilogue only.
-template <int WR, int WC, bool X3 = false>
+// GN: also reduce the GroupNorm statistics of the tile's outputs (ConvP::gn_*).
+template <int WR, int WC, bool X3 = false, bool GN = false>
 __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&acc)[4][2], char* smem, int m0, int n0,
                                                 int tid, int lane, int wr, int wc) {
     constexpr int BN = WC * 64;
@@ -30,6 +31,9 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
         const int n = n0 + wc * 64 + j * 32 + (lane & 31);
         bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
     }
+    float gs[16];   // GN: per-thread sum / sum of squares of the 8 channels of this thread's chunk column
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gs[e] = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         uint4 pre0[CPT], pre1[CPT];
@@ -94,6 +98,10 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r[e];
                 }
+                if constexpr (GN) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gs[8 + e] += v[e] * v[e]; }
+                }
                 if (!p.out_f32) {
                     uint4 hi, lo;
                     split8(v, hi, lo);
@@ -120,11 +128,16 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
                     for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
             }
+            if constexpr (GN && !X3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gs[8 + e] += v[e] * v[e]; }
+            }
             if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + out_row(p, m) * p.ldy + n, v);
             else store8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + out_row(p, m) * p.ldy + n, v);
         }
         if (pass == 0) __syncthreads();
     }
+    if constexpr (GN) gn_tile_reduce<BN / 8, 8>(p, gs, stage, tid, m0, n0, WR * 128);
 }
 
 }  // namespace

@@ -127,6 +127,49 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, int nblk, int
     }
 }
 
+// The same from the statistics the producing conv's epilogue left behind (igemm_common.h: gn_tile_reduce).  ws = [8 header
+// floats: tile rows of sub-launch s][sub 0: N x maxblk x groups x 2][sub 1 ...], maxblk = HWsub / 64 slots reserved per
+// image of which HWsub / rows are used.  One workgroup per image, one wavefront per group, fixed order, double.
+__global__ void gn_finalize_conv_kernel(const float* __restrict__ ws, int N, int nsub, int HWsub, int C, int groups, float eps,
+                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int n = blockIdx.x;
+    const int cpg = C / groups, maxblk = HWsub / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int g = wv; g < groups; g += nwv) {
+        double a = 0.0, b = 0.0;
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int rows = (int)ws[sub];
+            const int nblk = rows > 0 ? HWsub / rows : 0;
+            const float* part = ws + 8 + (((long)sub * N + n) * maxblk) * groups * 2;
+            for (int k = lane; k < nblk; k += 64) {
+                a += (double)part[((long)k * groups + g) * 2];
+                b += (double)part[((long)k * groups + g) * 2 + 1];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if (lane != 0) continue;
+        const double cnt = (double)nsub * HWsub * cpg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * gamma[c];
+        scale[(long)n * C + c] = sc;
+        shift[(long)n * C + c] = beta[c] - s_mean[g] * sc;
+    }
+}
+
 // Activation of CH values with the (uniform) switch outside the element loop.  bf16 tensors take the hardware
 // exp2 / rcp forms of SiLU and sigmoid (relative error ~1e-6, far below the bf16 rounding of the result: this kernel
 // is otherwise VALU-bound on the IEEE division); fp32 tensors keep the exact expf / division of the parity path.
@@ -462,6 +505,17 @@ extern "C" int pgt_groupnorm_affine(int32_t dtype, const void* x, int32_t ldx, i
     if (dtype == PGT_F32) return gn_affine_impl<float>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream);
     if (dtype == PGT_BF16) return gn_affine_impl<bf16_t>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream);
     PGT_CHECK(false, "groupnorm: bad dtype %d", dtype);
+}
+
+extern "C" int pgt_groupnorm_from_partials(const float* gn_workspace, int32_t N, int32_t nsub, int32_t HWsub, int32_t C,
+                                           int32_t groups, float eps, const float* gamma, const float* beta, float* scale,
+                                           float* shift, pgt_stream_t stream) {
+    PGT_CHECK(gn_workspace && gamma && beta && scale && shift, "groupnorm_from_partials: null argument");
+    PGT_CHECK(C % groups == 0 && groups <= 64 && nsub >= 1 && nsub <= 8 && HWsub % 64 == 0, "groupnorm_from_partials: bad geometry");
+    hipLaunchKernelGGL(gn_finalize_conv_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, gn_workspace, N, nsub, HWsub, C,
+                       groups, eps, gamma, beta, scale, shift);
+    PGT_LAUNCH_CHECK();
+    return 0;
 }
 
 template <typename T, bool X3 = false>

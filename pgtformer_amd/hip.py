@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
                                    "pad_l", "Ho", "Wo", "Cout", "ldy", "act", "post_relu", "ldr", "epi",
                                    "ld_dec", "ld_shift")] + [("sft_w", f32)] + \
                [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue", "kernel", "splitk", "stages",
-                                   "orow_mul", "orow_xmul", "orow_off", "x_lo", "y_lo", "r_lo")]
+                                   "orow_mul", "orow_xmul", "orow_off", "x_lo", "y_lo", "r_lo", "gn_groups", "gn_sub",
+                                   "gn_nsub", "gn_img0", "gn_nimg")]
 
 
 # name -> argtypes (restype is int32 unless listed in _RESTYPES); must cover every symbol of pgt_hip.h
@@ -32,6 +33,9 @@ SIGNATURES = {
     "pgt_conv2d": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp],
     "pgt_conv2d_workspace_bytes": [C.POINTER(ConvDesc)],
     "pgt_conv2d_ws": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+    "pgt_conv_gn_workspace_bytes": [i32, i32, i32, i32],
+    "pgt_conv2d_gn": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+    "pgt_groupnorm_from_partials": [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp],
     "pgt_groupnorm_workspace_bytes": [i32, i32, i32, i32],
     "pgt_groupnorm_affine": [i32, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp],
     "pgt_affine_act": [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp],
@@ -67,7 +71,7 @@ SIGNATURES = {
     "pgt_frame_to_u8": [i32, vp, i32, i32, i32, vp, vp],
 }
 _RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz,
-             "pgt_commit_loss_workspace_bytes": sz,
+             "pgt_commit_loss_workspace_bytes": sz, "pgt_conv_gn_workspace_bytes": sz,
              "pgt_conv2d_workspace_bytes": sz}
 
 

@@ -145,12 +145,14 @@ class TDResnetBlock(HipModule):
         if in_channels != out_channels:
             self.nin_shortcut = Conv2d(in_channels, out_channels, 1)
 
-    def forward(self, x, temb=None, out=None):
-        """out: optional (N,H,W,Cout) view (e.g. a channel slice of a concat buffer) that receives the result."""
-        h = self.conv1.run(self.norm1.run(x, ACT_SILU))
+    def forward(self, x, temb=None, out=None, gn_next=False):
+        """out: optional (N,H,W,Cout) view (e.g. a channel slice of a concat buffer) that receives the result.
+        gn_next: a GroupNorm follows this block - its statistics come out of conv2's epilogue (as norm2's come out of
+        conv1's: SURVEY K1/K7 "statistics from the producer")."""
+        h = self.conv1.run(self.norm1.run(x, ACT_SILU), gn=self.norm2.num_groups)
         h = self.norm2.run(h, ACT_SILU)
         sc = self.nin_shortcut.run(x) if self.in_channels != self.out_channels else x
-        return self.conv2.run(h, res=sc, out=out)
+        return self.conv2.run(h, res=sc, out=out, gn=32 if gn_next else None)
 
 
 class Mlp(HipModule):
@@ -201,8 +203,9 @@ class VSTSREncoderTransformerBlock(HipModule):
         self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, xt, B, H, W, out=None):
-        """xt: (B*D*H*W, C) tokens in (b,d,y,x) order; out: optional (rows, C) view receiving the result."""
+    def forward(self, xt, B, H, W, out=None, gn_images=None):
+        """xt: (B*D*H*W, C) tokens in (b,d,y,x) order; out: optional (rows, C) view receiving the result.
+        gn_images: number of images (B*D) when a GroupNorm follows: fc2's epilogue leaves its statistics."""
         C = self.dim
         win, shift = get_window_size((H, W), self.window_size, self.shift_size)
         x3 = _is_x3(self.dt)
@@ -211,7 +214,7 @@ class VSTSREncoderTransformerBlock(HipModule):
         ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift, x3=x3)
         x1 = self.attn.proj.run(ao, res=xt)
         m = self.mlp.fc1.run(self.norm2.run(x1), act=ACT_GELU)
-        return self.mlp.fc2.run(m, res=x1, out=out)
+        return self.mlp.fc2.run(m, res=x1, out=out, gn=None if gn_images is None else (32, gn_images))
 
 
 class EncoderLayer(HipModule):
@@ -227,13 +230,18 @@ class EncoderLayer(HipModule):
                                          (0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio, qkv_bias)
             for i in range(depth)])
 
-    def forward(self, x, out=None):
-        """x: (B*D, H, W, C) -> same; out: optional (B*D, H, W, C) view (channel slice of a wider buffer) for the result."""
+    def forward(self, x, out=None, gn_next=False):
+        """x: (B*D, H, W, C) -> same; out: optional (B*D, H, W, C) view (channel slice of a wider buffer) for the result.
+        gn_next: a GroupNorm follows (its statistics come out of the last MLP epilogue)."""
         n, h, w, c = x.shape
         assert h % self.window_size[0] == 0 or h <= self.window_size[0]
         xt = x.reshape(n * h * w, c)
         for i, blk in enumerate(self.blocks):
-            last = out is not None and i == len(self.blocks) - 1
+            fin = i == len(self.blocks) - 1
+            last = out is not None and fin
             xt = blk(xt, n // self.num_frames, h, w,
-                     out=out.as_strided((n * h * w, c), (out.stride(2), 1), out.storage_offset()) if last else None)
-        return out if out is not None else xt.reshape(n, h, w, c)
+                     out=out.as_strided((n * h * w, c), (out.stride(2), 1), out.storage_offset()) if last else None,
+                     gn_images=n if (gn_next and fin) else None)
+        y = out if out is not None else xt.reshape(n, h, w, c)
+        st = getattr(xt, "_pgt_gn", None)
+        return y if st is None else st.bind(y, c)

@@ -18,6 +18,32 @@ from .hip import (ACT_GELU, ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SI
 # such operands; reshapes over the leading dims work unchanged, the hi plane `t[..., :C]` is a valid bf16 view of the
 # rounded tensor.
 X3 = "bf16x3"
+# GroupNorm statistics from the producing conv's epilogue (PGT_EPILOGUE_GN=0: always the separate statistics pass)
+import os as _os
+USE_EPILOGUE_GN = _os.environ.get("PGT_EPILOGUE_GN", "1") != "0"
+
+
+class GnStats:
+    """GroupNorm statistics a producing conv left behind (pgt_conv2d_gn): attached to the conv's output tensor object as
+    `._pgt_gn`; the next GroupNorm over exactly that tensor finalises them instead of re-reading the tensor."""
+    __slots__ = ("ws", "n", "nsub", "hw", "c", "groups", "ptr", "ld")
+
+    def __init__(self, n, nsub, hw, c, groups, device):
+        nbytes = hip.lib().pgt_conv_gn_workspace_bytes(n, nsub, hw, groups)
+        self.ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        self.n, self.nsub, self.hw, self.c, self.groups = n, nsub, hw, c, groups
+        self.ptr = self.ld = None
+
+    def bind(self, t, c_stored):
+        """record the tensor the statistics belong to and attach them to it"""
+        self.ptr, self.ld = t.data_ptr(), (tuple(t.shape), c_stored)
+        t._pgt_gn = self
+        return t
+
+
+def gn_ok(n, hw, cout, groups=32):
+    """can a conv producing (n, hw pixels, cout) leave GroupNorm statistics? (tile rows up to 512 must divide hw)"""
+    return groups > 0 and cout % groups == 0 and cout % 8 == 0 and hw % 512 == 0
 
 
 def pack_x3_weight(w3):
@@ -154,14 +180,19 @@ def load_autotune(path):
     return True
 
 
-def _tune_conv(d, args, device, iters=4):
+def _tune_conv(d, args, device, iters=4, gn_ws=None):
     L = hip.lib()
     best, best_t = _TUNE_CANDIDATES[0], None
     for cand in _TUNE_CANDIDATES:
+        if gn_ws is not None and cand[0] in (2, 3):
+            continue       # no statistics epilogue in those kernels
         d.kernel, (d.force_bm, d.force_bn), d.stages = cand
         ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device) if ws_bytes else None
-        call = lambda: L.pgt_conv2d_ws(C.byref(d), *args, _p(ws), ws_bytes, _stream())  # noqa: E731
+        if gn_ws is not None:
+            call = lambda: L.pgt_conv2d_gn(C.byref(d), *args, _p(gn_ws), _p(ws), ws_bytes, _stream())  # noqa: E731
+        else:
+            call = lambda: L.pgt_conv2d_ws(C.byref(d), *args, _p(ws), ws_bytes, _stream())  # noqa: E731
         if call() != 0:
             continue   # variant not legal for this shape
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -178,13 +209,16 @@ def _tune_conv(d, args, device, iters=4):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None, x3=False):
+           out_parity=None, out_rows=None, x3=False, gn=None):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout).
     out_parity=(py, px): write the (N,Ho,Wo,Cout) result to out[:, py::2, px::2, :] of a required (N,2Ho,2Wo,Cout) `out`
     (sub-pixel convolutions; plain epilogue only).
     out_rows=(mul, xmul, off): general form - output pixel m is written to row mul*m + xmul*(m % Wo) + off of `out`
-    (any (..., Cout) view; its pixel stride is the row pitch)."""
+    (any (..., Cout) view; its pixel stride is the row pitch).
+    gn: None, or a number of groups: the epilogue also reduces the GroupNorm statistics of the output, attached to the
+    returned tensor as `._pgt_gn` (ops.GnStats) for the GroupNorm that follows; or (GnStats, sub) when several launches
+    write one tensor (the caller binds the statistics to the tensor after the last launch)."""
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     if x3:   # split-bf16 operands: x (N,H,W,2*Cin) = [hi | lo], w (Cout, kh*kw*3*Cin), y (N,Ho,Wo,2*Cout) unless out_f32
@@ -203,13 +237,17 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         if out is None:
             out = torch.empty((n, ho0, wo0, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
         per = max(1, ((1 << 31) - 1) // (h * wd * _ld_img(x) * x.element_size()))
+        st = None
+        if gn is not None and not isinstance(gn, tuple) and USE_EPILOGUE_GN and gn_ok(n, ho0 * wo0, cout, gn):
+            st = GnStats(n, 1, ho0 * wo0, cout, gn, x.device)
         for i in range(0, n, per):
             sl = slice(i, min(n, i + per))
             conv2d(x[sl], w, bias, kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, act=act,
                    res=None if res is None else res[sl], post_relu=post_relu,
                    sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
-                   tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3)
-        return out
+                   tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3,
+                   gn=None if st is None else (st, 0, i))
+        return out if st is None else st.bind(out, cst)
     hv, wv = (h * 2, wd * 2) if ups else (h, wd)
     ho = (hv + pad[0] + pad[1] - kh) // stride + 1
     wo = (wv + pad[2] + pad[3] - kw) // stride + 1
@@ -237,6 +275,17 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.stages = int(stages)
     if out_rows is not None:
         d.orow_mul, d.orow_xmul, d.orow_off = out_rows
+    st = None        # epilogue GroupNorm statistics
+    if gn is not None:
+        if isinstance(gn, tuple):
+            st, d.gn_sub = gn[0], gn[1]
+            d.gn_img0, d.gn_nimg = (gn[2], st.n) if len(gn) > 2 else (0, 0)
+            assert st.hw == ho * wo and st.c == cout
+        elif (USE_EPILOGUE_GN and gn_ok(n, ho * wo, cout, gn) and not out_f32 and not scalar_epi and kernel in (0, 1, 4, 5, 6)
+              and splitk in (0, 1)):
+            st = GnStats(n, 1, ho * wo, cout, gn, x.device)
+        if st is not None:
+            d.gn_groups, d.gn_nsub = st.groups, st.nsub
     dec = shift = None
     if sft is not None:
         dec, shift, sw = sft
@@ -252,18 +301,25 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     if (AUTOTUNE is not None and kernel == 0 and tile == (0, 0) and splitk == 0 and not scalar_epi
             and x.dtype == torch.bfloat16 and not x3):
         key = (n, h, wd, cin, d.ldx, d.ups, kh, kw, stride, tuple(pad), cout, d.ldy, act, d.post_relu, d.ldr, d.epi,
-               d.ld_dec, d.ld_shift, d.out_f32, bias is None, d.orow_mul, d.orow_xmul, d.orow_off)
+               d.ld_dec, d.ld_shift, d.out_f32, bias is None, d.orow_mul, d.orow_xmul, d.orow_off, d.gn_groups)
         cfg = AUTOTUNE.get(key)
         if cfg is None and not torch.cuda.is_current_stream_capturing():
             if L.pgt_conv2d_workspace_bytes(C.byref(d)):
                 cfg = AUTOTUNE[key] = (0, (0, 0), 0)   # split-K layer: every candidate would time the same split-K path
             else:
-                cfg = AUTOTUNE[key] = _tune_conv(d, (_p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out)), x.device)
+                cfg = AUTOTUNE[key] = _tune_conv(d, (_p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out)), x.device,
+                                                 gn_ws=None if st is None else st.ws)
         d.kernel, (d.force_bm, d.force_bn), d.stages = cfg if cfg is not None else (0, (0, 0), 0)
     ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None   # split-K scratch
-    hip.check(L.pgt_conv2d_ws(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out), _p(ws),
-                              ws_bytes, _stream()), "pgt_conv2d")
+    if st is not None:
+        hip.check(L.pgt_conv2d_gn(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out), _p(st.ws), _p(ws),
+                                  ws_bytes, _stream()), "pgt_conv2d_gn")
+        if not isinstance(gn, tuple):
+            st.bind(out, cst)
+    else:
+        hip.check(L.pgt_conv2d_ws(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out), _p(ws),
+                                  ws_bytes, _stream()), "pgt_conv2d")
     if prof is not None:
         e1.record()
         m = n * ho * wo
@@ -276,23 +332,40 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     return out
 
 
-def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False):
-    """x: (rows, Cin) -> (rows, Cout); x3: split-bf16 rows (rows, 2*Cin) -> (rows, 2*Cout) (or fp32 (rows, Cout))."""
+def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False, gn=None):
+    """x: (rows, Cin) -> (rows, Cout); x3: split-bf16 rows (rows, 2*Cin) -> (rows, 2*Cout) (or fp32 (rows, Cout)).
+    gn=(groups, n_images): the rows are n_images images of rows / n_images tokens each; the epilogue leaves the GroupNorm
+    statistics of the output per image (attached to the returned tensor, see conv2d)."""
     rows, cin = x.shape
-    x4 = x.as_strided((1, 1, rows, cin), (0, 0, _ld_rows(x), 1))
     cst = w.shape[0] * (2 if x3 and not out_f32 else 1)
     if out is None:
         out = torch.empty((rows, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
-    o4 = out.as_strided((1, 1, rows, cst), (0, 0, _ld_rows(out), 1))
-    r4 = None if res is None else res.as_strided((1, 1, rows, cst), (0, 0, _ld_rows(res), 1))
-    conv2d(x4, w, bias, act=act, res=r4, out=o4, out_f32=out_f32, x3=x3)
-    return out
+    nimg = gn[1] if gn is not None else 1
+    assert rows % nimg == 0
+    hw = rows // nimg
+    x4 = x.as_strided((nimg, 1, hw, cin), (hw * _ld_rows(x), 0, _ld_rows(x), 1))
+    o4 = out.as_strided((nimg, 1, hw, cst), (hw * _ld_rows(out), 0, _ld_rows(out), 1))
+    r4 = None if res is None else res.as_strided((nimg, 1, hw, cst), (hw * _ld_rows(res), 0, _ld_rows(res), 1))
+    o4 = conv2d(x4, w, bias, act=act, res=r4, out=o4, out_f32=out_f32, x3=x3, gn=None if gn is None else gn[0])
+    st = getattr(o4, "_pgt_gn", None)
+    return out if st is None else st.bind(out, cst)
 
 
 def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6, x3=False):
-    """GroupNorm statistics of x (N,H,W,C) folded with gamma/beta -> (scale, shift) fp32 (N,C)."""
+    """GroupNorm statistics of x (N,H,W,C) folded with gamma/beta -> (scale, shift) fp32 (N,C).  When the conv that produced
+    x left its statistics (x._pgt_gn, ops.GnStats) they are finalised instead of re-reading x."""
     n, h, w, c = x.shape
     L = hip.lib()
+    st = getattr(x, "_pgt_gn", None)
+    if st is not None and USE_EPILOGUE_GN:
+        cl = c // 2 if x3 else c
+        if (st.ptr == x.data_ptr() and st.n == n and st.nsub * st.hw == h * w and st.c == cl and st.groups == groups
+                and st.ld[1] == c):
+            scale = torch.empty((n, cl), dtype=torch.float32, device=x.device)
+            shift = torch.empty((n, cl), dtype=torch.float32, device=x.device)
+            hip.check(L.pgt_groupnorm_from_partials(_p(st.ws), n, st.nsub, st.hw, cl, groups, eps, _p(gamma), _p(beta), _p(scale),
+                                                    _p(shift), _stream()), "pgt_groupnorm_from_partials")
+            return scale, shift
     if x3:
         c //= 2
         nbytes = L.pgt_groupnorm_workspace_bytes(n, h * w, c, groups)

@@ -81,7 +81,7 @@ def _store(val, out, dtype):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None, x3=False):
+           out_parity=None, out_rows=None, x3=False, gn=None):
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     if x3:
@@ -122,7 +122,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     return _store(y, out, torch.float32 if out_f32 else x.dtype)
 
 
-def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False):
+def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False, gn=None):
     if x3:
         x, w = _merge(x), _unpack_x3_weight(w, 1)
         res = None if res is None else _merge(res)
@@ -380,3 +380,4 @@ def install(monkeypatch):
     me = sys.modules[__name__]
     for name in ALL:
         monkeypatch.setattr(real, name, getattr(me, name))
+    monkeypatch.setattr(real, "USE_EPILOGUE_GN", False)   # the emulated convs leave no epilogue statistics

@@ -558,3 +558,110 @@ def test_conv2d_output_parity_placement(kernel):
     check(f"parity_k{kernel}", out, ref, dtype)
     full = E.conv2d(x, w3.reshape(cout, -1).to(dtype), b, kh=3, kw=3, pad=(1, 1, 1, 1), ups=True)
     check(f"parity_vs_ups_k{kernel}", out, full, dtype, 2.0)   # merged taps are rounded to bf16 once, not three times
+
+
+# ------------------------------------------------------------------------------------------------
+# GroupNorm statistics from the producing conv's epilogue (pgt_conv2d_gn + pgt_groupnorm_from_partials)
+GN_CASES = [
+    # name, N,H,W,Cin,Cout,k, kernel, tile
+    ("gn_v1_64", 3, 32, 32, 64, 64, 3, 1, (64, 64)),
+    ("gn_v1_128x128", 2, 32, 32, 64, 128, 3, 1, (128, 128)),
+    ("gn_v4_256", 2, 32, 32, 128, 256, 3, 4, (0, 256)),
+    ("gn_v4_512x128", 2, 32, 32, 128, 128, 3, 4, (0, 128)),
+    ("gn_v5", 2, 32, 32, 256, 256, 3, 5, (0, 0)),
+    ("gn_v6", 3, 32, 32, 64, 64, 3, 6, (0, 0)),
+    ("gn_auto_512", 2, 32, 32, 512, 512, 1, 0, (0, 0)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", GN_CASES, ids=[c[0] for c in GN_CASES])
+def test_conv_epilogue_groupnorm_statistics(dtype, case):
+    """The conv epilogue's per-group sum / sum of squares, finalised by pgt_groupnorm_from_partials, give the same GroupNorm
+    coefficients as the separate statistics pass over the stored output (reference: Normalize, rstt_layers.py:754-755)."""
+    name, n, h, w_, cin, cout, k, kernel, tile = case
+    if dtype == torch.float32 and kernel != 1:
+        pytest.skip("fp32 runs on the register-staged kernel only")
+    O = ops()
+    x = rnd((n, h, w_, cin), 200, dtype)
+    wt = rnd((cout, k * k * cin), 201, dtype, 1.0 / np.sqrt(k * k * cin))
+    b = rnd((cout,), 202, torch.float32, 0.3)
+    res = rnd((n, h, w_, cout), 203, dtype)
+    gam, bet = 1 + 0.1 * rnd((cout,), 204), 0.1 * rnd((cout,), 205)
+    kw = dict(kh=k, kw=k, pad=(k // 2,) * 4, act=E.ACT_SILU, res=g(res), kernel=kernel, tile=tile)
+    y = O.conv2d(g(x), g(wt), g(b), gn=32, **kw)
+    st = getattr(y, "_pgt_gn", None)
+    assert st is not None and st.groups == 32 and st.hw == h * w_
+    plain = O.conv2d(g(x), g(wt), g(b), **kw)
+    assert torch.equal(y, plain)                                        # the statistics do not touch the outputs
+    s_e, b_e = O.groupnorm_affine(y, g(gam), g(bet))                    # from the epilogue statistics
+    s_p, b_p = O.groupnorm_affine(plain, g(gam), g(bet))                # separate pass over the stored tensor
+    s_w, b_w = E.groupnorm_affine(y.float().cpu(), gam, bet)
+    tol = 1.0 if dtype == torch.float32 else 20.0                       # bf16: statistics of the un-rounded fp32 outputs
+    check(f"{name}_scale", s_e, s_w, torch.float32, tol)
+    check(f"{name}_shift", b_e, b_w, torch.float32, tol)
+    check(f"{name}_scale_vs_pass", s_e, s_p, torch.float32, tol)
+    again = O.groupnorm_affine(O.conv2d(g(x), g(wt), g(b), gn=32, **kw), g(gam), g(bet))
+    assert torch.equal(again[0], s_e) and torch.equal(again[1], b_e)    # deterministic
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_epilogue_statistics_linear_and_subpixel_and_x3(dtype):
+    O = ops()
+    # linear: rows = 3 images x 1024 tokens
+    x, wt, b = rnd((3072, 256), 210, dtype), rnd((256, 256), 211, dtype, 1 / 16), rnd((256,), 212)
+    res = rnd((3072, 256), 213, dtype)
+    gam, bet = 1 + 0.1 * rnd((256,), 214), 0.1 * rnd((256,), 215)
+    y = O.linear(g(x), g(wt), g(b), res=g(res), gn=(32, 3))
+    assert getattr(y, "_pgt_gn", None) is not None
+    y4 = y.reshape(3, 32, 32, 256)
+    y._pgt_gn.bind(y4, 256)
+    s_e, b_e = O.groupnorm_affine(y4, g(gam), g(bet))
+    s_w, b_w = E.groupnorm_affine(y4.float().cpu(), gam, bet)
+    check("gn_linear_scale", s_e, s_w, torch.float32, 20.0)
+    check("gn_linear_shift", b_e, b_w, torch.float32, 20.0)
+    # the four sub-pixel convolutions of Upsample write one tensor: 4 statistics sub-ranges
+    from pgtformer_amd.archs.tdcrqvae3_arch import Upsample
+    torch.manual_seed(5)
+    up = Upsample(128, True)
+    up.prepare(DEV, dtype)
+    xin = rnd((2, 32, 32, 128), 216, dtype)
+    out = up(g(xin))
+    st = getattr(out, "_pgt_gn", None)
+    assert st is not None and st.nsub == 4 and out.shape == (2, 64, 64, 128)
+    gam, bet = 1 + 0.1 * rnd((128,), 217), 0.1 * rnd((128,), 218)
+    s_e, b_e = O.groupnorm_affine(out, g(gam), g(bet))
+    s_w, b_w = E.groupnorm_affine(out.float().cpu(), gam, bet)
+    check("gn_subpixel_scale", s_e, s_w, torch.float32, 20.0)
+    check("gn_subpixel_shift", b_e, b_w, torch.float32, 20.0)
+    # split-bf16 conv
+    xs = E.to_x3(rnd((2, 32, 32, 128), 219))
+    w3 = O.pack_x3_weight(rnd((256, 9, 128), 220, 1 / 34))
+    ys = O.conv2d(g(xs), g(w3), None, kh=3, kw=3, pad=(1, 1, 1, 1), x3=True, gn=32)
+    assert getattr(ys, "_pgt_gn", None) is not None
+    gam, bet = 1 + 0.1 * rnd((256,), 221), 0.1 * rnd((256,), 222)
+    s_e, b_e = O.groupnorm_affine(ys, g(gam), g(bet), x3=True)
+    s_w, b_w = E.groupnorm_affine(ys.cpu(), gam, bet, x3=True)
+    check("gn_x3_scale", s_e, s_w, torch.float32, 5.0)
+    check("gn_x3_shift", b_e, b_w, torch.float32, 5.0)
+
+
+def test_model_with_and_without_epilogue_statistics(monkeypatch):
+    """Whole TDResnetBlock / decoder-style chain: epilogue statistics on vs off (PGT_EPILOGUE_GN=0) agree to the rounding of
+    the statistics (bf16: the stored tensor vs its un-rounded fp32 values)."""
+    import pgtformer_amd.ops as O
+    from pgtformer_amd.modules.rstt_layers import TDResnetBlock
+    torch.manual_seed(7)
+    blk = TDResnetBlock(in_channels=128, out_channels=256)
+    for p_ in blk.parameters():
+        torch.nn.init.normal_(p_, std=0.05)
+    x = rnd((3, 32, 32, 128), 230)
+    for dtype in DTYPES:
+        blk.prepare(DEV, dtype)
+        on = blk(g(x.to(dtype)), gn_next=True)
+        assert getattr(on, "_pgt_gn", None) is not None
+        monkeypatch.setattr(O, "USE_EPILOGUE_GN", False)
+        off = blk(g(x.to(dtype)), gn_next=True)
+        monkeypatch.setattr(O, "USE_EPILOGUE_GN", True)
+        assert getattr(off, "_pgt_gn", None) is None
+        check(f"block_gn_on_vs_off_{dtype}", on, off, dtype, 0.5)

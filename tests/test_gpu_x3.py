@@ -74,6 +74,9 @@ X3_CONV = [
     ("x3_c1x1_nin", 3, 16, 16, 128, 256, 1, 1, (0, 0, 0, 0)),
     ("x3_c3x3_512_ragged", 1, 9, 7, 512, 200, 3, 1, (1, 1, 1, 1)),
     ("x3_c3x3_cout128", 2, 24, 24, 64, 128, 3, 1, (1, 1, 1, 1)),
+    ("x3_c3x3_64_64", 2, 32, 32, 64, 64, 3, 1, (1, 1, 1, 1)),
+    ("x3_c3x3_64_64_s2", 2, 32, 32, 64, 64, 3, 2, (0, 1, 0, 1)),
+    ("x3_c1x1_64_128", 2, 16, 16, 64, 128, 1, 1, (0, 0, 0, 0)),
 ]
 
 
@@ -118,7 +121,7 @@ def test_linear_x3(shape):
     check(f"linear_x3_f32out{shape}", got32, E.linear(xs, ws, None, out_f32=True, x3=True))
 
 
-@pytest.mark.parametrize("shape", [(3, 24, 24, 256), (2, 9, 7, 512), (3, 16, 16, 128)])
+@pytest.mark.parametrize("shape", [(3, 24, 24, 256), (2, 9, 7, 512), (3, 16, 16, 128), (2, 40, 40, 64)])
 def test_groupnorm_silu_x3(shape):
     x = rnd(shape, 30) * 1.5 + 0.4
     gam, bet = 1 + 0.1 * rnd((shape[3],), 31), 0.1 * rnd((shape[3],), 32)
