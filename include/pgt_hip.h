@@ -84,9 +84,11 @@ typedef struct pgt_conv_desc {
      * statistics workspace - the input of pgt_groupnorm_from_partials, which replaces the separate statistics pass of the
      * following GroupNorm (TDResnetBlock: conv -> GroupNorm, modules/rstt_layers.py:875-904).  A tensor written by
      * several launches (the four sub-pixel convolutions of Upsample) uses gn_nsub sub-ranges, this launch being gn_sub.
-     * Needs Cout % 8 == 0, Ho*Wo a multiple of the kernel's tile rows (<= 512), kernels 0, 1, 4, 5, 6, no split-K.      */
+     * Needs Cout % 8 == 0, Ho*Wo a multiple of the kernel's tile rows (<= 512), kernels 0, 1, 4, no split-K.            */
     int32_t gn_groups, gn_sub, gn_nsub;
     int32_t gn_img0, gn_nimg;   /* this call covers images gn_img0 .. gn_img0+N-1 of a gn_nimg-image tensor (0, 0 = all N) */
+    int32_t res_f32;            /* PGT_BF16X3 with out_f32: the residual is fp32 as well (ldr in floats) - split-bf16
+                                 * ARITHMETIC on tensors that are stored in fp32 (BiSeNet's BasicBlocks)              */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,

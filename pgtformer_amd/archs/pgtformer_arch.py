@@ -174,6 +174,20 @@ class BiSeNet(HipModule):
         self.conv_out16 = BiSeNetOutput(128, 64, n_classes)
         self.conv_out32 = BiSeNetOutput(128, 64, n_classes)
 
+    def prepare_x3f(self, device):
+        """bf16x3 mode: tensors stay fp32 (the glue kernels - max-pool, gates, resizes - are fp32 kernels) but every conv
+        whose shape fits the split-bf16 LDS-DMA kernel (Cin % 64 == 0, Cout % 8 == 0, no fused up-sampling, a dense fp32
+        output) multiplies on 3 bf16 MFMAs per product instead of the fp32 MFMA (1/16 of the bf16 rate)."""
+        from ..modules.rstt_layers import prepare_tree
+        from ..ops import X3F
+        prepare_tree(self, device, torch.float32)
+        skip = {id(self.cp.conv_head32.conv), id(self.cp.conv_head16.conv),                 # nearest x2 fused in the gather
+                id(self.conv_out.conv_out), id(self.conv_out16.conv_out), id(self.conv_out32.conv_out)}   # 19-channel slices
+        for m in self.modules():
+            if isinstance(m, Conv2d) and id(m) not in skip and m.in_channels % 64 == 0 and m.out_channels % 8 == 0:
+                m.dt = X3F
+                m._pack(device, X3F)
+
     def forward(self, x):
         """x: (N,512,512,8) ImageNet-normalised -> (N,32,32,64): 3*n_classes parsing logits + zero pad."""
         nc = self.n_classes

@@ -488,6 +488,8 @@ class TDCRQVAE3(HubMixin, HipModule):
                 prepare_tree(child, self.dev, self.enc_dt)
             elif name == "encoder":
                 child.prepare_split(self.dev)
+            elif name == "conditionnet":
+                child.prepare_x3f(self.dev)
             elif name in self.F32_IN_X3:
                 prepare_tree(child, self.dev, torch.float32)
             else:

@@ -455,7 +455,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         PGT_CHECK(d->Cout % d->gn_groups == 0 && d->Cout % 8 == 0 && d->gn_nsub >= 1 && d->gn_nsub <= 8 && d->gn_sub >= 0 &&
                   d->gn_sub < d->gn_nsub, "pgt_conv2d: bad GroupNorm statistics request (Cout=%d groups=%d sub=%d/%d)", d->Cout,
                   d->gn_groups, d->gn_sub, d->gn_nsub);
-        PGT_CHECK(d->kernel != 2 && d->kernel != 3, "pgt_conv2d: kernels 2 and 3 have no statistics epilogue");
+        PGT_CHECK(d->kernel == 0 || d->kernel == 1 || d->kernel == 4, "pgt_conv2d: the statistics epilogue exists in kernels 1 and 4 (kernel=%d)", d->kernel);
         const int hw = d->Ho * d->Wo;
         PGT_CHECK(hw % 64 == 0, "pgt_conv2d: GroupNorm statistics need Ho*Wo %% 64 == 0 (got %d)", hw);
         p.gn_cpg = d->Cout / d->gn_groups;
@@ -468,6 +468,8 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         p.gn_part = g_gn_ws + 8 + ((long)d->gn_sub * nimg + d->gn_img0) * p.gn_maxblk * p.gn_G * 2;
     }
     p.x3 = x3 ? 1 : 0;
+    p.res_f32 = (x3 && d->res_f32) ? 1 : 0;
+    PGT_CHECK(!d->res_f32 || (x3 && d->out_f32), "pgt_conv2d: res_f32 goes with dtype PGT_BF16X3 and out_f32");
     p.xlo = d->x_lo ? d->x_lo : d->Cin;
     p.ylo = d->y_lo ? d->y_lo : d->Cout;
     p.rlo = d->r_lo ? d->r_lo : d->Cout;
@@ -489,7 +491,8 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
                   "pgt_conv2d: bf16x3 needs Cin %% 64 == 0 (Cin=%d), no up-sampling, the plain epilogue", d->Cin);
         PGT_CHECK(d->ldx >= p.xlo + d->Cin && p.xlo % 8 == 0 && p.xlo >= d->Cin, "pgt_conv2d: bf16x3 x_lo=%d / ldx=%d do not hold [hi | lo] planes of %d channels", p.xlo, d->ldx, d->Cin);
         PGT_CHECK(d->out_f32 || (d->ldy >= p.ylo + d->Cout && p.ylo % 8 == 0 && p.ylo >= d->Cout), "pgt_conv2d: bf16x3 y_lo=%d / ldy=%d do not hold [hi | lo] planes of %d channels", p.ylo, d->ldy, d->Cout);
-        PGT_CHECK(!residual || (d->ldr >= p.rlo + d->Cout && p.rlo % 8 == 0), "pgt_conv2d: bf16x3 residual planes");
+        PGT_CHECK(!residual || p.res_f32 || (d->ldr >= p.rlo + d->Cout && p.rlo % 8 == 0), "pgt_conv2d: bf16x3 residual planes");
+        PGT_CHECK(!residual || !p.res_f32 || d->ldr % 4 == 0, "pgt_conv2d: fp32 residual rows must be 16-byte aligned");
         PGT_CHECK(p.vec_epi && (long)d->Cout * p.K * 2 < (1L << 31), "pgt_conv2d: bf16x3 needs Cout %% 8 == 0, 16-byte aligned rows and weights < 2 GiB");
         const int rc = pgt_igemm4_launch(&p, d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256), st);
         PGT_CHECK(rc != 1, "pgt_conv2d: bf16x3 has no %d-column tile (128, 256)", d->force_bn);

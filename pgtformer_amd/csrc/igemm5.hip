@@ -76,7 +76,6 @@ constexpr int newest5(int p) {
 // byte offset of (row e, 16-byte chunk c) in the extended A image
 __device__ __forceinline__ int swzx(int e, int c) { return e * 128 + ((c ^ ((e >> 1) & 7)) << 4); }
 
-template <bool GN>
 __global__ __launch_bounds__(512) void igemm5_kernel(ConvP p) {
     constexpr unsigned kOob = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // kLds5 bytes
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(ConvP p) {
     PGT_VMWAIT(0);
     __syncthreads();
     PGT_STAMP(2);
-    epilogue_128x64<2, 4, false, GN>(p, acc, smem, m0, n0, tid, lane, wr, wc);
+    epilogue_128x64<2, 4>(p, acc, smem, m0, n0, tid, lane, wr, wc);
     PGT_STAMP(3);
 }
 
@@ -313,19 +312,12 @@ int pgt_igemm5_launch(const void* pv, hipStream_t st) {
     p.nbn = (p.Cout + 255) / 256;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm5_kernel<false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm5_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds5);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm5_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds5);
         if (e != hipSuccess) { pgt_set_error("igemm5: cannot reserve %d B of LDS: %s", kLds5, hipGetErrorString(e)); return -12; }
         attr_set = true;
     }
-    if (p.gn_part) {
-        PGT_CHECK(p.gn_hw % 256 == 0 && 256 % p.gn_cpg == 0, "igemm5: GroupNorm statistics need HW %% 256 == 0 (HW=%d)", p.gn_hw);
-        hipLaunchKernelGGL(igemm5_kernel<true>, dim3(p.nbm * p.nbn), dim3(512), kLds5, st, p);
-    } else {
-        hipLaunchKernelGGL(igemm5_kernel<false>, dim3(p.nbm * p.nbn), dim3(512), kLds5, st, p);
-    }
+    hipLaunchKernelGGL(igemm5_kernel, dim3(p.nbm * p.nbn), dim3(512), kLds5, st, p);
     PGT_LAUNCH_CHECK();
     return 0;
 }

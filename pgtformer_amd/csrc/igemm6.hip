@@ -26,7 +26,6 @@ static_assert(128 * kSRow * 4 <= kLds6, "epilogue stage must fit");
 
 __device__ __forceinline__ int swz6(int e, int c) { return e * 128 + ((c ^ ((e >> 1) & 7)) << 4); }
 
-template <bool GN>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles) {
     constexpr unsigned kOob = 0x80000000u;
     __shared__ __attribute__((aligned(1024))) char smem[kLds6];
@@ -184,59 +183,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
                     for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
             }
-            if constexpr (GN) {   // final values back into the thread's own stage chunk: the statistics pass below reads them
-                *reinterpret_cast<float4*>(stage + rl * kSRow + c8) = *reinterpret_cast<const float4*>(v);
-                *reinterpret_cast<float4*>(stage + rl * kSRow + c8 + 4) = *reinterpret_cast<const float4*>(v + 4);
-            }
             if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + c8, v);
             else store8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + c8, v);
-        }
-        if constexpr (GN) {
-            // gn_tile_reduce, with the header written once per launch: the tile walk is persistent, so "workgroup 0" is
-            // the one that owns tile 0.  Statistics in a second, register-light sweep over the thread's OWN chunks (the
-            // 144 weight registers stay live across tiles): sum / sum of squares of chunk column tid & 7 over its 4 rows.
-            float gs[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) gs[e] = 0.f;
-            for (int cidx = tid; cidx < 128 * 8; cidx += 256) {
-                const int rl = cidx >> 3, c8 = (cidx & 7) * 8;
-                if (m0 + rl >= p.M || c8 >= p.Cout) continue;
-                float v[8];
-                *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * kSRow + c8);
-                *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * kSRow + c8 + 4);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gs[8 + e] += v[e] * v[e]; }
-            }
-            const int lane6 = tid & 63, wave6 = tid >> 6;
-#pragma unroll
-            for (int off = 32; off >= 8; off >>= 1)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) gs[e] += __shfl_xor(gs[e], off, 64);
-            __syncthreads();
-            if (lane6 < 8) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) stage[(wave6 * 8 + lane6) * 16 + e] = gs[e];
-            }
-            __syncthreads();
-            const int cpg = p.gn_cpg;
-            if (tid < 64 / cpg) {
-                const int c0 = tid * cpg;
-                float a = 0.f, b = 0.f;
-                for (int w = 0; w < 4; ++w)
-                    for (int c = c0; c < c0 + cpg; ++c) {
-                        const float* r = stage + (w * 8 + (c >> 3)) * 16 + (c & 7);
-                        a += r[0];
-                        b += r[8];
-                    }
-                if (c0 < p.Cout) {
-                    const int img = m0 / p.gn_hw;
-                    const int k = (m0 - img * p.gn_hw) >> 7;
-                    float* o = p.gn_part + (((long)img * p.gn_maxblk + k) * p.gn_G + c0 / cpg) * 2;
-                    o[0] = a;
-                    o[1] = b;
-                }
-            }
-            if (tid == 0 && tile == 0) *p.gn_hdr = 128.f;
         }
     }
 }
@@ -260,12 +208,7 @@ int pgt_igemm6_launch(const void* pv, hipStream_t st) {
         n_cu = prop.multiProcessorCount;
     }
     const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
-    if (p.gn_part) {
-        PGT_CHECK(p.vec_epi && p.gn_hw % 128 == 0 && 64 % p.gn_cpg == 0, "igemm6: GroupNorm statistics need the 16-byte epilogue and HW %% 128 == 0");
-        hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(grid), dim3(256), 0, st, p, ntiles);
-    } else {
-        hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(grid), dim3(256), 0, st, p, ntiles);
-    }
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), 0, st, p, ntiles);
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -45,7 +45,11 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
             pre0[c] = pre1[c] = make_uint4(0, 0, 0, 0);
             if (m < p.M && n < p.Cout) {
                 if (X3) {
-                    if (res) {
+                    if (res && p.res_f32) {      // 8 floats = 2 x 16 bytes
+                        const float* rf = reinterpret_cast<const float*>(p.res) + (long)m * p.ldr + n;
+                        pre0[c] = *reinterpret_cast<const uint4*>(rf);
+                        pre1[c] = *reinterpret_cast<const uint4*>(rf + 4);
+                    } else if (res) {
                         pre0[c] = *reinterpret_cast<const uint4*>(res + (long)m * p.ldr + n);
                         pre1[c] = *reinterpret_cast<const uint4*>(res + (long)m * p.ldr + p.rlo + n);
                     }
@@ -94,9 +98,18 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
             if (X3) {
                 if (res) {
                     float r[8];
-                    merge8(pre0[c], pre1[c], r);
+                    if (p.res_f32) {
+                        Vec16<float>::unpack(pre0[c], r);
+                        Vec16<float>::unpack(pre1[c], r + 4);
+                    } else {
+                        merge8(pre0[c], pre1[c], r);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                if (p.post_relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
                 if constexpr (GN) {
 #pragma unroll

@@ -16,8 +16,11 @@
 // 32 codes, the next block prefetched into registers while the current one is multiplied.  The k order of the
 // contraction (ascending 16-element steps, fp32 accumulation) is that of the implicit-GEMM kernels, so the dot
 // products - and therefore the codes - are bit-identical to the two-kernel form.
+#include <atomic>
+
 #include "common.h"
 #include "pgt_internal.h"
+#include "igemm_common.h"
 
 namespace {
 
@@ -111,6 +114,79 @@ __global__ __launch_bounds__(256) void rq_nearest_mfma_kernel(const uint16_t* __
     if (tok_ok && h == 0) codes[t] = bi;
 }
 
+// D = 512 (the model's embedding width): one codebook row is exactly one 1-KiB LDS-DMA (64 lanes x 16 bytes), so the
+// codebook streams global -> LDS without passing through registers, double-buffered: block cb+1 is in flight while block
+// cb is multiplied, one barrier per block, no staging stores.  |e|^2 of all codes sits in LDS for the whole kernel.
+__global__ __launch_bounds__(256) void rq_nearest_dma512_kernel(const uint16_t* __restrict__ x, int ldx,
+                                                                const uint16_t* __restrict__ book, const float* __restrict__ xnorm,
+                                                                const float* __restrict__ enorm, int rows, int K, int nb,
+                                                                int* __restrict__ codes) {
+    constexpr int D = 512, KS = D / 16, RSTR = D * 2 + 16, BUF = 32 * RSTR;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 * BUF bytes of code rows, then nb * 32 floats |e|^2
+    float* en_all = reinterpret_cast<float*>(smem + 2 * BUF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int t = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool tok_ok = t < rows;
+    const unsigned lds0 = lds_addr(smem);
+
+    auto issue = [&](int cb, int buf) {   // this wave's 8 rows of code block cb -> stage buf
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i;
+            int code = cb * 32 + r;
+            code = code < K ? code : K - 1;             // ragged last block: any valid row, masked by |e|^2 = +inf below
+            glds16(book + (long)code * D + lane * 8, lds0 + buf * BUF + r * RSTR);
+        }
+    };
+    issue(0, 0);
+    for (int j = tid; j < nb * 32; j += 256) en_all[j] = j < K ? enorm[j] : INFINITY;
+
+    uint4 xf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        xf[s] = make_uint4(0, 0, 0, 0);
+        if (tok_ok) xf[s] = *reinterpret_cast<const uint4*>(x + (long)t * ldx + s * 16 + h * 8);
+    }
+    const float x2 = tok_ok ? xnorm[t] : 0.f;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int cb = 0; cb < nb; ++cb) {
+        const int buf = cb & 1;
+        if (cb + 1 < nb) issue(cb + 1, buf ^ 1);       // every wave left stage buf^1 behind the barrier of block cb-1
+        const char* e_rd = smem + buf * BUF + (lane & 31) * RSTR + h * 16;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const uint4 a = *reinterpret_cast<const uint4*>(e_rd + s * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, xf[s]),
+                                                          acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 en4 = *reinterpret_cast<const float4*>(en_all + cb * 32 + 8 * g4 + 4 * h);
+            const float en[4] = {en4.x, en4.y, en4.z, en4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (x2 + en[r]) - 2.0f * acc[4 * g4 + r];
+                const int j = cb * 32 + 8 * g4 + 4 * h + r;
+                if (v < best) { best = v; bi = j; }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of block cb+1 have landed
+        __syncthreads();                                   // ... everybody's have, and everybody is done reading stage buf
+    }
+    const float ob = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(bi, 32, 64);
+    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    if (tok_ok && h == 0) codes[t] = bi;
+}
+
 }  // namespace
 
 // bf16 tokens x (rows, D) and codebook (K, D) bf16; xnorm / enorm fp32.  D in {64, 128, 256, 512}.
@@ -121,6 +197,23 @@ extern "C" int pgt_rq_nearest(int32_t dtype, const void* x, int32_t ldx, const v
     PGT_CHECK(ldx % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)book)) & 15) == 0, "rq_nearest: rows must be 16-byte aligned");
     const dim3 grid((rows + 127) / 128), blk(256);
     hipStream_t st = (hipStream_t)stream;
+    if (D == 512 && K <= 8192) {      // LDS-DMA streaming form
+        const int nb = (K + 31) / 32;
+        const int lds = 2 * 32 * (512 * 2 + 16) + nb * 32 * (int)sizeof(float);
+        static std::atomic<unsigned long long> attr_set{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_nearest_dma512_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * (512 * 2 + 16) + 8192 * 4);
+            if (e != hipSuccess) { pgt_set_error("rq_nearest: cannot reserve LDS: %s", hipGetErrorString(e)); return -12; }
+            attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
+        }
+        hipLaunchKernelGGL(rq_nearest_dma512_kernel, grid, blk, lds, st, (const uint16_t*)x, ldx, (const uint16_t*)book, xnorm,
+                           enorm, rows, K, nb, codes);
+        PGT_LAUNCH_CHECK();
+        return 0;
+    }
 #define RQN(D_)                                                                                                   \
     hipLaunchKernelGGL((rq_nearest_mfma_kernel<D_>), grid, blk, 0, st, (const uint16_t*)x, ldx, (const uint16_t*)book, \
                        xnorm, enorm, rows, K, codes)

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import ACT_GELU, ACT_NONE, ACT_SILU, X3
+from ..ops import ACT_GELU, ACT_NONE, ACT_SILU, X3, X3F
 
 
 class HipModule(nn.Module):
@@ -42,10 +42,14 @@ def _is_x3(dtype):
     return isinstance(dtype, str) and dtype == X3
 
 
+def _is_x3f(dtype):
+    return isinstance(dtype, str) and dtype == X3F
+
+
 def _pack_matrix(w2d, taps, device, dtype):
     """fp32 (Cout, taps*Cin) K-major weight -> kernel operand: a cast, or for split-bf16 modules the
     [w_hi | w_hi | w_lo]-per-tap form (ops.pack_x3_weight)."""
-    if _is_x3(dtype):
+    if _is_x3(dtype) or _is_x3f(dtype):
         return ops.pack_x3_weight(w2d.reshape(w2d.shape[0], taps, -1)).to(device)
     return w2d.contiguous().to(device=device, dtype=dtype)
 
@@ -81,6 +85,9 @@ class Conv2d(nn.Conv2d, HipModule):
         self.pb = _f32(b, device)
 
     def run(self, x, **kw):
+        if _is_x3f(self.dt):     # fp32 in / fp32 out, split-bf16 MFMA arithmetic in between
+            return ops.conv2d(ops.to_x3(x), self.pw, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
+                              stride=self.stride[0], pad=self.pad4, x3=True, out_f32=True, **kw)
         return ops.conv2d(x, self.pw, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
                           stride=self.stride[0], pad=self.pad4, x3=_is_x3(self.dt), **kw)
 

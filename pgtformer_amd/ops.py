@@ -18,6 +18,7 @@ from .hip import (ACT_GELU, ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SI
 # such operands; reshapes over the leading dims work unchanged, the hi plane `t[..., :C]` is a valid bf16 view of the
 # rounded tensor.
 X3 = "bf16x3"
+X3F = "bf16x3/f32"      # split-bf16 arithmetic, fp32 storage: the module splits its fp32 input on the way in, writes fp32
 # GroupNorm statistics from the producing conv's epilogue (PGT_EPILOGUE_GN=0: always the separate statistics pass)
 import os as _os
 USE_EPILOGUE_GN = _os.environ.get("PGT_EPILOGUE_GN", "1") != "0"
@@ -41,8 +42,13 @@ class GnStats:
         return t
 
 
-def gn_ok(n, hw, cout, groups=32):
-    """can a conv producing (n, hw pixels, cout) leave GroupNorm statistics? (tile rows up to 512 must divide hw)"""
+def gn_ok(n, hw, cout, groups=32, cin=None, k=None):
+    """can a conv producing (n, hw pixels, cout) leave GroupNorm statistics? (tile rows up to 512 must divide hw).
+    The 64 -> 64 3x3 layers are left to the separate statistics pass: their streaming kernel (igemm6: 144 weight registers
+    held across tiles) has no registers to spare for the reduction - measured on MI355X, its statistics variant lost more
+    than the statistics pass costs (profiles/r2_gn_epilogue_ab.md)."""
+    if cin == 64 and cout <= 64 and k == 3:
+        return False
     return groups > 0 and cout % groups == 0 and cout % 8 == 0 and hw % 512 == 0
 
 
@@ -184,8 +190,8 @@ def _tune_conv(d, args, device, iters=4, gn_ws=None):
     L = hip.lib()
     best, best_t = _TUNE_CANDIDATES[0], None
     for cand in _TUNE_CANDIDATES:
-        if gn_ws is not None and cand[0] in (2, 3):
-            continue       # no statistics epilogue in those kernels
+        if gn_ws is not None and cand[0] in (2, 3, 5, 6):
+            continue       # statistics epilogue: kernels 1 and 4 (the heuristic picks among them)
         d.kernel, (d.force_bm, d.force_bn), d.stages = cand
         ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device) if ws_bytes else None
@@ -238,7 +244,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
             out = torch.empty((n, ho0, wo0, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
         per = max(1, ((1 << 31) - 1) // (h * wd * _ld_img(x) * x.element_size()))
         st = None
-        if gn is not None and not isinstance(gn, tuple) and USE_EPILOGUE_GN and gn_ok(n, ho0 * wo0, cout, gn):
+        if gn is not None and not isinstance(gn, tuple) and USE_EPILOGUE_GN and gn_ok(n, ho0 * wo0, cout, gn, cin, kh):
             st = GnStats(n, 1, ho0 * wo0, cout, gn, x.device)
         for i in range(0, n, per):
             sl = slice(i, min(n, i + per))
@@ -281,8 +287,8 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
             st, d.gn_sub = gn[0], gn[1]
             d.gn_img0, d.gn_nimg = (gn[2], st.n) if len(gn) > 2 else (0, 0)
             assert st.hw == ho * wo and st.c == cout
-        elif (USE_EPILOGUE_GN and gn_ok(n, ho * wo, cout, gn) and not out_f32 and not scalar_epi and kernel in (0, 1, 4, 5, 6)
-              and splitk in (0, 1)):
+        elif (USE_EPILOGUE_GN and gn_ok(n, ho * wo, cout, gn, cin, kh) and not out_f32 and not scalar_epi
+              and kernel in (0, 1, 4) and splitk in (0, 1)):
             st = GnStats(n, 1, ho * wo, cout, gn, x.device)
         if st is not None:
             d.gn_groups, d.gn_nsub = st.groups, st.nsub
@@ -291,7 +297,10 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         dec, shift, sw = sft
         d.epi, d.ld_dec, d.ld_shift, d.sft_w = EPI_SFT, _ld_img(dec), _ld_img(shift), float(sw)
         assert dec.dtype == x.dtype and shift.dtype == x.dtype
-    if res is not None:
+    if res is not None and x3 and res.dtype == torch.float32:
+        assert out_f32 and tuple(res.shape) == tuple(out.shape)      # split-bf16 arithmetic on fp32-stored tensors
+        d.res_f32 = 1
+    elif res is not None:
         assert res.dtype == x.dtype and tuple(res.shape[:-1]) == tuple(out.shape[:-1]) and res.shape[-1] == (2 * cout if x3 else cout)
     prof = PROFILE
     if prof is not None:

@@ -89,7 +89,8 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         cin //= 2
         x = _merge(x)
         w = _unpack_x3_weight(w, kh * kw)
-        res = None if res is None else _merge(res)
+        if res is not None:
+            res = res if res.dtype == torch.float32 else _merge(res)      # fp32 residual: fp32-stored tensors (BiSeNet)
     assert w.shape[1] == kh * kw * cin and w.dtype == x.dtype
     xi = x.float().permute(0, 3, 1, 2)
     if ups:

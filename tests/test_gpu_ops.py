@@ -568,8 +568,7 @@ GN_CASES = [
     ("gn_v1_128x128", 2, 32, 32, 64, 128, 3, 1, (128, 128)),
     ("gn_v4_256", 2, 32, 32, 128, 256, 3, 4, (0, 256)),
     ("gn_v4_512x128", 2, 32, 32, 128, 128, 3, 4, (0, 128)),
-    ("gn_v5", 2, 32, 32, 256, 256, 3, 5, (0, 0)),
-    ("gn_v6", 3, 32, 32, 64, 64, 3, 6, (0, 0)),
+    ("gn_v4_two_n_tiles", 2, 32, 32, 128, 512, 3, 4, (0, 256)),
     ("gn_auto_512", 2, 32, 32, 512, 512, 1, 0, (0, 0)),
 ]
 

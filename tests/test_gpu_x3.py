@@ -191,3 +191,24 @@ def test_gather_frames():
     assert torch.equal(ops().gather_frames(u8, idx), u8[idx.long()])
     f32 = g(rnd((5, 3, 3, 8), 91))
     assert torch.equal(ops().gather_frames(f32, idx), f32[idx.long()])
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv2d_x3_on_fp32_stored_tensors(stride):
+    """Split-bf16 arithmetic on tensors that stay fp32 (BiSeNet's BasicBlocks in bf16x3 mode, reference
+    archs/pgtformer_arch.py:40-76): split input, fp32 output, fp32 residual, post-ReLU - relu(shortcut + bn2(conv2(.)))."""
+    n, h, w_, cin, cout = 2, 16, 16, 128, 256
+    x, wt, b = rnd((n, h, w_, cin), 300), rnd((cout, 9 * cin), 301, 1.0 / np.sqrt(9 * cin)), rnd((cout,), 302, 0.1)
+    ho = (h + 2 - 3) // stride + 1
+    res = rnd((n, ho, ho, cout), 303)
+    xs, ws = E.to_x3(x), ops().pack_x3_weight(wt.reshape(cout, 9, cin))
+    kw = dict(kh=3, kw=3, stride=stride, pad=(1, 1, 1, 1), x3=True, out_f32=True, post_relu=True)
+    want = E.conv2d(xs, ws, b, res=res, **kw)
+    got = ops().conv2d(g(xs), g(ws), g(b), res=g(res), **kw)
+    assert got.dtype == torch.float32 and (got >= 0).all()
+    check(f"x3_f32res_postrelu_s{stride}", got, want)
+    # a pooled (N,1,1,C) map: M = N rows only (ARM / FFM gates)
+    pooled = rnd((18, 1, 1, 128), 304)
+    w1 = rnd((128, 128), 305, 0.1)
+    got = ops().conv2d(g(E.to_x3(pooled)), g(ops().pack_x3_weight(w1.reshape(128, 1, 128))), None, act=E.ACT_SIGMOID, x3=True, out_f32=True)
+    check("x3_pooled_gate", got, E.conv2d(E.to_x3(pooled), ops().pack_x3_weight(w1.reshape(128, 1, 128)), None, act=E.ACT_SIGMOID, x3=True, out_f32=True))
