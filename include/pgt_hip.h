@@ -75,8 +75,8 @@ typedef struct pgt_conv_desc {
      * residual / SFT operands); kernels 1 and 4 (and 0 = auto).                                                  */
     int32_t orow_mul, orow_xmul, orow_off;
     /* dtype == PGT_BF16X3: element offsets of the lo planes of x, y and the residual inside a pixel row (0 = Cin / Cout /
-     * Cout, i.e. dense [hi | lo] tensors).  w then has 3*KH*KW*Cin columns: per filter tap [w_hi | w_hi | w_lo] (Cin
-     * each), matching the K order [x_hi | x_lo | x_hi].  y is split as well unless out_f32.  Kernel 4 only (bf16 MFMA,
+     * Cout, i.e. dense [hi | lo] tensors).  w then has 3*KH*KW*Cin columns: per filter tap and per 64-channel
+     * block [w_hi | w_hi | w_lo] (64 each), matching the K order [x_hi | x_lo | x_hi] of that block.  y is split as well unless out_f32.  Kernel 4 only (bf16 MFMA,
      * Cin % 64 == 0); no SFT epilogue.                                                                              */
     int32_t x_lo, y_lo, r_lo;
     /* GroupNorm statistics of the output from the conv epilogue (pgt_conv2d_gn): gn_groups > 0 asks every workgroup tile

@@ -323,8 +323,13 @@ class Fuse_sft_block(HipModule):
                 ops.copy_into(dec_feat, cat[..., c:2 * c])
             src = cat.view(b, t, h * wd, ctp)[..., :2 * c]            # windows x T frames x pixels x [enc|dec]
             dst = cat.view(n, 1, h * wd, ctp)[..., 2 * c:ct]          # fut channels, rows = frame * h*w + pixel
-            for to in range(t):   # output pixel m = window*h*w + pix  ->  row (window*T + to)*h*w + pix
-                ops.conv2d(src, self.w_mix[to], self.b_mix[to], kh=t, kw=1, out=dst, out_rows=(t, 1 - t, to * h * wd))
+            # the kernels take 32-bit byte offsets: more windows than fit 2 GiB of concat buffer run as window chunks
+            per = max(1, ((1 << 31) - 1) // (t * h * wd * ctp * cat.element_size()))
+            for i0 in range(0, b, per):
+                i1 = min(b, i0 + per)
+                for to in range(t):   # output pixel m = window*h*w + pix  ->  row (window*T + to)*h*w + pix
+                    ops.conv2d(src[i0:i1], self.w_mix[to], self.b_mix[to], kh=t, kw=1, out=dst[i0 * t:i1 * t],
+                               out_rows=(t, 1 - t, to * h * wd))
             e = self.encode_enc(cat if self.encode_enc.cpad is not None else cat[..., :ct])
             ss = ops.conv2d(e, self.w_ss0, self.b_ss0, kh=3, kw=3, pad=(1, 1, 1, 1), act=ACT_LEAKY02)
             co = self.out_ch

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     int a_pix[2][PA];
     unsigned a_mask[2][PA], a_sel[2][PA], b_off[2][PB];
     int ky = 0, kx = 0, c0 = 0;   // filter tap / first channel of the K tile whose A units are issued next (uniform)
-    // X3: per tap the K axis runs over three Cin-wide segments [x_hi | x_lo | x_hi] (the weights hold [w_hi | w_hi |
-    // w_lo]): `seg` is the segment, a_soff the byte offset of the K tile's first channel inside the pixel row.
+    // X3: every 64-channel block of a tap is visited three times, K order [x_hi | x_lo | x_hi] per block (the weights hold
+    // [w_hi | w_hi | w_lo] per block): `seg` is the visit, a_soff the byte offset of the K tile inside the pixel row.
     int seg = 0, a_soff = 0;
 
     auto setup_b = [&](int h) {
@@ -180,19 +180,21 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
                 bufdma16(a_sel[h][g], rsrc_x, a_soff, lds0 + buf * STAGE + (g * 128 + h * 64 + wave * 8) * 128);
     };
     auto advance = [&]() {
+        if (X3 && ++seg < 3) {
+            // next plane of the SAME 64-channel block: K order per block is [x_hi | x_lo | x_hi] (weights [w_hi | w_hi | w_lo]),
+            // so the second read of the hi plane follows the first by two K tiles and hits the cache
+            a_soff = (c0 + (seg == 1 ? p.xlo : 0)) * 2;
+            return;
+        }
+        seg = 0;
         c0 += 64;
         if (c0 == p.Cin) {
             c0 = 0;
-            if (X3 && ++seg < 3) {
-                // next segment of the same tap: same pixels, other plane
-            } else {
-                seg = 0;
-                if (++kx == p.KW) { kx = 0; ++ky; }
-                select_tap(0);
-                select_tap(1);
-            }
+            if (++kx == p.KW) { kx = 0; ++ky; }
+            select_tap(0);
+            select_tap(1);
         }
-        a_soff = (c0 + ((X3 && seg == 1) ? p.xlo : 0)) * 2;
+        a_soff = c0 * 2;
     };
     auto issue_b = [&](int h, int buf, int kt) {
 #pragma unroll

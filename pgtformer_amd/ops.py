@@ -53,12 +53,16 @@ def gn_ok(n, hw, cout, groups=32, cin=None, k=None):
 
 
 def pack_x3_weight(w3):
-    """w3: fp32 (Cout, taps, Cin) -> bf16 (Cout, taps*3*Cin) with [w_hi | w_hi | w_lo] per tap: the B operand matching the
-    kernels' K order [x_hi | x_lo | x_hi] (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo)."""
+    """w3: fp32 (Cout, taps, Cin), Cin % 64 == 0 -> bf16 (Cout, taps*3*Cin): per tap and per 64-channel block
+    [w_hi | w_hi | w_lo] (64 each) - the B operand matching the kernels' K order [x_hi | x_lo | x_hi] per block
+    (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo)."""
     w3 = w3.float()
+    cout, taps, cin = w3.shape
+    assert cin % 64 == 0, "split-bf16 operands come in 64-channel K blocks"
     hi = w3.to(torch.bfloat16)
     lo = (w3 - hi.float()).to(torch.bfloat16)
-    return torch.cat([hi, hi, lo], 2).reshape(w3.shape[0], -1).contiguous()
+    hi4, lo4 = hi.reshape(cout, taps, cin // 64, 1, 64), lo.reshape(cout, taps, cin // 64, 1, 64)
+    return torch.cat([hi4, hi4, lo4], 3).reshape(cout, -1).contiguous()
 
 
 def to_x3(x, out=None):

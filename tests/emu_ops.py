@@ -49,11 +49,11 @@ def _store_x3(val, out):
 
 
 def _unpack_x3_weight(w, taps):
-    """(Cout, taps*3*Cin) [w_hi | w_hi | w_lo] per tap -> fp32 (Cout, taps*Cin) = w_hi + w_lo"""
+    """(Cout, taps*3*Cin): per tap and 64-channel block [w_hi | w_hi | w_lo] -> fp32 (Cout, taps*Cin) = w_hi + w_lo"""
     cout = w.shape[0]
-    w4 = w.float().reshape(cout, taps, 3, -1)
-    assert torch.equal(w4[:, :, 0], w4[:, :, 1])
-    return (w4[:, :, 0] + w4[:, :, 2]).reshape(cout, -1)
+    w5 = w.float().reshape(cout, taps, -1, 3, 64)
+    assert torch.equal(w5[:, :, :, 0], w5[:, :, :, 1])
+    return (w5[:, :, :, 0] + w5[:, :, :, 2]).reshape(cout, -1)
 
 
 def to_x3(x, out=None):
