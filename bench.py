@@ -61,6 +61,8 @@ def live_roofline(runner, frames, precision, nwin):
     """Instrumented eager pass of ONE step (the runner's own forward: same frames, same window index): every
     implicit-GEMM launch bracketed by events on its launch stream."""
     from pgtformer_amd import ops
+    from pgtformer_amd.archs import pgtformer_arch
+    side, pgtformer_arch.SIDE_STREAM = pgtformer_arch.SIDE_STREAM, False   # one stream: a bracketed launch runs alone
     runner.static_in.copy_(frames)
     runner._forward(runner.static_in)      # warm
     torch.cuda.synchronize()
@@ -71,6 +73,7 @@ def live_roofline(runner, frames, precision, nwin):
         torch.cuda.synchronize()
     finally:
         ops.PROFILE = None
+        pgtformer_arch.SIDE_STREAM = side
     t_ms = sum(r["events"][0].elapsed_time(r["events"][1]) for r in recs)
     flops = sum(r["flops"] for r in recs)
     byts = sum(r["bytes"] for r in recs)

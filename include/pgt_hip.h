@@ -257,6 +257,10 @@ int pgt_copy2d(int32_t src_dtype, const void* src, int32_t lds, int32_t dst_dtyp
 int pgt_gather_frames(const void* src, int64_t src_row_stride, void* dst, int64_t dst_row_stride,
                       const int32_t* idx, int32_t n_dst, int64_t rows, int32_t row_bytes, pgt_stream_t stream);
 
+/* dst[r, 0:row_bytes] = 0 for `rows` rows of stride ldd_bytes (16-byte granules): the zero pad channels of the
+ * [enc | dec | fut | 0] concat buffers and of the 57 -> 64 channel parsing map (replaces torch.zeros / zero_()) */
+int pgt_zero2d(void* dst, int64_t ldd_bytes, int64_t rows, int32_t row_bytes, pgt_stream_t stream);
+
 /* ---- driver edges (inference.py:6-19) ----------------------------------------------------------
  * input window -> channels-last 8-channel (RGB + 5 zero) tensors: raw = v/255 (encoder input) and
  * norm = (v/255 - mean)/std (BiSeNet input, transforms.Normalize pgtformer_arch.py:554-556,606).

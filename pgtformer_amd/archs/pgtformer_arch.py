@@ -19,6 +19,9 @@ from ..registry import ARCH_REGISTRY
 from .codeformer_arch import TransformerSALayer, adaptive_instance_normalization
 from .tdcrqvae3_arch import TDCRQVAE3
 
+import os as _os
+SIDE_STREAM = _os.environ.get("PGT_SIDE_STREAM", "1") != "0"
+
 
 # ----------------------------------------------------------------------------------------------
 # BiSeNet (reference: pgtformer_arch.py:34-397).  Eval-mode BatchNorm is folded into the preceding
@@ -195,7 +198,7 @@ class BiSeNet(HipModule):
         feat_fuse = self.ffm(feat_res8, feat_cp8)
         n = x.shape[0]
         cpad = (3 * nc + 7) // 8 * 8
-        outf = torch.zeros((n, 32, 32, cpad), device=x.device, dtype=x.dtype)
+        outf = ops.zero_(torch.empty((n, 32, 32, cpad), device=x.device, dtype=x.dtype))
         ops.resize_bilinear_ac(self.conv_out(feat_fuse), 32, 32, out=outf[..., 0:nc])
         ops.resize_bilinear_ac(self.conv_out16(feat_cp8), 32, 32, out=outf[..., nc:2 * nc])
         f32 = self.conv_out32(feat_cp16)
@@ -239,7 +242,7 @@ class ResBlock(HipModule):
             assert x_in.shape[-1] == self.cpad, (x_in.shape, self.cpad)
             n, hh, ww, _ = x_in.shape
             hbuf = torch.empty((n, hh, ww, self.cpad), device=x_in.device, dtype=x_in.dtype)
-            hbuf[..., self.in_channels:].zero_()                     # only the pad channels need the zeros
+            ops.zero_(hbuf[..., self.in_channels:])                  # only the pad channels need the zeros
             self.norm1.run(x_in[..., :self.in_channels], ACT_SILU, out=hbuf[..., :self.in_channels])
             h = self.conv1.run(hbuf, gn=32)          # norm2's statistics from conv1's epilogue
         else:
@@ -303,7 +306,7 @@ class Fuse_sft_block(HipModule):
         ct, ctp = self.concat_width()
         cat = torch.empty((n, h, wd, ctp), device=device, dtype=dtype)
         if ctp != ct:
-            cat[..., ct:].zero_()
+            ops.zero_(cat[..., ct:])
         return cat
 
     def forward(self, enc_feat, dec_feat, temb=None, w=1, cat=None):
@@ -430,17 +433,31 @@ class PGTFormer(TDCRQVAE3):
         raw, nx = self._ingest(x)
         bt = raw.shape[0] if win is None else win.numel()
         b = bt // t
-        # condition branch: BiSeNet parsing map -> positional embedding of the code transformer (per frame)
-        self.last_parsing = self.conditionnet(nx)                           # (F,32,32,64): 3 x 19 parsing logits + pad
-        cond = self.convpos.run(self.last_parsing)                          # (F,32,32,512)
-        if win is not None:
-            cond = ops.gather_frames(cond, win)                              # (bt,32,32,512)
+        # condition branch: BiSeNet parsing map -> positional embedding of the code transformer (per frame).  Its many small
+        # launches (18 frames, maps down to 16x16: a fraction of the chip each) can run on a second stream next to the
+        # encoder's large HBM-bound launches (PGT_SIDE_STREAM=0 disables; the fork / join is captured into the HIP graph).
+        x3 = _is_x3(self.enc_dt)
+
+        def condition_branch():
+            self.last_parsing = self.conditionnet(nx)                       # (F,32,32,64): 3 x 19 parsing logits + pad
+            c = self.convpos.run(self.last_parsing)                         # (F,32,32,512)
+            if win is not None:
+                c = ops.gather_frames(c, win)                               # (bt,32,32,512)
+            p = c.reshape(bt * c.shape[1] * c.shape[2], c.shape[3])          # rows (b,t,y,x) == (T*H*W, B) order
+            return c, (ops.to_x3(p) if x3 else p)                           # fp32 BiSeNet map -> split-bf16 operand
+
+        side = None
+        if SIDE_STREAM and raw.is_cuda:
+            main = torch.cuda.current_stream(raw.device)
+            side = self.__dict__.setdefault("_side_stream", None) or torch.cuda.Stream(device=raw.device)
+            self.__dict__["_side_stream"] = side
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cond, pos = condition_branch()
+        else:
+            cond, pos = condition_branch()
         self.last_cond = cond
         th, tw = cond.shape[1], cond.shape[2]
-        pos = cond.reshape(bt * th * tw, cond.shape[3])                      # rows (b,t,y,x) == (T*H*W, B) order
-        x3 = _is_x3(self.enc_dt)
-        if x3:
-            pos = ops.to_x3(pos)                                             # fp32 BiSeNet map -> split-bf16 operand
         # encoder.  bf16: the fusion blocks' [enc | dec | fut] concat buffers exist up front and the encoder levels / the
         # decoder levels write their feature maps straight into the enc / dec slices (no concat copies)
         cats, feat_out = {}, None
@@ -464,6 +481,8 @@ class PGTFormer(TDCRQVAE3):
         lq_feat = self.quant_conv.run(z)                                     # (bt,32,32,512); x3: (bt,32,32,1024)
         lq_style = lq_feat[..., :lq_feat.shape[3] // 2] if x3 else lq_feat   # AdaIN style statistics: the hi plane
         # code-prediction transformer over the T*32*32 tokens of each window
+        if side is not None:
+            torch.cuda.current_stream(raw.device).wait_stream(side)          # join: pos is first used here
         L = t * th * tw
         q = self.feat_emb.run(lq_feat.reshape(bt * th * tw, lq_feat.shape[3]))
         for layer in self.ft_layers:

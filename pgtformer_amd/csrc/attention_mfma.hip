@@ -10,8 +10,8 @@
 // contributes to k-step s if the keys inside each 16-key group are taken in the order
 // {4h..4h+3, 8+4h..8+4h+3}; V^T fragments are read with the same key order (two ds_read_b64), so the
 // contraction is unchanged and P never round-trips through LDS.
-// Workgroup = 4 waves x 32 queries; K/V streamed in 64-key tiles, next tile prefetched into registers
-// while the current one is consumed.
+// Workgroup = 4 waves x 32 queries; K/V streamed in 64-key tiles through a DOUBLE-buffered LDS stage: tile t+1 is
+// fetched into registers while tile t is multiplied and written to the other stage afterwards - one barrier per tile.
 #include "common.h"
 #include "pgt_internal.h"
 
@@ -35,9 +35,8 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
                                                        int qlo, int klo, int vlo, int olo) {
     constexpr int NP = X3 ? 2 : 1;
     constexpr int PLANE = BKV * KSTR + HD * VSTR;
-    __shared__ __attribute__((aligned(16))) char smem[NP * PLANE];
-    char* Ks = smem;
-    char* Vt = smem + BKV * KSTR;
+    constexpr int STAGE = NP * PLANE;                       // one K / V^T tile (hi [+ lo] planes)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -72,7 +71,9 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
                 if (vj < L) rv[pl][i] = *reinterpret_cast<const uint4*>(v + (rowbase + vj) * ldv + pl * vlo + head * HD + v_c * 8);
             }
     };
-    auto sstore = [&]() {
+    auto sstore = [&](int buf) {
+        char* Ks = smem + buf * STAGE;
+        char* Vt = Ks + BKV * KSTR;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
@@ -99,13 +100,13 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
 
     const int nt = (L + BKV - 1) / BKV;
     gload(0);
-    sstore();
+    sstore(0);
     __syncthreads();
-    const char* k_rd = Ks + (lane & 31) * KSTR + h * 16;
-    const char* v_rd = Vt + (lane & 31) * VSTR + h * 8;
     for (int t = 0; t < nt; ++t) {
         const int k0 = t * BKV;
         const bool more = t + 1 < nt;
+        const char* k_rd = smem + (t & 1) * STAGE + (lane & 31) * KSTR + h * 16;
+        const char* v_rd = smem + (t & 1) * STAGE + BKV * KSTR + (lane & 31) * VSTR + h * 8;
         if (more) gload(k0 + BKV);
         // ---- S^T = K Q^T : 2 key blocks x 4 k-steps
         f32x16 s[2];
@@ -198,11 +199,9 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                                    __builtin_bit_cast(bf16x8, pf[kb][s2]), o[d], 0, 0, 0);
                 }
+        // the other stage was last read in tile t-1, which every wave left through the barrier below
+        if (more) sstore((t + 1) & 1);
         __syncthreads();
-        if (more) {
-            sstore();
-            __syncthreads();
-        }
     }
     l += __shfl_xor(l, 32, 64);
     if (qi < L) {

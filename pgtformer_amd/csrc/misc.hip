@@ -309,6 +309,13 @@ __global__ __launch_bounds__(256) void rq_soft_codes_kernel(const float* __restr
     if (lane == 0) codes[row] = bi;
 }
 
+// zero a (rows, row_bytes) byte matrix with row stride ldd bytes (16-byte granules): pad channels of concat buffers
+__global__ void zero2d_kernel(char* __restrict__ dst, long ldd, long rows, int chunks) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * chunks) return;
+    *reinterpret_cast<uint4*>(dst + (i / chunks) * ldd + (i % chunks) * 16) = make_uint4(0, 0, 0, 0);
+}
+
 inline dim3 grid1d(long n, int blk = 256) { return dim3((unsigned)((n + blk - 1) / blk)); }
 
 }  // namespace
@@ -517,6 +524,16 @@ extern "C" int pgt_rq_soft_codes(const float* dot, int32_t ld, const float* xnor
     PGT_CHECK(dot && xnorm && enorm && soft && codes && K > 0 && temp > 0.f, "rq_soft_codes: bad argument");
     hipLaunchKernelGGL(rq_soft_codes_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dot, ld, xnorm, enorm,
                        rows, K, 1.0f / temp, soft, codes);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_zero2d(void* dst, int64_t ldd_bytes, int64_t rows, int32_t row_bytes, pgt_stream_t stream) {
+    PGT_CHECK(dst && rows >= 0 && row_bytes > 0 && row_bytes % 16 == 0 && ldd_bytes % 16 == 0 && (((uintptr_t)dst) & 15) == 0,
+              "zero2d: rows must be 16-byte aligned multiples of 16 bytes (row_bytes=%d)", row_bytes);
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(zero2d_kernel, grid1d((long)rows * (row_bytes / 16)), dim3(256), 0, (hipStream_t)stream, (char*)dst,
+                       (long)ldd_bytes, (long)rows, row_bytes / 16);
     PGT_LAUNCH_CHECK();
     return 0;
 }

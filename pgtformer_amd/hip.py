@@ -66,6 +66,7 @@ SIGNATURES = {
     "pgt_resize_bilinear_ac": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
     "pgt_copy2d": [i32, vp, i32, i32, vp, i32, i64, i32, vp],
     "pgt_gather_frames": [vp, i64, vp, i64, vp, i32, i64, i32, vp],
+    "pgt_zero2d": [vp, i64, i64, i32, vp],
     "pgt_prep_input": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
     "pgt_nhwc_to_nchw_f32": [i32, vp, i32, i32, i32, i32, i32, vp, vp],
     "pgt_frame_to_u8": [i32, vp, i32, i32, i32, vp, vp],

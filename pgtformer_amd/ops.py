@@ -648,6 +648,17 @@ def gather_frames(src, idx, out=None):
     return out
 
 
+def zero_(t):
+    """t[...] = 0 for a (..., C) view with a contiguous last dim whose C * element_size is a multiple of 16 bytes (pad channel
+    slices of wider buffers, or whole buffers)."""
+    c = t.shape[-1]
+    rows = t.numel() // c
+    ld = (_ld_img(t) if t.dim() == 4 else _ld_rows(t)) if rows > 1 else c
+    es = t.element_size()
+    hip.check(hip.lib().pgt_zero2d(_p(t), ld * es, rows, c * es, _stream()), "pgt_zero2d")
+    return t
+
+
 def prep_input(src, dtype, want_raw=True, want_norm=True):
     """src: uint8 (N,H,W,3) or float32 (N,3,H,W) -> raw, norm as (N,H,W,8) channel-padded tensors."""
     if src.dtype == torch.uint8:

@@ -342,6 +342,11 @@ def cast(x, dtype):
     return x if x.dtype == dtype else x.to(dtype)
 
 
+def zero_(t):
+    t.zero_()
+    return t
+
+
 def prep_input(src, dtype, want_raw=True, want_norm=True):
     if src.dtype == torch.uint8:
         r = src.float() / 255.0
@@ -370,7 +375,7 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
-       "straight_through"]
+       "straight_through", "zero_"]
 
 
 def install(monkeypatch):
