@@ -5,7 +5,9 @@ One "step" = one forward of B = `--windows-per-forward` consecutive sliding wind
 (reference driver semantics, inference.py:12-19, 38-74: every output frame is the middle frame of a 3-frame
 window; the reference itself only accepts one window per call).  The B windows of a step cover B+2
 consecutive frames: everything per-frame (BiSeNet, the encoder up to its first temporal attention) is
-computed once per frame and gathered to window order (results equal B separate forwards).
+computed once per frame and gathered to window order (results equal B separate forwards), and after the
+decoder's last temporal operation (the 256x256 fusion block's temporal mix) only the middle frame of every
+window - the one the driver keeps - is computed (`--full-tail`: all three, as the reference computes and discards).
 Workload = BASELINE.json configs[1]: pgtformer-base, synthetic degraded 512x512 clip, 3-frame window,
 bf16 MFMA arithmetic with fp32 accumulation (default precision "bf16x3": decoder / fusion in bf16, the
 code-prediction branch on split-bf16 operands so that the codes equal the fp32 reference's), random-init
@@ -48,6 +50,9 @@ def parse():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "mixed", "fp32"])
     ap.add_argument("--resident", action="store_true", help="clip resident in HBM (no H2D/D2H in the timed region)")
     ap.add_argument("--no-overlap", action="store_true", help="stack 3 frames per window (no per-frame reuse)")
+    ap.add_argument("--full-tail", action="store_true",
+                    help="push all 3 frames of every window through the decoder's per-frame tail, as the reference does before "
+                         "discarding two of them (default: middle frames only after the last temporal operation)")
     ap.add_argument("--windows-per-forward", type=int, default=16,
                     help="independent 3-frame windows batched into one forward (reference semantics: B separate calls)")
     ap.add_argument("--no-graph", action="store_true")
@@ -203,7 +208,7 @@ def main():
     padded_host = torch.empty((n_local + 2, 512, 512, 3), dtype=torch.uint8).pin_memory()
     padded_host[1:n_local + 1].copy_(clip)
     out_host = torch.empty((n_local, 512, 512, 3), dtype=torch.uint8).pin_memory()
-    runner = WindowRunner(model, 1.0, not args.no_graph, 512, 512, batch=B, overlap=not args.no_overlap)
+    runner = WindowRunner(model, 1.0, not args.no_graph, 512, 512, batch=B, overlap=not args.no_overlap, full_tail=args.full_tail)
 
     n_warm = max(B, min(args.warmup * B, n_local))
     warm_host = torch.empty((n_warm + 2, 512, 512, 3), dtype=torch.uint8).pin_memory()   # own buffer: the halo rows
@@ -256,6 +261,9 @@ def main():
                                   "VFHQ-shape clip, random-init weights (BASELINE.json configs[1])",
                       "precision": args.precision, "frames_per_step": B, "frames_per_rank": n_local, "hip_graph": not args.no_graph,
                       "windows_per_forward": B, "per_frame_reuse": not args.no_overlap,
+                      "decoder_tail": ("all 3 frames of every window" if args.full_tail else
+                                       "middle frame only after the last temporal operation (the driver keeps [0][1], inference.py:15; "
+                                       "identical restored frames; --full-tail for the reference's discarded work)"),
                       "clip_location": "HBM (resident)" if args.resident else "pinned host memory (H2D/D2H inside the timed region)",
                       "parallelism": f"frame-range shard x{world}, 1 all_gather of boundary frames"}}
     if hbm_rate is not None:

@@ -309,9 +309,21 @@ class Fuse_sft_block(HipModule):
             ops.zero_(cat[..., ct:])
         return cat
 
-    def forward(self, enc_feat, dec_feat, temb=None, w=1, cat=None):
+    def _frame_index(self, b, k, device):
+        """int32 device tensor [k, T+k, 2T+k, ...]: frame k of each of the b windows (cached: created once, before graph capture)."""
+        key = (b, k, str(device))
+        cache = self.__dict__.setdefault("_fidx", {})
+        if key not in cache:
+            cache[key] = (torch.arange(b, dtype=torch.int32) * self.t + k).to(device)
+        return cache[key]
+
+    def forward(self, enc_feat, dec_feat, temb=None, w=1, cat=None, keep=None):
         """enc_feat, dec_feat: (B*T, h, w, C) (reference: :460-484).  cat: a new_concat() buffer whose enc and/or dec
-        slices were already written by the producers (then enc_feat / dec_feat ARE those slices and are not copied)."""
+        slices were already written by the producers (then enc_feat / dec_feat ARE those slices and are not copied).
+        keep: None, or a frame index k: only frame k of every window is wanted from here on (the driver keeps the middle
+        frame, inference.py:15, and everything after this block's temporal mix is per-frame): the mix is evaluated for
+        output frame k only and the per-frame tail (ResBlock, scale / shift, modulation) runs on B frames instead of
+        B*T; returns (B, h, w, C)."""
         n, h, wd, c = dec_feat.shape
         t, tcc = self.t, self.tcc
         b = n // t
@@ -330,9 +342,13 @@ class Fuse_sft_block(HipModule):
             per = max(1, ((1 << 31) - 1) // (t * h * wd * ctp * cat.element_size()))
             for i0 in range(0, b, per):
                 i1 = min(b, i0 + per)
-                for to in range(t):   # output pixel m = window*h*w + pix  ->  row (window*T + to)*h*w + pix
+                for to in (range(t) if keep is None else (keep,)):
+                    # output pixel m = window*h*w + pix  ->  row (window*T + to)*h*w + pix
                     ops.conv2d(src[i0:i1], self.w_mix[to], self.b_mix[to], kh=t, kw=1, out=dst[i0 * t:i1 * t],
                                out_rows=(t, 1 - t, to * h * wd))
+            if keep is not None:     # frame `keep` of every window: [enc | dec | fut | 0] rows of B frames
+                cat = ops.gather_frames(cat, self._frame_index(b, keep, dev))
+                dec_feat = cat[..., c:2 * c]
             e = self.encode_enc(cat if self.encode_enc.cpad is not None else cat[..., :ct])
             ss = ops.conv2d(e, self.w_ss0, self.b_ss0, kh=3, kw=3, pad=(1, 1, 1, 1), act=ACT_LEAKY02)
             co = self.out_ch
@@ -358,7 +374,8 @@ class Fuse_sft_block(HipModule):
         co = self.out_ch
         shift = self.shift[2].run(ss[..., co:])
         # out = dec + w*(dec*scale + shift) as the epilogue of the last scale conv
-        return self.scale[2].run(ss[..., :co], sft=(dec_feat, shift, w))
+        out = self.scale[2].run(ss[..., :co], sft=(dec_feat, shift, w))
+        return out if keep is None else ops.gather_frames(out, self._frame_index(b, keep, dev))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -414,7 +431,7 @@ class PGTFormer(TDCRQVAE3):
         return (torch.arange(n_windows, dtype=torch.int32)[:, None] + torch.arange(t, dtype=torch.int32)[None, :]).reshape(-1).to(device)
 
     @torch.no_grad()
-    def forward_nhwc(self, x, w=None, code_only=None, adain=None, win=None, codes=None, direct=None):
+    def forward_nhwc(self, x, w=None, code_only=None, adain=None, win=None, codes=None, direct=None, middle_only=False):
         """Same computation, channels-last results and no layout conversion: out (B*T,512,512,3) in the
         decoder dtype, logits fp32, lq_feat (B*T,32,32,512) in the encoder dtype ((B*T,32,32,1024) split-bf16 planes
         [hi | lo] in bf16x3 mode).
@@ -425,7 +442,11 @@ class PGTFormer(TDCRQVAE3):
         win=None call on x[win] (the per-frame operators act on each frame independently).
         codes: optional (B*T,32,32,depth) integer tensor that REPLACES the predicted codes (teacher forcing: tests feed the
         reference's codes to separate decoder arithmetic from code flips).
-        direct: None = automatic; False forces the copying (non in-place) concat path in bf16 (tests)."""
+        direct: None = automatic; False forces the copying (non in-place) concat path in bf16 (tests).
+        middle_only: the caller keeps only the middle frame of every window (the reference driver: `[0][1]`,
+        inference.py:15).  Everything after the decoder's last temporal operation (with the shipping config: the temporal
+        mix of the 256x256 fusion block; attention stops at 128x128) is per-frame, so from there on only the middle frames
+        are computed: out is (B,512,512,3).  The middle frame is the same as in the full computation."""
         self._check_ready()
         w = self.w if w is None else w
         adain = self.adain if adain is None else adain
@@ -504,10 +525,20 @@ class PGTFormer(TDCRQVAE3):
             quant = adaptive_instance_normalization(quant, lq_style)
         z_q = self.post_quant_conv.run(quant)
 
+        # the decoder's last temporal operation: a fusion block's temporal mix (w > 0) or an EncoderLayer
+        mid = None
+        if middle_only:
+            sizes = [self.decoder.resolution >> i for i in reversed(range(self.decoder.num_resolutions))]   # 32 .. 512
+            temporal = [(str(sz), "fuse" if (str(sz) in self.connect_list and w > 0) else "attn")
+                        for sz, lvl in zip(sizes, reversed(list(self.decoder.up)))
+                        if (str(sz) in self.connect_list and w > 0) or len(lvl.attn) > 0]
+            mid = (t // 2,) + (temporal[-1] if temporal else (str(sizes[0]), "start"))
+
         def fuse(f_size, h):
             if f_size in self.connect_list and w > 0:
+                keep = mid[0] if (mid is not None and mid[1:] == (f_size, "fuse")) else None
                 return self.fuse_convs_dict[f_size](ops.cast(enc_feat[f_size], self.dec_dt), h, temb=None, w=w,
-                                                    cat=cats.get(f_size))
+                                                    cat=cats.get(f_size), keep=keep)
             return h
 
         def fuse_dst(f_size):
@@ -516,22 +547,26 @@ class PGTFormer(TDCRQVAE3):
                 return cats[f_size][..., c:2 * c]
             return None
 
-        out = self.decoder(z_q, fuse=fuse, fuse_dst=fuse_dst if cats else None)   # (bt,512,512,3)
+        out = self.decoder(z_q, fuse=fuse, fuse_dst=fuse_dst if cats else None, mid=mid)   # (bt | b, 512,512,3)
         return out, logits, lq_feat
 
     @torch.no_grad()
-    def restore_middle_u8(self, window_u8, w=1.0, win=None, out=None):
+    def restore_middle_u8(self, window_u8, w=1.0, win=None, out=None, full_tail=False):
         """Driver fast path (reference: inference.py:12-19): uint8 (3,H,W,3) window -> restored middle
         frame as uint8 (H,W,3) with floor(clamp(x,0,1)*255), without leaving the device.
         B windows stacked on the frame axis, (B*3,H,W,3), give (B,H,W,3): B independent windows per forward
         (the reference accepts only B=1, modules/rstt_layers.py:904; here B>1 == B separate calls).
-        win: see forward_nhwc - window_u8 then holds the windows' unique frames."""
-        res, _, _ = self.forward_nhwc(window_u8, w=w, win=win)
-        b = res.shape[0] // self.t
+        win: see forward_nhwc - window_u8 then holds the windows' unique frames.
+        full_tail: compute all T frames through the per-frame tail of the decoder as the reference does before it discards
+        two of them (`[0][1]`); default: only the middle frames after the last temporal operation (same result)."""
+        res, _, _ = self.forward_nhwc(window_u8, w=w, win=win, middle_only=not full_tail)   # (B,H,W,3): the middle frames
+        if full_tail:
+            res = res[self.t // 2::self.t]
+        b = res.shape[0]
         if b == 1 and out is None:
-            return ops.frame_to_u8(res[self.t // 2])
+            return ops.frame_to_u8(res[0])
         if out is None:
             out = torch.empty((b,) + tuple(res.shape[1:3]) + (3,), device=res.device, dtype=torch.uint8)
         for i in range(b):
-            ops.frame_to_u8(res[i * self.t + self.t // 2], out=out[i])
+            ops.frame_to_u8(res[i], out=out[i])
         return out

@@ -344,12 +344,24 @@ class Decoder(HipModule):
         self.norm_out = Normalize(block_in)
         self.conv_out = Conv2d(block_in, out_ch, 3, padding=1)
 
-    def forward(self, z, fuse=None, fuse_dst=None):
+    def forward(self, z, fuse=None, fuse_dst=None, mid=None):
         """z: (B*T, h, w, z_channels) (reference: :672-707; with `fuse`, the loop inlined in
         PGTFormer.forward, archs/pgtformer_arch.py:684-710). fuse(f_size:str, h) -> h.
         fuse_dst(f_size:str) -> (B*T,h,w,C) view or None: where the level's last block writes the feature map that
-        goes into `fuse` (the `dec` slice of the fusion block's concat buffer: no copy later)."""
+        goes into `fuse` (the `dec` slice of the fusion block's concat buffer: no copy later).
+        mid = (k, size, kind): only frame k of every window is wanted; `size`/`kind` name the last temporal operation
+        ("fuse": the fusion block at that size narrows to B frames itself; "attn": narrowed here after that level's
+        EncoderLayers; "start": no temporal operation at all).  Everything after it runs on B frames."""
         self.last_z_shape = z.shape
+
+        def narrow(hh):      # frame mid[0] of every window (index tensor cached: built once, before any graph capture)
+            key = (hh.shape[0], mid[0], str(hh.device))
+            cache = self.__dict__.setdefault("_fidx", {})
+            if key not in cache:
+                cache[key] = (torch.arange(hh.shape[0] // self.num_frames, dtype=torch.int32) * self.num_frames + mid[0]).to(hh.device)
+            return ops.gather_frames(hh, cache[key])
+        if mid is not None and mid[2] == "start":
+            z = narrow(z)
         h = self.conv_in.run(z, gn=32)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h), gn_next=True), gn_next=True)
         for i_level in reversed(range(self.num_resolutions)):
@@ -365,6 +377,8 @@ class Decoder(HipModule):
                 h = lvl.block[i_block](h, out=dst if last and not has_attn else None, gn_next=gn_after and not has_attn)
                 if has_attn:
                     h = lvl.attn[i_block](h, out=dst if last else None, gn_next=gn_after)
+            if mid is not None and mid[1:] == (str(h.shape[2]), "attn"):
+                h = narrow(h)
             if fuse is not None:
                 h = fuse(str(h.shape[2]), h)
             if i_level != 0:

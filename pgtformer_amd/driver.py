@@ -24,10 +24,12 @@ class WindowRunner:
     overlap=True (default): a forward takes the batch + 2 CONSECUTIVE frames its `batch` sliding windows cover and the
     model computes everything per-frame (BiSeNet, the encoder up to its first temporal attention) once per frame
     (PGTFormer.forward_nhwc(win=...)); overlap=False stacks the windows' 3 frames each (batch*3 frames, the reference's
-    per-window recomputation)."""
+    per-window recomputation).  The model computes the outer two frames of a window only as far as the middle frame depends
+    on them (up to the decoder's last temporal operation): the driver keeps `[0][1]` (reference inference.py:15)."""
 
-    def __init__(self, model, w=1.0, use_graph=True, height=512, width=512, batch=1, overlap=True):
+    def __init__(self, model, w=1.0, use_graph=True, height=512, width=512, batch=1, overlap=True, full_tail=False):
         self.model, self.w = model, w
+        self.full_tail = full_tail     # True: all 3 frames of every window through the decoder's per-frame tail (discarded)
         self.dev = model.dev
         self.t = model.t
         self.batch = batch
@@ -59,6 +61,8 @@ class WindowRunner:
 
     def _forward(self, frames_u8):
         kw = {"win": self.win} if self.overlap else {}
+        if self.full_tail:
+            kw["full_tail"] = True
         return self.model.restore_middle_u8(frames_u8, w=self.w, out=self.static_out, **kw)
 
     def _capture(self):

@@ -366,3 +366,53 @@ def test_large_batch_chunks_inputs_over_2gib(models):
         err = max(err, (both[3 * j:3 * j + 3] - sep).abs().max().item())
     _LOG["batch16_vs_separate_f32"] = {"max_abs_err": err}
     assert err < 2e-3
+
+
+def test_middle_only_tail_equals_full_forward(models):
+    """The driver keeps the middle frame of every window (inference.py:15).  forward_nhwc(middle_only=True) stops computing
+    the two outer frames after the decoder's last temporal operation (the 256x256 fusion block's temporal mix; with w=0 the
+    128x128 EncoderLayers): its frames equal the middle frames of the full forward - fp32 to round-off, default mode to the
+    bf16 decoder's noise floor with identical codes."""
+    from pgtformer_amd.synth import make_clip
+
+    lq, _ = make_clip(4, 512, seed=9)
+    frames = torch.from_numpy(lq).to(DEV)
+    for prec, wv in (("fp32", 1.0), ("fp32", 0), ("bf16x3", 1.0)):
+        m = models[prec]
+        win = m.window_index(2, 3, DEV)
+        full, lf, _ = m.forward_nhwc(frames, w=wv, win=win)
+        mid, lm, _ = m.forward_nhwc(frames, w=wv, win=win, middle_only=True)
+        torch.cuda.synchronize()
+        assert mid.shape == (2, 512, 512, 3) and full.shape == (6, 512, 512, 3)
+        want = full[1::3].float()
+        d = float((mid.float() - want).abs().max())
+        p_db = psnr(mid.float().clamp(0, 1).cpu(), want.clamp(0, 1).cpu())
+        _LOG[f"middle_only/{prec}/w{wv}"] = {"max_abs": d, "psnr_db": p_db, "logits_equal": bool(torch.equal(lf, lm))}
+        assert torch.equal(lf, lm)
+        assert (d <= 2e-3) if prec == "fp32" else (p_db >= 33.0), (prec, wv, d, p_db)
+
+
+def test_driver_119_frame_clip_through_the_real_model(models):
+    """BASELINE configs[0] geometry (119 frames of 512x512 rgb24) through the REAL model and the pipelined host driver
+    (pinned clip, 16 windows per forward, ragged tail batch, HIP graph): 119 frames in -> 119 out, and frames of the first,
+    an interior and the last window equal their single-window forwards (fp32; u8 +-1)."""
+    from pgtformer_amd.driver import WindowRunner, restore_clip_host
+    from pgtformer_amd.synth import make_clip
+
+    m = models["fp32"]
+    base, _ = make_clip(7, 512, seed=11)
+    clip = np.concatenate([base] * 17, 0)[:119]
+    padded = torch.empty((121, 512, 512, 3), dtype=torch.uint8).pin_memory()
+    padded[1:120].copy_(torch.from_numpy(clip))
+    out = torch.empty((119, 512, 512, 3), dtype=torch.uint8).pin_memory()
+    runner = WindowRunner(m, 1.0, use_graph=True, batch=16)
+    restore_clip_host(runner, padded, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(padded[0].numpy(), clip[0]) and np.array_equal(padded[120].numpy(), clip[118])   # replicate halos
+    worst = 0
+    for j in (0, 57, 118):
+        tri = [max(j - 1, 0), j, min(j + 1, 118)]
+        single = m.restore_middle_u8(torch.from_numpy(clip[tri]).to(DEV), w=1.0).cpu()
+        worst = max(worst, int((out[j].int() - single.int()).abs().max()))
+    _LOG["driver_119_frames/fp32"] = {"max_u8_diff_vs_single_window": worst}
+    assert worst <= 1

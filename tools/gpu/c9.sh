@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/c9; mkdir -p $O
+O=gpurun_out/c11; mkdir -p $O
 ( timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -12 ) > $O/tests.log; tail -4 $O/tests.log
 for f in parity_model parity_x3 parity_r2 parity_ops; do cp gpurun_out/$f.json $O/ 2>/dev/null; done
 export PGT_AUTOTUNE_CACHE=$GRAFT_REPO_ROOT/$O/tune.json
@@ -19,4 +19,6 @@ python tools/pmc_traffic.py $(find $O/pmc_FETCH_SIZE -name "*results.db" | head 
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 unset PGT_AUTOTUNE_CACHE
 timeout 900 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --precision bf16 > $O/bench_bf16.json 2> $O/bench_bf16.err; head -c 230 $O/bench_bf16.json; echo
+timeout 900 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-roofline --full-tail > $O/bench_x3_fulltail.json 2> $O/bench_x3_fulltail.err; head -c 230 $O/bench_x3_fulltail.json; echo
+timeout 300 python tools/bench_micro.py --iters 10 > $O/micro.jsonl 2> $O/micro.err
 head -c 400 $O/pmc.log
