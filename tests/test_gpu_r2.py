@@ -112,7 +112,8 @@ def test_vector_quantizer_matches_reference_golden(gold, name):
         assert int(idx.cpu().reshape(1, 6, 5)[0, 1, 2]) == 5
 
 
-@pytest.mark.parametrize("shape", [(3072, 1024, 512), (1000, 1024, 512), (70, 1000, 256), (4096, 512, 64), (333, 1025, 128)])
+@pytest.mark.parametrize("shape", [(3072, 1024, 512), (1000, 1024, 512), (5000, 1024, 512), (700, 1000, 512), (300, 96, 512), (70, 1000, 256),
+                                   (4096, 512, 64), (333, 1025, 128)])
 def test_fused_nearest_code_equals_two_kernel_form(shape):
     """arg-min inside the distance GEMM == distance GEMM (fp32 out) + row arg-min on the same bf16 operands: same dot
     products (same k order), same association, same first-index tie rule -> identical codes."""

@@ -96,13 +96,22 @@ def rq_lookup(iters):
                         return codes
                     us = timeit(run, max(2, iters // (1 + ntok // 65536)))
                     codes = run() if depth == 1 else None
+                    # the search kernel(s) alone: |x|^2, the gather of the chosen rows and the residual update excluded
+                    xn = ops.row_sumsq(x)
+                    if fused:
+                        k_us = timeit(lambda: ops.rq_nearest(x, book_t, xn, enorm), max(2, iters // (1 + ntok // 65536)))
+                    else:
+                        k_us = timeit(lambda: ops.rq_argmin(ops.linear(x, book_t, None, out_f32=True), xn, enorm),
+                                      max(2, iters // (1 + ntok // 65536)))
                     tie_ok = bool(codes[5].item() == 13) if codes is not None else None
                     flops = 2.0 * ntok * 1024 * 512 * depth
                     # algorithmic HBM bytes: x in + quantised out (+ residual r/w at depth > 1) + codes + codebook
                     es = 2 if dt == torch.bfloat16 else 4
                     byts = depth * (ntok * 512 * es * (2 if depth == 1 else 4) + ntok * 4) + 1024 * 512 * es
                     print(json.dumps({"bench": "rq_lookup", "dtype": str(dt).replace("torch.", ""), "Ntok": ntok, "depth": depth,
-                                      "fused_argmin": fused, "us": round(us, 1), "Mtok_per_s": round(ntok / us, 2),
+                                      "fused_argmin": fused, "us": round(us, 1), "search_kernels_us_per_level": round(k_us, 1),
+                                      "search_mfma_frac": round(2.0 * ntok * 1024 * 512 / k_us / 1e6 / (2500 if es == 2 else 157.3), 3),
+                                      "Mtok_per_s": round(ntok / us, 2),
                                       "TFLOPs": round(flops / us / 1e6, 1), "mfma_frac": round(flops / us / 1e6 / (2500 if es == 2 else 157.3), 3),
                                       "algorithmic_GBps": round(byts / us / 1e3, 1), "lowest_index_tie": tie_ok}))
 
