@@ -85,6 +85,15 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     const int n0 = (sw % p.nbn) * BN;
     const unsigned lds0 = lds_addr(smem);
     PGT_STAMP(0);
+#if PGT_PROBE & 32
+    if (tid == 0) {   // where and when (constant 100 MHz clock) this workgroup started
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_pgt_probe_ts[blockIdx.x & 4095][6] = ((unsigned long long)xcc << 32) | hw;
+        g_pgt_probe_ts[blockIdx.x & 4095][7] = __builtin_readcyclecounter();
+    }
+#endif
 
     // ---- DMA roles.  A piece (h, g): tile rows g*128 + h*64 + wave*8 .. +7 (g < WR).  B piece (h, g): j = wave + 8g
     //      (g < PB), tile columns (j>>2)*64 + h*32 + (j&3)*8 .. +7.  Lane l lands in slot (l & 15) of super row

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
+#include <utility>
 
 #ifdef PGT_PROBE_V5
 #include "../pgtformer_amd/csrc/igemm5.hip"
@@ -74,6 +76,29 @@ int main(int argc, char** argv) {
     for (int b = 0; b < cnt; ++b) { s4 += (double)(ts[b * 8 + 4] - ts[b * 8]); s5 += (double)(ts[b * 8 + 5] - ts[b * 8 + 4]); }
     printf("  setup split: address arithmetic %.0f  prologue issue + first wait %.0f  barrier %.0f\n", s4 / cnt, s5 / cnt,
            (s[0] - s4 - s5) / cnt);
+    {   // gaps between consecutive workgroups of one CU, and the counter rate against the event time
+        std::vector<std::pair<unsigned long long, int>> order;
+        for (int b = 0; b < cnt; ++b) order.push_back({((ts[b * 8 + 6] & 0xf0000ffffull) >> 8 << 8) | 0, b});
+        // key = (xcc, se, sh, cu): HW_ID bits [15:8], XCC_ID bits [3:0] of the high word
+        std::vector<std::vector<int>> percu(8 * 256);
+        for (int b = 0; b < cnt; ++b) {
+            const unsigned hw = (unsigned)ts[b * 8 + 6], xcc = (unsigned)(ts[b * 8 + 6] >> 32) & 0xf;
+            percu[(xcc & 7) * 256 + ((hw >> 8) & 0xff)].push_back(b);
+        }
+        double gap = 0, span = 0; int ngap = 0, ncu = 0; unsigned long long tmin = ~0ull, tmax = 0;
+        for (auto& v : percu) {
+            if (v.empty()) continue;
+            ++ncu;
+            std::sort(v.begin(), v.end(), [&](int a, int b) { return ts[a * 8] < ts[b * 8]; });
+            for (size_t i = 1; i < v.size(); ++i) { gap += (double)(ts[v[i] * 8] - ts[v[i - 1] * 8 + 3]); ++ngap; }
+            span += (double)(ts[v.back() * 8 + 3] - ts[v.front() * 8]);
+            if (ts[v.front() * 8] < tmin) tmin = ts[v.front() * 8];
+            if (ts[v.back() * 8 + 3] > tmax) tmax = ts[v.back() * 8 + 3];
+        }
+        printf("  %d CUs used, %.1f workgroups per CU; gap between consecutive workgroups of a CU %.0f ticks (avg of %d); "
+               "per-CU busy span %.0f ticks; event time %.1f us -> %.3f ticks per ns\n",
+               ncu, (double)cnt / ncu, ngap ? gap / ngap : 0.0, ngap, span / ncu, us, span / ncu / (us * 1e3));
+    }
     printf("  per workgroup (s_memtime ticks, avg of %d): setup+prologue %.0f  main loop %.0f (%.0f per K tile, %.0f per phase)  epilogue %.0f\n",
            cnt, s[0] / cnt, s[1] / cnt, s[1] / cnt / (p.K / 64), s[1] / cnt / (p.K / 64) / 4, s[2] / cnt);
 #endif
