@@ -155,10 +155,14 @@ int pgt_window_attention(int32_t dtype, const void* qkv, int32_t ldqkv, void* ou
 /* Video-Swin form of the same attention (modules/swin.py: WindowAttention3D :85-167 + window_partition/reverse :38-64 +
  * the 3-axis torch.roll of SwinTransformerBlock3D.forward_part1 :212-246 + compute_mask :311-323): windows (wd,wh,ww) of
  * the (D,H,W) token grid, cyclic shift (sd,sh,sw), 27-region mask.  qkv: (B*D*H*W, 3C) rows in (b,d,y,x) order
- * (the fused `qkv` Linear's output, columns [q | k | v]); bias dense (heads, N, N) fp32, N = wd*wh*ww (multiple of 48,
- * <= 192: e.g. 3x8x8).  dtype PGT_BF16 or PGT_F16 (fp16 MFMA, BASELINE.json configs[4]). */
+ * (the fused `qkv` Linear's output, columns [q | k | v]); bias dense (heads, N, N) fp32, N = wd*wh*ww.
+ * dtype PGT_BF16 or PGT_F16 with N a multiple of 48 (<= 192, e.g. 3x8x8) and (D,H,W) multiples of the window: the MFMA
+ * kernel (fp16 MFMA: BASELINE.json configs[4]).  Everything else - PGT_F32 storage, other N <= 256, feature maps that are
+ * not multiples of the window - takes the general kernel, which pads the grid at the far end of D, H, W as
+ * forward_part1 does (:218-223): `pad_row` (3C elements of `dtype`, or NULL = zeros) is the qkv row of a padding token,
+ * i.e. the qkv Linear's bias; outputs of padding tokens are not written. */
 int pgt_window_attention3d(int32_t dtype, const void* qkv, int32_t ldqkv, void* out, int32_t ldo,
-                           const float* bias, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                           const float* bias, const void* pad_row, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
                            int32_t heads, int32_t wd, int32_t wh, int32_t ww, int32_t sd, int32_t sh,
                            int32_t sw, pgt_stream_t stream);
 /* global multi-head attention, flash style (nn.MultiheadAttention inside TransformerSALayer,
@@ -223,6 +227,19 @@ int pgt_commit_loss(int32_t dtype, const void* x, int32_t ldx, const void* q, in
 /* y = x + (q - x): the value of the straight-through estimator in RQBottleneck.forward (:336), same fp32 order */
 int pgt_straight_through(int32_t dtype, const void* x, int32_t ldx, const void* q, int32_t ldq, void* y,
                          int32_t ldy, int64_t rows, int32_t cols, pgt_stream_t stream);
+/* Training-side quantiser (VQEmbedding EMA update, tdcrqvae3_arch.py:138-186), fp32.
+ * pgt_vq_cluster_stats: stats[0 .. K*D) = per code the sum of the batch vectors assigned to it, stats[K*D .. K*D+K) = how
+ * many (`one_hot @ vectors`, `one_hot.sum(1)` of _update_buffers :139-158) - one flat buffer, so that data-parallel ranks
+ * combine both with ONE all-reduce (the reference issues two, :157-158).  Deterministic: vectors are added in row order.
+ * pgt_vq_ema_update: cluster_size_ema / embed_ema <- decay * ema + (1 - decay) * stats (:160-161); codes whose EMA count
+ * fell below 1 restart from restart[k] (K x D, NULL = restart_unused_codes off; :163-177); then the codebook rows
+ * weight[k] = embed_ema[k] / (n (cs_k + eps) / (n + K eps)), n = sum(cs) (_update_embedding :179-186); the padding row
+ * weight[K] is not touched. */
+int pgt_vq_cluster_stats(const float* x, int32_t ldx, const int32_t* codes, int32_t rows, int32_t K, int32_t D,
+                         float* stats, pgt_stream_t stream);
+int pgt_vq_ema_update(float* cluster_size_ema, float* embed_ema, const float* stats, const float* restart,
+                      float* weight, int32_t ldw, int32_t K, int32_t D, float decay, float one_minus_decay, float eps,
+                      pgt_stream_t stream);
 /* out[r,:] (+)= codebook[codes[r],:] ; optionally resid[r,:] -= codebook[codes[r],:]
  * (VQEmbedding.embed :201-203, RQBottleneck.embed_code :355-368, quantize loop :318-325).
  * codebook fp32 (K+1, D); out/resid dtype = `dtype`. accumulate: 0 = overwrite, 1 = add */

@@ -15,6 +15,8 @@ frame stacks); leaf arithmetic is torch ATen CPU, the same library the reference
 """
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -587,7 +589,8 @@ def swin_relative_position_index(ws):
 
 def swin_window_attention(p, xw, heads, ws, mask=None):
     """WindowAttention3D.forward (reference: swin.py:128-167).  p: dict with qkv.weight [, qkv.bias], proj.weight,
-    proj.bias, relative_position_bias_table; xw (B_, N, C)."""
+    proj.bias, relative_position_bias_table; xw (B_, N, C).  ws: the window the module was CONSTRUCTED with - when the
+    feature map clamps the window, the reference still slices that window's index table, index[:N, :N] (:150)."""
     b_, n, c = xw.shape
     qkv = F.linear(xw, p["qkv.weight"], p.get("qkv.bias")).reshape(b_, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
@@ -605,21 +608,95 @@ def swin_window_attention(p, xw, heads, ws, mask=None):
     return F.linear(x, p["proj.weight"], p["proj.bias"])
 
 
-def swin_block_part1(p, x, heads, ws, ss):
-    """SwinTransformerBlock3D.forward_part1 for feature maps that are multiples of the window (reference: swin.py:212-246):
-    norm1 -> cyclic shift on (D,H,W) -> partition -> attention (+ mask when shifted) -> reverse -> shift back."""
+def swin_block_part1(p, x, heads, ws, ss, ws_ctor=None):
+    """SwinTransformerBlock3D.forward_part1 (reference: swin.py:212-246): norm1 -> zero-pad (D,H,W) up to multiples of the
+    window -> cyclic shift -> partition -> attention (+ mask of the PADDED grid when shifted) -> reverse -> shift back -> crop.
+    ws / ss: the window and shift in effect (already clamped to the map); ws_ctor: the constructor's window (bias index)."""
     b, d, h, w, c = x.shape
     x = F.layer_norm(x, (c,), p["norm1.weight"], p["norm1.bias"], 1e-5)
+    pd, pb, pr = (ws[0] - d % ws[0]) % ws[0], (ws[1] - h % ws[1]) % ws[1], (ws[2] - w % ws[2]) % ws[2]
+    x = F.pad(x, (0, 0, 0, pr, 0, pb, 0, pd))
+    dp, hp, wp = d + pd, h + pb, w + pr
     shifted = any(i > 0 for i in ss)
     if shifted:
         x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
-    mask = swin_compute_mask(d, h, w, ws, ss) if shifted else None
+    mask = swin_compute_mask(dp, hp, wp, ws, ss) if shifted else None
     attn_p = {k[len("attn."):]: v for k, v in p.items() if k.startswith("attn.")}
-    aw = swin_window_attention(attn_p, swin_window_partition(x, ws), heads, ws, mask)
-    x = swin_window_reverse(aw.view(-1, ws[0], ws[1], ws[2], c), ws, b, d, h, w)
+    aw = swin_window_attention(attn_p, swin_window_partition(x, ws), heads, ws_ctor or ws, mask)
+    x = swin_window_reverse(aw.view(-1, ws[0], ws[1], ws[2], c), ws, b, dp, hp, wp)
     if shifted:
         x = torch.roll(x, shifts=(ss[0], ss[1], ss[2]), dims=(1, 2, 3))
-    return x
+    return x[:, :d, :h, :w, :].contiguous()
+
+
+def swin_block(p, x, heads, ws, ss, ws_ctor=None):
+    """SwinTransformerBlock3D.forward (reference: swin.py:251-270; drop_path = 0): x + part1(x), then + mlp(norm2(.)),
+    Mlp = fc1 -> exact GELU -> fc2 (:14-35)."""
+    c = x.shape[-1]
+    x = x + swin_block_part1(p, x, heads, ws, ss, ws_ctor)
+    y = F.layer_norm(x, (c,), p["norm2.weight"], p["norm2.bias"], 1e-5)
+    y = F.linear(F.gelu(F.linear(y, p["mlp.fc1.weight"], p["mlp.fc1.bias"])), p["mlp.fc2.weight"], p["mlp.fc2.bias"])
+    return x + y
+
+
+def swin_basic_layer(p, x, depth, heads, ws):
+    """BasicLayer.forward without down-sampling (reference: swin.py:389-409): x (B,C,D,H,W); block i uses shift (0,0,0)
+    for even i and window // 2 for odd i (:361-375), windows clamped to the feature map (get_window_size :67-82).
+    p: state-dict-style keys `blocks.{i}.<block key>`."""
+    b, c, d, h, w = x.shape
+    x = x.permute(0, 2, 3, 4, 1).contiguous()
+    half = tuple(i // 2 for i in ws)
+    for i in range(depth):
+        ss = (0, 0, 0) if i % 2 == 0 else half
+        use_w = tuple(min(s, wv) for s, wv in zip((d, h, w), ws))
+        use_s = tuple(0 if s <= wv else sv for s, wv, sv in zip((d, h, w), ws, ss))
+        bp = {k[len(f"blocks.{i}."):]: v for k, v in p.items() if k.startswith(f"blocks.{i}.")}
+        x = swin_block(bp, x, heads, use_w, use_s, ws)
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# Training-side quantiser: EMA codebook update (reference: tdcrqvae3_arch.py:128-186)
+# ----------------------------------------------------------------------------------------------
+def vq_tile_with_noise(x, target_n, noise):
+    """VQEmbedding._tile_with_noise (:129-136) with the uniform noise given (`torch.rand_like` in the reference)."""
+    b, d = x.shape
+    n_rep = (target_n + b - 1) // b
+    std = x.new_ones(d) * 0.01 / np.sqrt(d)
+    return x.repeat(n_rep, 1) + noise * std
+
+
+def vq_ema_step(weight, cluster_size_ema, embed_ema, vectors, idxs, decay=0.99, eps=1e-5, restart=True, perm=None,
+                noise=None, reduce=None):
+    """One training step of VQEmbedding on given assignments: _update_buffers (:138-177) then _update_embedding (:179-186).
+    weight (K+1, D), cluster_size_ema (K,), embed_ema (K, D) are NOT modified; returns the new (weight, cluster_size_ema,
+    embed_ema).  perm / noise: the draws of torch.randperm / torch.rand_like the reference makes (fixtures carry them);
+    reduce: optional callable standing for the two all-reduces (:157-158)."""
+    k, d = weight.shape[0] - 1, weight.shape[1]
+    vectors = vectors.reshape(-1, d)
+    idxs = idxs.reshape(-1).long()
+    n_vec = vectors.shape[0]
+    one_hot = vectors.new_zeros(k, n_vec)
+    one_hot.scatter_(0, idxs.unsqueeze(0), vectors.new_ones(1, n_vec))
+    cluster_size = one_hot.sum(1)
+    vec_sum = one_hot @ vectors
+    if reduce is not None:
+        vec_sum, cluster_size = reduce(vec_sum), reduce(cluster_size)
+    cs = cluster_size_ema.clone().mul_(decay).add_(cluster_size, alpha=1 - decay)
+    em = embed_ema.clone().mul_(decay).add_(vec_sum, alpha=1 - decay)
+    if restart:
+        if n_vec < k:
+            vectors = vq_tile_with_noise(vectors, k, noise)
+        rnd = vectors[perm][:k]
+        usage = (cs.view(-1, 1) >= 1).float()
+        em.mul_(usage).add_(rnd * (1 - usage))
+        cs.mul_(usage.view(-1))
+        cs.add_(torch.ones_like(cs) * (1 - usage).view(-1))
+    n = cs.sum()
+    norm = n * (cs + eps) / (n + k * eps)
+    new_w = weight.clone()
+    new_w[:-1, :] = em / norm.reshape(-1, 1)
+    return new_w, cs, em
 
 
 # ----------------------------------------------------------------------------------------------

@@ -4,7 +4,9 @@ Mirror of the reference archs/tdcrqvae3_arch.py surface that the inference path 
 names, constructor kwargs and state-dict keys (Encoder :460, Decoder :577, VQEmbedding :80,
 RQBottleneck :206, TDCRQVAE3 :711).  Activations are channels-last (B*T, H, W, C); `forward` takes the
 reference's (B*T, 3, H, W) fp32 tensor (or uint8 (B*T,H,W,3) frames) and returns the reference's
-tuple.  EMA-codebook training updates and their collectives (:138-186) are out of scope.
+tuple.  The training-side quantiser - the EMA codebook update of VQEmbedding with its collectives (:128-199) - is
+`VQEmbedding.forward` in training mode (fp32): statistics and update are HIP kernels (csrc/vq_ema.hip), the two
+all-reduces of the reference travel as ONE buffer over RCCL.
 """
 import functools
 import inspect
@@ -73,19 +75,30 @@ class Downsample(HipModule):
 
 
 class VQEmbedding(nn.Embedding, HipModule):
-    """Codebook with EMA buffers (kept for checkpoint compatibility; reference: :80-97)."""
+    """Codebook with EMA update (reference: :80-203).  Inference: nearest-code search + gather.  Training (`.train()`,
+    fp32 modules, after `prepare`): `forward` also folds the batch into the EMA buffers and renormalises the codebook, in the
+    reference's order - search with the current codebook, batch statistics, gather with the CURRENT codebook, then the
+    update (:188-199).  The state lives on the device (`book`, `cs_ema_d`, `embed_ema_d`); `state_dict()` copies it back
+    into the nn parameters / buffers first, so checkpoints see the trained values."""
 
     def __init__(self, n_embed, embed_dim, ema=True, decay=0.99, restart_unused_codes=True, eps=1e-5):
         nn.Embedding.__init__(self, n_embed + 1, embed_dim, padding_idx=n_embed)
         self.n_embed = n_embed
+        self.ema, self.decay, self.eps, self.restart_unused_codes = ema, decay, eps, restart_unused_codes
+        if ema:
+            for p in self.parameters():
+                p.requires_grad_(False)
         self.register_buffer("cluster_size_ema", torch.zeros(n_embed))
         self.register_buffer("embed_ema", self.weight[:-1, :].detach().clone())
+        nn.Module.eval(self)      # inference-first build: the EMA path needs an explicit .train() (on this module or a parent)
 
     def _pack(self, device, dtype):
         w = self.weight.detach().float()
         self.book = w.to(device).contiguous()                      # fp32 (K+1, D) for the gather
         self.book_t = w[:-1].to(device=device, dtype=dtype).contiguous()   # (K, D) distance GEMM operand
         self.enorm = w[:-1].pow(2.0).sum(1).to(device).contiguous()  # |e_j|^2 (reference :111)
+        self.cs_ema_d = self.cluster_size_ema.detach().float().to(device).contiguous()
+        self.embed_ema_d = self.embed_ema.detach().float().to(device).contiguous()
 
     def distances_dot(self, x2d):
         """(rows, K) fp32 dot products x.e_j and |x|^2 (the two terms compute_distances combines, reference :100-117)."""
@@ -99,9 +112,81 @@ class VQEmbedding(nn.Embedding, HipModule):
         dot, xn = self.distances_dot(x2d)
         return ops.rq_argmin(dot, xn, self.enorm)
 
+    # ---- training side (reference :128-186) ------------------------------------------------------------------------
+    def _tile_with_noise(self, x, target_n, noise=None):
+        """repeat the batch up to target_n rows and add U[0,1) * 0.01 / sqrt(D) (reference :128-136)."""
+        b, d = x.shape
+        n_rep = (target_n + b - 1) // b
+        x = x.repeat(n_rep, 1)
+        if noise is None:
+            noise = torch.rand_like(x)
+        return x + noise.to(x.device) * (0.01 / float(d) ** 0.5)
+
+    @torch.no_grad()
+    def batch_statistics(self, vectors, idxs, perm=None, noise=None):
+        """First half of _update_buffers (:138-158, :163-171): this batch's per-code vector sums and counts as one flat
+        buffer, all-reduced over the data-parallel group in ONE collective (the reference issues two), and the K candidate
+        restart vectors (a random subset of the batch, broadcast from rank 0).  perm / noise: fixed draws for tests."""
+        import torch.distributed as dist
+
+        k, d = self.n_embed, self.weight.shape[1]
+        x = vectors.reshape(-1, d)
+        if x.dtype != torch.float32:
+            raise TypeError("the EMA codebook update runs in fp32 (prepare(device, torch.float32))")
+        x = x.contiguous()
+        stats = ops.vq_cluster_stats(x, idxs.reshape(-1).to(torch.int32).contiguous(), k)
+        multi = dist.is_available() and dist.is_initialized()
+        if multi:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        restart = None
+        if self.restart_unused_codes:
+            if x.shape[0] < k:
+                x = self._tile_with_noise(x, k, noise)
+            if perm is None:
+                perm = torch.randperm(x.shape[0], device=x.device)
+            sel = perm[:k].to(device=x.device, dtype=torch.int32).contiguous()
+            restart = ops.embed_rows(x, sel, torch.float32)        # row gather: the batch is the "codebook"
+            if multi:
+                dist.broadcast(restart, 0)
+        return stats, restart
+
+    @torch.no_grad()
+    def apply_ema(self, stats, restart):
+        """Second half of _update_buffers + _update_embedding (:160-186): EMA of counts and sums, restart of codes whose
+        EMA count is below 1, codebook = embed_ema / normalised count; then the search operands follow the new codebook."""
+        k = self.n_embed
+        ops.vq_ema_update(self.cs_ema_d, self.embed_ema_d, stats, restart, self.book, self.decay, self.eps)
+        new = self.book[:k]
+        self.book_t = new if self.book_t.dtype == torch.float32 else new.to(self.book_t.dtype)
+        self.enorm = ops.row_sumsq(new)
+
+    def forward(self, inputs, perm=None, noise=None):
+        """inputs (..., D) -> (embeds (..., D), codes int32 (...)) (reference :188-199)."""
+        d = inputs.shape[-1]
+        x2d = inputs.reshape(-1, d)
+        idxs = self.find_nearest_embedding(x2d)
+        pend = self.batch_statistics(x2d, idxs, perm, noise) if (self.training and self.ema) else None
+        embeds = ops.embed_rows(self.book, idxs, inputs.dtype)
+        if pend is not None:
+            self.apply_ema(*pend)
+        return embeds.reshape(inputs.shape), idxs.reshape(inputs.shape[:-1])
+
+    def sync_host(self):
+        """device state -> nn parameters / buffers (checkpointing)"""
+        if hasattr(self, "book"):
+            with torch.no_grad():
+                self.weight.copy_(self.book.detach().cpu())
+                self.cluster_size_ema.copy_(self.cs_ema_d.detach().cpu())
+                self.embed_ema.copy_(self.embed_ema_d.detach().cpu())
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.sync_host()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
 
 class RQBottleneck(HipModule):
-    """Residual quantiser (reference: :206-368), inference methods only."""
+    """Residual quantiser (reference: :206-368).  In training mode the codebooks fold every batch into their EMA buffers
+    (VQEmbedding.forward :188-199) - statistics are taken on the residual the search saw, before it is updated."""
 
     def __init__(self, latent_shape, code_shape, n_embed, decay=0.99, shared_codebook=False,
                  restart_unused_codes=True, commitment_loss="cumsum"):
@@ -133,7 +218,10 @@ class RQBottleneck(HipModule):
         for i in range(depth):
             book = self.codebooks[i]
             c = book.find_nearest_embedding(resid)
+            pend = book.batch_statistics(resid, c) if (book.training and book.ema) else None   # EMA update (:188-199)
             ops.embed_rows(book.book, c, x.dtype, out=agg, accumulate=i > 0, resid=resid if depth > 1 else None)
+            if pend is not None:
+                book.apply_ema(*pend)
             codes.append(c)
         return agg.reshape(b, h, w, d), torch.stack(codes, -1).reshape(b, h, w, depth)
 
@@ -151,7 +239,10 @@ class RQBottleneck(HipModule):
         for i in range(depth):
             book = self.codebooks[i]
             c = book.find_nearest_embedding(resid)
+            pend = book.batch_statistics(resid, c) if (book.training and book.ema) else None   # EMA update (:188-199)
             ops.embed_rows(book.book, c, x.dtype, out=agg, accumulate=i > 0, resid=resid if depth > 1 else None)
+            if pend is not None:
+                book.apply_ema(*pend)
             loss = ops.commit_loss(x2, agg, out=loss, scale=1.0 / depth)      # mean over depths of mean((x - agg_i)^2)
             codes.append(c)
         quants = ops.straight_through(x2, agg)

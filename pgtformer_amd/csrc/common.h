@@ -32,6 +32,11 @@ template <> struct ElemIO<bf16_t> {
     static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(p->v); }
     static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f2bf(v); }
 };
+struct half_t { _Float16 v; };   // IEEE half storage (pgt_window_attention3d, PGT_F16)
+template <> struct ElemIO<half_t> {
+    static __device__ __forceinline__ float ld(const half_t* p) { return (float)p->v; }
+    static __device__ __forceinline__ void st(half_t* p, float v) { p->v = (_Float16)v; }
+};
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return ElemIO<T>::ld(p); }
 template <typename T> __device__ __forceinline__ void stf(T* p, float v) { ElemIO<T>::st(p, v); }
 

@@ -43,7 +43,7 @@ SIGNATURES = {
     "pgt_channel_stats": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
     "pgt_adain_affine": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
     "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "pgt_window_attention3d": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "pgt_window_attention3d": [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pgt_mha": [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],
     "pgt_groupnorm_affine_x3": [vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp],
     "pgt_affine_act_x3": [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp],
@@ -59,6 +59,8 @@ SIGNATURES = {
     "pgt_commit_loss_workspace_bytes": [],
     "pgt_commit_loss": [i32, vp, i32, vp, i32, i64, i32, vp, f32, i32, vp, sz, vp],
     "pgt_straight_through": [i32, vp, i32, vp, i32, vp, i32, i64, i32, vp],
+    "pgt_vq_cluster_stats": [vp, i32, vp, i32, i32, i32, vp, vp],
+    "pgt_vq_ema_update": [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, vp],
     "pgt_embed_rows": [i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp],
     "pgt_row_sumsq": [i32, vp, i32, i32, i32, vp, vp],
     "pgt_maxpool3x3s2": [i32, vp, i32, i32, i32, i32, vp, vp],

@@ -471,15 +471,20 @@ def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
     return out
 
 
-def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift):
-    """Video-Swin window attention (modules/swin.py): qkv (B*D*H*W, 3C) bf16 or fp16 -> (B*D*H*W, C); win = (wd, wh, ww),
-    shift = (sd, sh, sw)."""
+def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift, pad_row=None):
+    """Video-Swin window attention (modules/swin.py): qkv (B*D*H*W, 3C) -> (B*D*H*W, C); win = (wd, wh, ww), shift =
+    (sd, sh, sw).  bf16 / fp16 with wd*wh*ww a multiple of 48 (<= 192) on whole windows: the MFMA kernel; fp32 storage,
+    other window sizes (<= 256 tokens) and feature maps that are not multiples of the window (padded as the reference
+    does; pad_row = the qkv row of a padding token, i.e. the qkv bias, or None = zeros): the general kernel."""
     rows = B * D * H * W
-    assert tuple(qkv.shape) == (rows, 3 * C_) and qkv.dtype in (torch.bfloat16, torch.float16)
+    assert tuple(qkv.shape) == (rows, 3 * C_) and qkv.dtype in (torch.bfloat16, torch.float16, torch.float32)
     out = torch.empty((rows, C_), device=qkv.device, dtype=qkv.dtype)
-    dt = hip.PGT_F16 if qkv.dtype == torch.float16 else PGT_BF16
-    hip.check(hip.lib().pgt_window_attention3d(dt, _p(qkv), _ld_rows(qkv), _p(out), C_, _p(bias), B, D, H, W, C_, heads,
-                                               win[0], win[1], win[2], shift[0], shift[1], shift[2], _stream()),
+    dt = hip.PGT_F16 if qkv.dtype == torch.float16 else _dt(qkv)
+    if pad_row is not None:
+        pad_row = pad_row.to(device=qkv.device, dtype=qkv.dtype).contiguous()
+        assert pad_row.numel() == 3 * C_
+    hip.check(hip.lib().pgt_window_attention3d(dt, _p(qkv), _ld_rows(qkv), _p(out), C_, _p(bias), _p(pad_row), B, D, H, W, C_,
+                                               heads, win[0], win[1], win[2], shift[0], shift[1], shift[2], _stream()),
               "pgt_window_attention3d")
     return out
 
@@ -567,6 +572,25 @@ def embed_rows(codebook, codes, dtype, out=None, accumulate=False, resid=None):
                                        int(accumulate), _p(resid), _ld_rows(resid) if resid is not None else 0,
                                        _stream()), "pgt_embed_rows")
     return out
+
+
+def vq_cluster_stats(x, codes, k):
+    """One batch's per-code statistics for the EMA codebook update: flat fp32 [K*D sums | K counts] (reference:
+    VQEmbedding._update_buffers, tdcrqvae3_arch.py:139-158).  x (rows, D) fp32, codes int32 (rows,)."""
+    rows, d = x.shape
+    assert x.dtype == torch.float32 and codes.dtype == torch.int32 and codes.numel() == rows
+    stats = torch.empty((k * d + k,), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().pgt_vq_cluster_stats(_p(x), _ld_rows(x), _p(codes), rows, k, d, _p(stats), _stream()),
+              "pgt_vq_cluster_stats")
+    return stats
+
+
+def vq_ema_update(cluster_size_ema, embed_ema, stats, restart, weight, decay, eps):
+    """In place: EMA buffers, restart of dead codes (restart (K, D) or None), codebook rows weight[:K] (reference: :160-186)."""
+    k, d = embed_ema.shape
+    assert weight.shape[0] >= k and weight.shape[1] == d and weight.is_contiguous() and embed_ema.is_contiguous()
+    hip.check(hip.lib().pgt_vq_ema_update(_p(cluster_size_ema), _p(embed_ema), _p(stats), _p(restart), _p(weight), d, k, d,
+                                          float(decay), float(1.0 - decay), float(eps), _stream()), "pgt_vq_ema_update")
 
 
 def row_sumsq(x):

@@ -218,12 +218,20 @@ def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
     return o.reshape(B * T * H * W, C_).to(qkv.dtype)
 
 
-def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift):
-    """Video-Swin form: (wd,wh,ww) windows, 3-axis roll, 27-region mask from region labels (independent formulation)."""
+def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift, pad_row=None):
+    """Video-Swin form: (wd,wh,ww) windows, 3-axis roll, 27-region mask from region labels (independent formulation);
+    feature maps that are not multiples of the window are padded at the far end with `pad_row` tokens (zeros if None)."""
     wd, wh, ww = win
     sd, sh, sw = shift
     hd = C_ // heads
     x = qkv.float().reshape(B, D, H, W, 3 * C_)
+    D0, H0, W0 = D, H, W
+    D, H, W = -(-D // wd) * wd, -(-H // wh) * wh, -(-W // ww) * ww
+    if (D, H, W) != (D0, H0, W0):
+        fill = torch.zeros(3 * C_) if pad_row is None else pad_row.float().reshape(-1)
+        xp = fill.reshape(1, 1, 1, 1, -1).expand(B, D, H, W, 3 * C_).clone()
+        xp[:, :D0, :H0, :W0] = x
+        x = xp
     shifted = bool(sd or sh or sw)
     if shifted:
         x = torch.roll(x, shifts=(-sd, -sh, -sw), dims=(1, 2, 3))
@@ -253,7 +261,8 @@ def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift):
     o = o.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, C_)
     if shifted:
         o = torch.roll(o, shifts=(sd, sh, sw), dims=(1, 2, 3))
-    return o.reshape(B * D * H * W, C_).to(qkv.dtype)
+    o = o[:, :D0, :H0, :W0]
+    return o.reshape(B * D0 * H0 * W0, C_).to(qkv.dtype)
 
 
 def mha(q, k, v, B, L, heads, hd, scale, x3=None):
@@ -295,6 +304,30 @@ def commit_loss(x, q, out=None, scale=1.0):
 
 def straight_through(x, q):
     return (x.float() + (q.float() - x.float())).to(x.dtype)
+
+
+def vq_cluster_stats(x, codes, k):
+    """flat [K*D sums | K counts]; sums in row order (sequential index_add on CPU)"""
+    rows, d = x.shape
+    sums = torch.zeros((k, d), dtype=torch.float32).index_add_(0, codes.long(), x.float())
+    cnt = torch.bincount(codes.long(), minlength=k).float()
+    return torch.cat([sums.reshape(-1), cnt])
+
+
+def vq_ema_update(cluster_size_ema, embed_ema, stats, restart, weight, decay, eps):
+    k, d = embed_ema.shape
+    alpha = float(torch.tensor(1.0 - decay, dtype=torch.float32))
+    cs = cluster_size_ema * float(torch.tensor(decay, dtype=torch.float32)) + alpha * stats[k * d:]
+    em = embed_ema * float(torch.tensor(decay, dtype=torch.float32)) + alpha * stats[:k * d].reshape(k, d)
+    if restart is not None:
+        dead = ~(cs >= 1)
+        em = torch.where(dead.unsqueeze(1), restart, em)
+        cs = torch.where(dead, torch.ones_like(cs), cs)
+    n = cs.sum()
+    norm = n * (cs + eps) / (n + k * eps)
+    cluster_size_ema.copy_(cs)
+    embed_ema.copy_(em)
+    weight[:k].copy_(em / norm.unsqueeze(1))
 
 
 def embed_rows(codebook, codes, dtype, out=None, accumulate=False, resid=None):
@@ -375,7 +408,7 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
-       "straight_through", "zero_"]
+       "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update"]
 
 
 def install(monkeypatch):
