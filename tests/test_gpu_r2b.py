@@ -3,7 +3,7 @@ and the Video-Swin BasicLayer stage (pgtformer_amd/modules/swin.py) - against th
 tests/golden/r2b_golden.npz and the oracle.
 
 Tolerances: codes and counts bit-exact; fp32 state 2e-6 * max|ref| (the reference forms the per-code sums with a GEMM whose
-summation order is unspecified; the kernel adds in row order); BasicLayer bf16 5e-2, fp32 with fp16 attention 6e-3 * max|ref|."""
+summation order is unspecified; the kernel adds in row order); BasicLayer bf16 2e-2, fp32 with fp16 / bf16 attention 1e-3 / 6e-3 * max|ref|."""
 import json
 import os
 
@@ -159,7 +159,7 @@ def test_swin_basic_layer_matches_reference_golden(gold, name, mode):
     y = layer(C.layer_input(name).to(DEV)).float().cpu()
     ref = torch.from_numpy(gold[f"{name}.out"])
     err = (y[:, :C.KEEP[name]] - ref).abs().max().item()
-    tol = {"bf16": 5e-2, "fp32_fp16attn": 6e-3, "fp32_bf16attn": 4e-2}[mode] * max(1.0, ref.abs().max().item())
+    tol = {"bf16": 2e-2, "fp32_fp16attn": 1e-3, "fp32_bf16attn": 6e-3}[mode] * max(1.0, ref.abs().max().item())
     _LOG[f"swin_layer/{name}/{mode}"] = {"max_abs_err": err, "tol": tol, "ref_absmax": ref.abs().max().item()}
     assert y.shape == tuple(C.layer_input(name).shape) and err <= tol, (name, mode, err)
     want = ORA.swin_basic_layer(C.layer_params(name), C.layer_input(name), depth, heads, ws)   # all channels, via the oracle
