@@ -157,7 +157,8 @@ int pgt_window_attention(int32_t dtype, const void* qkv, int32_t ldqkv, void* ou
  * the (D,H,W) token grid, cyclic shift (sd,sh,sw), 27-region mask.  qkv: (B*D*H*W, 3C) rows in (b,d,y,x) order
  * (the fused `qkv` Linear's output, columns [q | k | v]); bias dense (heads, N, N) fp32, N = wd*wh*ww.
  * dtype PGT_BF16 or PGT_F16 with N a multiple of 48 (<= 192, e.g. 3x8x8) and (D,H,W) multiples of the window: the MFMA
- * kernel (fp16 MFMA: BASELINE.json configs[4]).  Everything else - PGT_F32 storage, other N <= 256, feature maps that are
+ * kernel (fp16 MFMA: BASELINE.json configs[4]).  Everything else - PGT_F32 storage, other N (K, V and the N x N
+ * probabilities of a window live in LDS: (2 N (hd + 4) + N (N + 1)) * 4 bytes <= 160 KiB, i.e. N <= ~170), feature maps that are
  * not multiples of the window - takes the general kernel, which pads the grid at the far end of D, H, W as
  * forward_part1 does (:218-223): `pad_row` (3C elements of `dtype`, or NULL = zeros) is the qkv row of a padding token,
  * i.e. the qkv Linear's bias; outputs of padding tokens are not written. */

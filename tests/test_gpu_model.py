@@ -310,6 +310,45 @@ def test_oracle_on_this_host_matches_build_f32(models, cfg, full_sd, golden_wind
     assert rec["lq_max_abs_err"] < 1e-3 and rec["logits_max_abs_err"] < 5e-3
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_default_mode_codes_with_other_weights_and_inputs(cfg, seed):
+    """The 100 % code agreement of the default mode is not a property of weight seed 0 / the golden window: other
+    random-init weights and another window of the synthetic clip, against the CPU oracle run here on the GPU box's host.
+    Every code must equal the oracle's except where the oracle's own top-2 logit margin is below 1e-3."""
+    from oracle import pgt_oracle as O
+    from pgtformer_amd import PGTFormer
+    from pgtformer_amd.manifest import pgtformer_manifest
+    from pgtformer_amd.synth import make_clip, window_from_clip
+    from pgtformer_amd.weightgen import generate_state_dict
+
+    sd = generate_state_dict(pgtformer_manifest(cfg), cfg, seed=seed)
+    lq_u8, _ = make_clip(5, 512, seed=4321 + seed)
+    win = window_from_clip(lq_u8, 2 + seed % 2)
+    x = torch.from_numpy(win.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    taps = {}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    o_out, o_logits, o_lq = O.pgtformer_forward(sd, cfg, x, w=1.0, taps=taps)
+    m = PGTFormer(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m.prepare(DEV, "bf16x3")
+    out, logits, lq = m(x.to(DEV))
+    codes = m.last_codes.cpu().numpy().reshape(-1)
+    want = taps["codes"].numpy().reshape(-1)
+    top2 = o_logits.reshape(-1, o_logits.shape[-1]).topk(2, -1).values
+    margin = (top2[:, 0] - top2[:, 1]).numpy()
+    bad = codes != want
+    d = (out.float().cpu().clamp(0, 1) - o_out.clamp(0, 1))
+    rec = {"code_agreement": float(1.0 - bad.mean()), "mismatches": int(bad.sum()),
+           "max_mismatch_margin": float(margin[bad].max()) if bad.any() else 0.0, "min_margin": float(margin.min()),
+           "logits_err": float((logits.cpu() - o_logits).abs().max()),
+           "psnr_db": float(-10.0 * torch.log10(d.pow(2).mean()))}
+    _LOG[f"whole/bf16x3_seed{seed}_vs_host_oracle"] = rec
+    assert rec["max_mismatch_margin"] < 1e-3 and rec["code_agreement"] >= 0.997, rec
+    assert rec["logits_err"] < 2e-3, rec
+    if not bad.any():
+        assert rec["psnr_db"] >= 34.0, rec
+
+
 def test_stage1_rqvae_matches_reference(models, golden_window):
     from pgtformer_amd.archs.tdcrqvae3_arch import TDCRQVAE3
 

@@ -168,7 +168,7 @@ def test_swin_basic_layer_matches_reference_golden(gold, name, mode):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(1, 3, 32, 32, 512, 8, (3, 5, 5), (0, 2, 2), False), (2, 3, 7, 8, 64, 4, (2, 3, 3), (1, 1, 1), True),
-                                  (1, 4, 8, 8, 128, 4, (2, 4, 4), (1, 2, 2), False), (1, 5, 6, 6, 256, 8, (5, 6, 6), (0, 0, 0), True),
+                                  (1, 4, 8, 8, 128, 4, (2, 4, 4), (1, 2, 2), False), (1, 5, 5, 6, 256, 8, (5, 5, 6), (0, 0, 0), True),
                                   (1, 2, 9, 9, 64, 4, (2, 4, 4), (0, 2, 2), True)])
 def test_window_attention3d_general_kernel(case, dtype):
     """pgt_window_attention3d outside the MFMA kernel's shapes: windows whose token count is not a multiple of 48, feature
