@@ -1,6 +1,7 @@
 // Quantiser look-ups (K9, K10), BiSeNet glue (K13) and the driver-edge conversions.  All HBM-bound.
 #include "common.h"
 #include "pgt_internal.h"
+#include "igemm_common.h"
 
 namespace {
 
@@ -66,14 +67,56 @@ __global__ void embed_rows_kernel(const float* __restrict__ book, int D, const i
     }
 }
 
+// the same with 8 consecutive channels per thread (D, ldo, ldres multiples of 8, 16-byte aligned rows): 32-byte codebook
+// reads, 16-byte (bf16) / 32-byte (fp32) row accesses; element-wise arithmetic identical to the scalar form
+template <typename T>
+__global__ __launch_bounds__(256) void embed_rows_vec8_kernel(const float* __restrict__ book, int D, const int* __restrict__ codes,
+                                                              int rows, T* __restrict__ out, int ldo, int accumulate,
+                                                              T* __restrict__ resid, int ldres) {
+    const int cpr = D >> 3;                                   // 8-channel chunks per row
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cpr) return;
+    const int r = (int)(i / cpr), c = (int)(i - (long)r * cpr) * 8;
+    float e[8], v[8];
+    load8<float>(book + (long)codes[r] * D + c, e);
+    T* o = out + (long)r * ldo + c;
+    if (accumulate) {
+        load8<T>(o, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += e[k];
+        store8<T>(o, v);
+    } else {
+        store8<T>(o, e);
+    }
+    if (resid) {
+        T* rr = resid + (long)r * ldres + c;
+        load8<T>(rr, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] -= e[k];
+        store8<T>(rr, v);
+    }
+}
+
+// |x_r|^2 per row, fp32.  One wave per row; every lane adds its elements in ascending column order (16-byte loads when the
+// row allows), then the 64 partial sums are combined by a butterfly.
 template <typename T>
 __global__ __launch_bounds__(256) void row_sumsq_kernel(const T* __restrict__ x, int ldx, int rows, int C,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int vec) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) { const float v = ldf(x + (long)row * ldx + c); s += v * v; }
+    const T* xr = x + (long)row * ldx;
+    if (vec) {
+        for (int c = lane * 8; c < C; c += 512) {
+            float v[8];
+            load8<T>(xr + c, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k] * v[k];
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) { const float v = ldf(xr + c); s += v * v; }
+    }
     s = wave_sum(s);
     if (lane == 0) out[row] = s;
 }
@@ -350,6 +393,14 @@ extern "C" int pgt_embed_rows(int32_t dtype, const float* codebook, int32_t D, c
                               pgt_stream_t stream) {
     PGT_CHECK(codebook && codes && out, "embed_rows: null argument");
     hipStream_t st = (hipStream_t)stream;
+    const bool vec = D % 8 == 0 && ldo % 8 == 0 && (((uintptr_t)out | (uintptr_t)codebook) & 15) == 0 &&
+                     (!resid || (ldres % 8 == 0 && ((uintptr_t)resid & 15) == 0));
+    if (vec) {
+        const dim3 g8 = grid1d((long)rows * (D / 8));
+        DT_DISPATCH(dtype, "embed_rows",
+                    hipLaunchKernelGGL((embed_rows_vec8_kernel<float>), g8, dim3(256), 0, st, codebook, D, codes, rows, (float*)out, ldo, accumulate, (float*)resid, ldres),
+                    hipLaunchKernelGGL((embed_rows_vec8_kernel<bf16_t>), g8, dim3(256), 0, st, codebook, D, codes, rows, (bf16_t*)out, ldo, accumulate, (bf16_t*)resid, ldres));
+    }
     const dim3 g = grid1d((long)rows * D);
     DT_DISPATCH(dtype, "embed_rows",
                 hipLaunchKernelGGL((embed_rows_kernel<float>), g, dim3(256), 0, st, codebook, D, codes, rows, (float*)out, ldo, accumulate, (float*)resid, ldres),
@@ -361,9 +412,10 @@ extern "C" int pgt_row_sumsq(int32_t dtype, const void* x, int32_t ldx, int32_t 
     PGT_CHECK(x && out, "row_sumsq: null argument");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((rows + 3) / 4);
+    const int vec = C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0;
     DT_DISPATCH(dtype, "row_sumsq",
-                hipLaunchKernelGGL((row_sumsq_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, rows, C, out),
-                hipLaunchKernelGGL((row_sumsq_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, C, out));
+                hipLaunchKernelGGL((row_sumsq_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, rows, C, out, vec),
+                hipLaunchKernelGGL((row_sumsq_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, C, out, vec));
 }
 
 extern "C" int pgt_maxpool3x3s2(int32_t dtype, const void* x, int32_t N, int32_t H, int32_t W, int32_t C, void* y,
