@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--windows-per-forward", type=int, default=16,
                     help="independent 3-frame windows batched into one forward (reference semantics: B separate calls)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="forwards in flight: HIP graphs of one step each on separate streams (1 = one step at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, physical cores))")
     ap.add_argument("--no-roofline", action="store_true")
@@ -208,7 +210,8 @@ def main():
     padded_host = torch.empty((n_local + 2, 512, 512, 3), dtype=torch.uint8).pin_memory()
     padded_host[1:n_local + 1].copy_(clip)
     out_host = torch.empty((n_local, 512, 512, 3), dtype=torch.uint8).pin_memory()
-    runner = WindowRunner(model, 1.0, not args.no_graph, 512, 512, batch=B, overlap=not args.no_overlap, full_tail=args.full_tail)
+    runner = WindowRunner(model, 1.0, not args.no_graph, 512, 512, batch=B, overlap=not args.no_overlap, full_tail=args.full_tail,
+                          lanes=args.lanes)
 
     n_warm = max(B, min(args.warmup * B, n_local))
     warm_host = torch.empty((n_warm + 2, 512, 512, 3), dtype=torch.uint8).pin_memory()   # own buffer: the halo rows
@@ -261,6 +264,7 @@ def main():
                                   "VFHQ-shape clip, random-init weights (BASELINE.json configs[1])",
                       "precision": args.precision, "frames_per_step": B, "frames_per_rank": n_local, "hip_graph": not args.no_graph,
                       "windows_per_forward": B, "per_frame_reuse": not args.no_overlap,
+                      "steps_in_flight": runner.lanes,
                       "decoder_tail": ("all 3 frames of every window" if args.full_tail else
                                        "middle frame only after the last temporal operation (the driver keeps [0][1], inference.py:15; "
                                        "identical restored frames; --full-tail for the reference's discarded work)"),

@@ -455,3 +455,16 @@ def test_driver_119_frame_clip_through_the_real_model(models):
         worst = max(worst, int((out[j].int() - single.int()).abs().max()))
     _LOG["driver_119_frames/fp32"] = {"max_u8_diff_vs_single_window": worst}
     assert worst <= 1
+    # two and three forwards in flight (one HIP graph per lane, batches dealt round-robin): the same frames, bit for bit,
+    # from the pinned-host pipeline and from a device-resident clip
+    for lanes in (2, 3):
+        r2 = WindowRunner(m, 1.0, use_graph=True, batch=16, lanes=lanes)
+        out2 = torch.empty((119, 512, 512, 3), dtype=torch.uint8).pin_memory()
+        restore_clip_host(r2, padded, out2)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2), lanes
+        out3 = torch.zeros((119, 512, 512, 3), dtype=torch.uint8, device=DEV)
+        r2.run_clip(padded.to(DEV), out3)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out3.cpu()), lanes
+        del r2
