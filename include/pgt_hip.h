@@ -89,6 +89,11 @@ typedef struct pgt_conv_desc {
     int32_t gn_img0, gn_nimg;   /* this call covers images gn_img0 .. gn_img0+N-1 of a gn_nimg-image tensor (0, 0 = all N) */
     int32_t res_f32;            /* PGT_BF16X3 with out_f32: the residual is fp32 as well (ldr in floats) - split-bf16
                                  * ARITHMETIC on tensors that are stored in fp32 (BiSeNet's BasicBlocks)              */
+    int32_t x3_fold;            /* PGT_BF16X3, Cout == 64: the weight matrix has 128 rows and TWO K segments per tap and
+                                 * 64-channel block (K = KH*KW*2*Cin, the input visited as [x_hi | x_lo]): rows 0..63 hold
+                                 * [w_hi | w_hi], rows 64..127 [w_lo | 0]; y[n] = acc[n] + acc[n + 64] before activation /
+                                 * residual.  A 64-channel layer then fills the 128-column tile with 2/3 of the K steps
+                                 * (the standard form leaves half of the tile idle for three segments).                  */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,

@@ -448,7 +448,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.post_relu = d->post_relu; p.ldr = d->ldr; p.epi = d->epi; p.ld_dec = d->ld_dec;
     p.ld_shift = d->ld_shift; p.sft_w = d->sft_w; p.out_f32 = d->out_f32;
     p.M = d->N * d->Ho * d->Wo;
-    p.K = d->KH * d->KW * d->Cin * (x3 ? 3 : 1);
+    p.K = d->KH * d->KW * d->Cin * (x3 ? (d->x3_fold ? 2 : 3) : 1);
     p.gn_part = nullptr; p.gn_hdr = nullptr; p.gn_cpg = p.gn_G = p.gn_maxblk = p.gn_hw = 0;
     if (d->gn_groups > 0) {
         PGT_CHECK(g_gn_ws != nullptr, "pgt_conv2d: gn_groups set without a statistics workspace (use pgt_conv2d_gn)");
@@ -467,7 +467,9 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         p.gn_hdr = g_gn_ws + d->gn_sub;
         p.gn_part = g_gn_ws + 8 + ((long)d->gn_sub * nimg + d->gn_img0) * p.gn_maxblk * p.gn_G * 2;
     }
-    p.x3 = x3 ? 1 : 0;
+    p.x3 = x3 ? (d->x3_fold ? 2 : 1) : 0;
+    p.nw = (x3 && d->x3_fold) ? 128 : d->Cout;
+    PGT_CHECK(!d->x3_fold || (x3 && d->Cout == 64 && d->gn_groups == 0), "pgt_conv2d: x3_fold is the 64-output-channel form of dtype PGT_BF16X3 (no statistics epilogue)");
     p.res_f32 = (x3 && d->res_f32) ? 1 : 0;
     PGT_CHECK(!d->res_f32 || (x3 && d->out_f32), "pgt_conv2d: res_f32 goes with dtype PGT_BF16X3 and out_f32");
     p.xlo = d->x_lo ? d->x_lo : d->Cin;
@@ -494,7 +496,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         PGT_CHECK(!residual || p.res_f32 || (d->ldr >= p.rlo + d->Cout && p.rlo % 8 == 0), "pgt_conv2d: bf16x3 residual planes");
         PGT_CHECK(!residual || !p.res_f32 || d->ldr % 4 == 0, "pgt_conv2d: fp32 residual rows must be 16-byte aligned");
         PGT_CHECK(p.vec_epi && (long)d->Cout * p.K * 2 < (1L << 31), "pgt_conv2d: bf16x3 needs Cout %% 8 == 0, 16-byte aligned rows and weights < 2 GiB");
-        const int rc = pgt_igemm4_launch(&p, d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256), st);
+        const int rc = pgt_igemm4_launch(&p, d->x3_fold ? 128 : (d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256)), st);
         PGT_CHECK(rc != 1, "pgt_conv2d: bf16x3 has no %d-column tile (128, 256)", d->force_bn);
         return rc;
     }

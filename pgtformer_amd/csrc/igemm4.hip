@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     //      a_pix = byte offset of the input pixel under filter tap (0,0) (may be "negative" for padding: only used
     //      when the tap is valid), a_mask = valid-tap bits (+ the output pixel's y/x parity in bits 30/31 for UPS).
     const v4i rsrc_x = make_rsrc(p.x, (unsigned)((long)p.N * p.H * p.W * p.ldx * 2));
-    const v4i rsrc_w = make_rsrc(p.w, (unsigned)((long)p.Cout * p.K * 2));
+    const v4i rsrc_w = make_rsrc(p.w, (unsigned)((long)p.nw * p.K * 2));
     const int Hv = UPS ? 2 * p.H : p.H, Wv = UPS ? 2 * p.W : p.W;   // virtual (up-sampled) input size
     const bool pointwise = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0;
     int a_pix[2][PA];
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
             const int sr = (cc >> 1) + (lane >> 4);
             const int slot = (lane & 15) ^ (sr & 15);
             const int n = n0 + 2 * sr + (slot >> 3);
-            b_off[h][g] = n < p.Cout ? (unsigned)((n * p.K + (slot & 7) * 8) * 2) : kOob;
+            b_off[h][g] = n < p.nw ? (unsigned)((n * p.K + (slot & 7) * 8) * 2) : kOob;
         }
     };
     auto setup_a = [&](int h) {   // 32-bit arithmetic throughout: every tensor is < 2 GiB
@@ -189,9 +189,10 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
                 bufdma16(a_sel[h][g], rsrc_x, a_soff, lds0 + buf * STAGE + (g * 128 + h * 64 + wave * 8) * 128);
     };
     auto advance = [&]() {
-        if (X3 && ++seg < 3) {
+        if (X3 && ++seg < (p.x3 == 2 ? 2 : 3)) {
             // next plane of the SAME 64-channel block: K order per block is [x_hi | x_lo | x_hi] (weights [w_hi | w_hi | w_lo]),
-            // so the second read of the hi plane follows the first by two K tiles and hits the cache
+            // so the second read of the hi plane follows the first by two K tiles and hits the cache.  Folded form (x3 == 2,
+            // 64 output channels): [x_hi | x_lo] against rows [w_hi | w_hi] and, in the other tile half, [w_lo | 0]
             a_soff = (c0 + (seg == 1 ? p.xlo : 0)) * 2;
             return;
         }
@@ -337,7 +338,7 @@ template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false> int launch
     p.wo_shift = pow2 ? __builtin_ctz(p.Wo) : -1;
     p.ho_shift = pow2 ? __builtin_ctz(p.Ho) : -1;
     p.nbm = (p.M + BM - 1) / BM;
-    p.nbn = (p.Cout + BN - 1) / BN;
+    p.nbn = (p.nw + BN - 1) / BN;
     if (GN) PGT_CHECK(p.gn_hw % BM == 0 && BN % p.gn_cpg == 0, "igemm4: GroupNorm statistics need HW %% %d == 0 (HW=%d) and whole groups per tile", BM, p.gn_hw);
     // the attribute is per device and per function: set it once per (device, instantiation), thread-safe
     static std::atomic<unsigned long long> attr_set{0};

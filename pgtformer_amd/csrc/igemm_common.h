@@ -40,6 +40,7 @@ struct ConvP {
     int x3;                     // split-bf16 operands: x = [hi | lo] planes, K runs over [x_hi | x_lo | x_hi] per tap
     int xlo, ylo, rlo;          // element offset of the lo plane inside a pixel row of x / y / residual
     int res_f32;                // x3 with fp32 output: the residual is fp32 too (ldr counts floats)
+    int nw;                     // rows of the weight matrix = GEMM columns (Cout; 128 for the folded 64-channel x3 form, x3 == 2)
     // GroupNorm statistics of the OUTPUT from the epilogue (gn_part != nullptr): every workgroup tile writes the sum and
     // sum of squares of its outputs per channel group to gn_part[((img * gn_maxblk + k) * gn_G + g) * 2 + {0, 1}], k = the
     // tile's row block inside the image (gn_hw output pixels per image in this launch, a multiple of the tile rows);

@@ -73,6 +73,24 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
                 }
         }
         __syncthreads();
+        if (X3 && p.x3 == 2) {     // folded 64-channel form: columns 64.. hold the x_hi * w_lo products of channels 0..63
+#pragma unroll 1
+            for (int c = 0; c < CPT; ++c) {
+                const int cidx = tid + 512 * c;
+                const int c8 = (cidx % (BN / 8)) * 8;
+                if (c8 < 64) {
+                    float* sp = stage + (cidx / (BN / 8)) * SROW + c8;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 4) {
+                        float4 a = *reinterpret_cast<const float4*>(sp + e);
+                        const float4 b = *reinterpret_cast<const float4*>(sp + 64 + e);
+                        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                        *reinterpret_cast<float4*>(sp + e) = a;
+                    }
+                }
+            }
+            __syncthreads();       // the activation below rewrites chunks other threads have just read
+        }
         if (p.act != ACT_NONE) {   // in place on the thread's own chunks, in a ROLLED loop: one copy of the switch
 #pragma unroll 1
             for (int c = 0; c < CPT; ++c) {

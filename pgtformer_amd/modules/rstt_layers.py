@@ -10,12 +10,16 @@ kernel.
 torch.nn modules are used as PARAMETER CONTAINERS only (so checkpoints load unchanged); their
 forward() is never called.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import ops
 from ..ops import ACT_GELU, ACT_NONE, ACT_SILU, X3, X3F
+
+USE_X3_FOLD = os.environ.get("PGT_X3_FOLD", "1") != "0"   # A/B switch of the folded 64-channel split-bf16 convs
 
 
 class HipModule(nn.Module):
@@ -83,12 +87,26 @@ class Conv2d(nn.Conv2d, HipModule):
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, self.cin_pad - cin))
         self.pw = _pack_matrix(w.permute(0, 2, 3, 1).reshape(cout, -1), kh * kw, device, dtype)
         self.pb = _f32(b, device)
+        # split-bf16 layers with 64 output channels: the folded form fills the 128-column tile (pgt_conv_desc.x3_fold)
+        self.pw_fold = None
+        cin_k = self._fold_cin = w.shape[1]
+        if (_is_x3(dtype) or _is_x3f(dtype)) and cout == 64 and cin_k % 64 == 0 and USE_X3_FOLD:
+            self.pw_fold = ops.pack_x3_fold_weight(w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin_k)).to(device)
 
     def run(self, x, **kw):
+        fold = self.pw_fold is not None
+        if fold and kw.get("gn") is not None:
+            if self._fold_cin == 64 and self.kernel_size[0] == 3:
+                kw = {k: v for k, v in kw.items() if k != "gn"}     # these layers leave no epilogue statistics (ops.gn_ok)
+            else:
+                fold = False
+        w = self.pw_fold if fold else self.pw
+        if fold:
+            kw = dict(kw, x3_fold=True)
         if _is_x3f(self.dt):     # fp32 in / fp32 out, split-bf16 MFMA arithmetic in between
-            return ops.conv2d(ops.to_x3(x), self.pw, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
+            return ops.conv2d(ops.to_x3(x), w, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
                               stride=self.stride[0], pad=self.pad4, x3=True, out_f32=True, **kw)
-        return ops.conv2d(x, self.pw, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
+        return ops.conv2d(x, w, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
                           stride=self.stride[0], pad=self.pad4, x3=_is_x3(self.dt), **kw)
 
 

@@ -65,6 +65,22 @@ def pack_x3_weight(w3):
     return torch.cat([hi4, hi4, lo4], 3).reshape(cout, -1).contiguous()
 
 
+def pack_x3_fold_weight(w3):
+    """Folded form for 64-output-channel layers (pgt_conv_desc.x3_fold): w3 fp32 (64, taps, Cin) -> bf16 (128, taps*2*Cin):
+    rows 0..63 hold [w_hi | w_hi] per tap and 64-channel block, rows 64..127 [w_lo | 0]; the kernel visits the input as
+    [x_hi | x_lo] per block and adds the two halves of its 128-column tile: x_hi*w_hi + x_lo*w_hi + x_hi*w_lo in two K
+    segments instead of three, on a tile that is full instead of half idle."""
+    w3 = w3.float()
+    cout, taps, cin = w3.shape
+    assert cout == 64 and cin % 64 == 0
+    hi = w3.to(torch.bfloat16)
+    lo = (w3 - hi.float()).to(torch.bfloat16)
+    hi4, lo4 = hi.reshape(cout, taps, cin // 64, 1, 64), lo.reshape(cout, taps, cin // 64, 1, 64)
+    top = torch.cat([hi4, hi4], 3).reshape(cout, -1)
+    bot = torch.cat([lo4, torch.zeros_like(lo4)], 3).reshape(cout, -1)
+    return torch.cat([top, bot], 0).contiguous()
+
+
 def to_x3(x, out=None):
     """fp32 (..., C) -> split-bf16 (..., 2C)."""
     assert x.dtype == torch.float32 and x.stride(-1) == 1
@@ -219,7 +235,7 @@ def _tune_conv(d, args, device, iters=4, gn_ws=None):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None, x3=False, gn=None):
+           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout).
     out_parity=(py, px): write the (N,Ho,Wo,Cout) result to out[:, py::2, px::2, :] of a required (N,2Ho,2Wo,Cout) `out`
@@ -234,7 +250,11 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     if x3:   # split-bf16 operands: x (N,H,W,2*Cin) = [hi | lo], w (Cout, kh*kw*3*Cin), y (N,Ho,Wo,2*Cout) unless out_f32
         assert x.dtype == torch.bfloat16 and cin % 2 == 0 and sft is None and not ups and out_rows is None and out_parity is None
         cin //= 2
-        assert w.shape[1] == kh * kw * 3 * cin, (w.shape, kh, kw, cin)
+        if x3_fold:   # 64 output channels, w = pack_x3_fold_weight(...): (128, kh*kw*2*Cin)
+            assert cout == 128 and w.shape[1] == kh * kw * 2 * cin and gn is None, (w.shape, kh, kw, cin)
+            cout = 64
+        else:
+            assert w.shape[1] == kh * kw * 3 * cin, (w.shape, kh, kw, cin)
     else:
         assert w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
     assert w.dtype == x.dtype and w.is_contiguous()
@@ -256,7 +276,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                    res=None if res is None else res[sl], post_relu=post_relu,
                    sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
                    tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3,
-                   gn=None if st is None else (st, 0, i))
+                   gn=None if st is None else (st, 0, i), x3_fold=x3_fold)
         return out if st is None else st.bind(out, cst)
     hv, wv = (h * 2, wd * 2) if ups else (h, wd)
     ho = (hv + pad[0] + pad[1] - kh) // stride + 1
@@ -283,6 +303,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.kernel = int(kernel)
     d.splitk = int(splitk)
     d.stages = int(stages)
+    d.x3_fold = int(bool(x3_fold))
     if out_rows is not None:
         d.orow_mul, d.orow_xmul, d.orow_off = out_rows
     st = None        # epilogue GroupNorm statistics

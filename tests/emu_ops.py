@@ -81,14 +81,21 @@ def _store(val, out, dtype):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None, x3=False, gn=None):
+           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False):
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     if x3:
         assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and sft is None and not ups
         cin //= 2
         x = _merge(x)
-        w = _unpack_x3_weight(w, kh * kw)
+        if x3_fold:   # (128, taps*2*Cin): rows 0..63 [w_hi | w_hi], rows 64..127 [w_lo | 0] per tap and 64-channel block
+            assert cout == 128
+            w5 = w.float().reshape(128, kh * kw, -1, 2, 64)
+            assert torch.equal(w5[:64, :, :, 0], w5[:64, :, :, 1]) and not w5[64:, :, :, 1].any()
+            w = (w5[:64, :, :, 0] + w5[64:, :, :, 0]).reshape(64, -1)
+            cout = 64
+        else:
+            w = _unpack_x3_weight(w, kh * kw)
         if res is not None:
             res = res if res.dtype == torch.float32 else _merge(res)      # fp32 residual: fp32-stored tensors (BiSeNet)
     assert w.shape[1] == kh * kw * cin and w.dtype == x.dtype

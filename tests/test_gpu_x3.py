@@ -212,3 +212,50 @@ def test_conv2d_x3_on_fp32_stored_tensors(stride):
     w1 = rnd((128, 128), 305, 0.1)
     got = ops().conv2d(g(E.to_x3(pooled)), g(ops().pack_x3_weight(w1.reshape(128, 1, 128))), None, act=E.ACT_SIGMOID, x3=True, out_f32=True)
     check("x3_pooled_gate", got, E.conv2d(E.to_x3(pooled), ops().pack_x3_weight(w1.reshape(128, 1, 128)), None, act=E.ACT_SIGMOID, x3=True, out_f32=True))
+
+
+X3_FOLD = [
+    # name, N,H,W,Cin,k,stride,pad4   (Cout = 64)
+    ("fold_c3x3_64", 2, 32, 32, 64, 3, 1, (1, 1, 1, 1)),
+    ("fold_c3x3_64_s2", 2, 32, 32, 64, 3, 2, (0, 1, 0, 1)),
+    ("fold_c3x3_128_64", 3, 16, 24, 128, 3, 1, (1, 1, 1, 1)),
+    ("fold_c1x1_256_64", 2, 16, 16, 256, 1, 1, (0, 0, 0, 0)),
+    ("fold_c3x3_64_ragged_m", 1, 19, 23, 64, 3, 1, (1, 1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", X3_FOLD, ids=[c[0] for c in X3_FOLD])
+def test_conv2d_x3_folded_64_channel_form(case):
+    """pgt_conv_desc.x3_fold: 64 output channels on the full 128-column tile - rows [w_hi | w_hi] and [w_lo | 0], the
+    input visited as [x_hi | x_lo], y[n] = acc[n] + acc[n + 64] - against the emulation and against the standard
+    three-segment form (same products, different summation order: 1e-4 like every x3 kernel)."""
+    name, n, h, w_, cin, k, stride, pad4 = case
+    cout = 64
+    x = rnd((n, h, w_, cin), 20)
+    wt = rnd((cout, k * k * cin), 21, 1.0 / np.sqrt(k * k * cin))
+    wt[:, 0] += torch.arange(cout, dtype=torch.float32) * 0.01
+    b = rnd((cout,), 22, 0.1)
+    xs = E.to_x3(x)
+    wf = ops().pack_x3_fold_weight(wt.reshape(cout, k * k, cin))
+    w3 = ops().pack_x3_weight(wt.reshape(cout, k * k, cin))
+    assert wf.shape == (128, k * k * 2 * cin)
+    kw = dict(kh=k, kw=k, stride=stride, pad=pad4, x3=True)
+    for act in (E.ACT_NONE, E.ACT_RELU, E.ACT_SILU):
+        want = E.from_x3(E.conv2d(xs, wf, b, act=act, x3_fold=True, **kw))
+        got = ops().conv2d(g(xs), g(wf), g(b), act=act, x3_fold=True, **kw)
+        assert got.dtype == torch.bfloat16 and got.shape[-1] == 2 * cout
+        check(f"{name}_act{act}", ops().from_x3(got), want)
+        std = ops().conv2d(g(xs), g(w3), g(b), act=act, **kw)
+        check(f"{name}_act{act}_vs_3seg", ops().from_x3(got), ops().from_x3(std))
+    res = E.to_x3(rnd(tuple(want.shape), 23))
+    got = ops().conv2d(g(xs), g(wf), g(b), res=g(res), x3_fold=True, **kw)
+    check(f"{name}_res", ops().from_x3(got), E.from_x3(E.conv2d(xs, wf, b, res=res, x3_fold=True, **kw)))
+    # fp32-stored tensors (BiSeNet BasicBlocks): fp32 residual, post-ReLU, fp32 out
+    ho, wo = got.shape[1], got.shape[2]
+    rf = rnd((n, ho, wo, cout), 24)
+    kw2 = dict(kw, out_f32=True, post_relu=True)
+    got = ops().conv2d(g(xs), g(wf), g(b), res=g(rf), x3_fold=True, **kw2)
+    assert got.dtype == torch.float32 and got.shape[-1] == cout
+    check(f"{name}_f32", got, E.conv2d(xs, wf, b, res=rf, x3_fold=True, **kw2))
+    again = ops().conv2d(g(xs), g(wf), g(b), res=g(rf), x3_fold=True, **kw2)
+    assert torch.equal(got, again)

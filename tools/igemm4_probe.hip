@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     p.x = (const char*)x; p.w = (const char*)w; p.bias = bias; p.y = (char*)y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.ldx = Cin; p.KH = p.KW = k; p.stride = 1; p.pad_t = p.pad_l = k / 2;
     p.ups = ups; p.Ho = ups ? 2 * H : H; p.Wo = ups ? 2 * W : W; p.Cout = Cout; p.ldy = Cout; p.vec_epi = 1;
-    p.M = N * p.Ho * p.Wo; p.K = k * k * Cin;
+    p.M = N * p.Ho * p.Wo; p.K = k * k * Cin; p.nw = Cout;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     PROBE_LAUNCH(&p, bn);
