@@ -1,7 +1,10 @@
 """Driver plumbing (BASELINE config 1 geometry: 119 frames of 512x512 rgb24; here a small frame size) on CPU:
 raw rgb24 file I/O, the reference window policy (first/last frame replicated, inference.py:38-74), batching of
 windows with a ragged tail, and output order.  A stub stands in for the model (the real one needs the GPU)."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 from oracle import pgt_oracle as O
@@ -96,3 +99,71 @@ def test_padded_clip_layout():
     clip = _clip(5)
     padded = parallel.padded_local_clip(clip, 0, 1)
     assert padded[:, 0, 0, 0].tolist() == [0, 0, 1, 2, 3, 4, 4]
+
+
+_FAKE_FFMPEG = r"""#!/usr/bin/env python3
+# test stand-in for the ffmpeg binary: checks the reference's argument lists (inference.py:23-35) and moves raw rgb24
+# bytes, "decoding" <input> by copying it to stdout and "encoding" stdin by copying it to <output>
+import sys
+a = sys.argv[1:]
+if "image2pipe" in a:
+    assert a[0] == "-i" and a[2:] == ["-f", "image2pipe", "-pix_fmt", "rgb24", "-vcodec", "rawvideo", "-"], a
+    with open(a[1], "rb") as f:
+        while True:
+            b = f.read(1 << 20)
+            if not b:
+                break
+            sys.stdout.buffer.write(b)
+else:
+    assert a[:7] == ["-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", a[6]] and "x" in a[6], a
+    assert a[7] == "-r" and a[9:12] == ["-i", "-", "-an"], a
+    assert a[12:18] == ["-vcodec", "libx265", "-crf", "18", "-tag:v", "hvc1"], a
+    with open(a[18], "wb") as f:
+        f.write(("%s@%s\n" % (a[6], a[8])).encode())
+        while True:
+            b = sys.stdin.buffer.read(1 << 20)
+            if not b:
+                break
+            f.write(b)
+"""
+
+_FAKE_FFPROBE = r"""#!/usr/bin/env python3
+import sys
+a = sys.argv[1:]
+assert a[:8] == ["-v", "error", "-select_streams", "v:0", "-show_entries", "stream=width,height,r_frame_rate", "-of", "csv=p=0"], a
+print("8,6,30000/1001")
+"""
+
+
+def test_ffmpeg_pipe_protocol_with_stub_binaries(tmp_path, monkeypatch):
+    """The mp4 branches of the driver (probe with ffprobe, decode / encode through ffmpeg pipes with the reference's
+    arguments, inference.py:23-35, W*H*3 bytes per frame, chunked reads) against stand-in binaries that check the
+    argument lists and pass raw rgb24 through - the container has no ffmpeg."""
+    import stat
+
+    from pgtformer_amd import driver
+
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    for name, body in (("ffmpeg", _FAKE_FFMPEG), ("ffprobe", _FAKE_FFPROBE)):
+        p = bindir / name
+        p.write_text(body)
+        p.chmod(p.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ.get("PATH", ""))
+    clip = np.random.default_rng(5).integers(0, 256, (11, 6, 8, 3), dtype=np.uint8)
+    src = tmp_path / "in.mp4"
+    src.write_bytes(clip.tobytes())                       # the stub "decodes" by copying
+    assert driver.probe_video(str(src)) == (8, 6, 30000 / 1001)
+    chunks = list(driver.iter_frames(str(src), 8, 6, chunk=4))
+    assert [c.shape[0] for c in chunks] == [4, 4, 3] and np.array_equal(np.concatenate(chunks, 0), clip)
+    assert np.array_equal(driver.read_frames(str(src), 8, 6), clip)
+    with pytest.raises(ValueError):
+        list(driver.iter_frames(str(src), 16, 16))        # the probed geometry must match the model's
+    dst = tmp_path / "out.mp4"
+    wr = driver.FrameWriter(str(dst), 8, 6, fps=29.97)
+    for c in chunks:
+        wr.write(c)
+    wr.close()
+    raw = dst.read_bytes()
+    head, body = raw.split(b"\n", 1)
+    assert head == b"8x6@29.97" and body == clip.tobytes()
