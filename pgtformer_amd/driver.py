@@ -236,6 +236,52 @@ def restore_clip_host(runner, padded_host, out_host, rank=0, world=1, group=None
     return runner.run_clip(padded_host, out_host)
 
 
+def restore_stream(runner, chunks, sink, segment=256):
+    """Bounded-memory form for clips of any length: `chunks` yields uint8 (k,H,W,3) arrays (iter_frames), `sink` receives
+    the restored frames in order as uint8 numpy arrays.  The clip is cut into segments of `segment` frames; a segment's
+    halos are the last frame of the previous segment and the first frame after it (replicated at the clip ends, the reference
+    driver's first / last frame duplication, inference.py:38-74), so the result equals one pass over the whole clip.  Two
+    pinned staging buffers of segment + 2 and segment frames are all the host memory held.  Returns the frame count."""
+    it = iter(chunks)
+    buf, nbuf, prev, total, eof = [], 0, None, 0, False
+    pin_in = pin_out = None
+    cuda = runner.dev.type == "cuda"
+    while True:
+        while not eof and nbuf < segment + 1:
+            try:
+                c = next(it)
+            except StopIteration:
+                eof = True
+                break
+            if c.shape[0]:
+                buf.append(np.asarray(c))
+                nbuf += c.shape[0]
+        if nbuf == 0:
+            break
+        frames = buf[0] if len(buf) == 1 else np.concatenate(buf, 0)
+        take = nbuf if eof else segment          # not at the end: >= segment + 1 frames are held, the extra one is the halo
+        seg, rest = frames[:take], frames[take:]
+        if pin_in is None or pin_in.shape[0] < take + 2:
+            shape = tuple(frames.shape[1:])
+            pin_in = torch.empty((max(take, segment) + 2,) + shape, dtype=torch.uint8)
+            pin_out = torch.empty((max(take, segment),) + shape, dtype=torch.uint8)
+            if cuda:
+                pin_in, pin_out = pin_in.pin_memory(), pin_out.pin_memory()
+        pin_in[0].copy_(torch.from_numpy(np.ascontiguousarray(prev if prev is not None else seg[0])))
+        pin_in[1:take + 1].copy_(torch.from_numpy(np.ascontiguousarray(seg)))
+        pin_in[take + 1].copy_(torch.from_numpy(np.ascontiguousarray(rest[0] if rest.shape[0] else seg[-1])))
+        runner.run_clip(pin_in[:take + 2], pin_out[:take])
+        if cuda:
+            torch.cuda.synchronize(runner.dev)
+        sink(pin_out[:take].numpy())
+        prev = np.array(seg[-1])
+        buf, nbuf = ([rest], rest.shape[0]) if rest.shape[0] else ([], 0)
+        total += take
+        if eof and nbuf == 0:
+            break
+    return total
+
+
 # ---- frame I/O (raw rgb24 files, or ffmpeg pipes with the reference's arguments) -----------------
 def probe_video(path):
     """(width, height, fps) of a video file through ffprobe (the reference probes with cv2.VideoCapture,
@@ -367,6 +413,7 @@ def main(argv=None):
     ap.add_argument("--synthetic", action="store_true", help="random-init weights (smoke tests only)")
     ap.add_argument("--batch", type=int, default=16, help="sliding windows per forward")
     ap.add_argument("--lanes", type=int, default=2, help="forwards in flight (HIP graphs on separate streams)")
+    ap.add_argument("--segment", type=int, default=256, help="frames held in host memory at a time (multiple of --batch)")
     args = ap.parse_args(argv)
     if args.weights is None and not args.synthetic:
         ap.error("--weights is required (the reference downloads kepeng/pgtformer-base; no network here). "
@@ -379,21 +426,12 @@ def main(argv=None):
             fps = 30
     model = load_architecture(args.precision, args.weights, synthetic=args.synthetic)
     runner = WindowRunner(model, 1.0, True, args.size, args.size, batch=args.batch, lanes=args.lanes)
-    # the clip is decoded in chunks into one pinned buffer, restored by the pipelined host path and written out
-    chunks = list(iter_frames(args.input_video, args.size, args.size))
-    n = sum(c.shape[0] for c in chunks)
-    padded = torch.empty((n + 2, args.size, args.size, 3), dtype=torch.uint8).pin_memory()
-    o = 1
-    for c in chunks:
-        padded[o:o + c.shape[0]].copy_(torch.from_numpy(c))
-        o += c.shape[0]
-    out = torch.empty((n, args.size, args.size, 3), dtype=torch.uint8).pin_memory()
-    restore_clip_host(runner, padded, out)
-    torch.cuda.synchronize()
+    # decode -> restore -> encode in segments: bounded host memory for clips of any length
     os.makedirs(os.path.dirname(os.path.abspath(args.output_video)), exist_ok=True)
     wr = FrameWriter(args.output_video, args.size, args.size, fps)
-    wr.write(out.numpy())
+    n = restore_stream(runner, iter_frames(args.input_video, args.size, args.size), wr.write, segment=args.segment)
     wr.close()
+    print(f"{n} frames restored -> {args.output_video}")
 
 
 if __name__ == "__main__":

@@ -468,3 +468,34 @@ def test_driver_119_frame_clip_through_the_real_model(models):
         torch.cuda.synchronize()
         assert torch.equal(out, out3.cpu()), lanes
         del r2
+
+
+def test_cli_streams_a_raw_clip_end_to_end(models, tmp_path):
+    """`python -m pgtformer_amd.driver -i clip.rgb -o out.rgb --synthetic` (the counterpart of `python inference.py -i .. -o ..`):
+    decode in chunks -> segments with 1-frame halos -> pipelined restore -> sink; 21 frames in segments of 16, 8 windows per
+    forward, against one pass of the in-process driver over the whole clip (same synthetic weights, fp32 mode: u8 within
+    +-1; in the bf16 modes two processes that tune to different kernel variants differ at the decoder's 35 dB bf16 floor)."""
+    import subprocess
+    import sys
+
+    from pgtformer_amd.driver import WindowRunner, restore_clip_host
+    from pgtformer_amd.synth import make_clip
+
+    base, _ = make_clip(7, 512, seed=21)
+    clip = np.concatenate([base] * 3, 0)
+    src, dst = tmp_path / "clip.rgb", tmp_path / "out" / "restored.rgb"
+    src.write_bytes(clip.tobytes())
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pgtformer_amd.driver", "-i", str(src), "-o", str(dst), "--synthetic", "--batch", "8",
+                        "--segment", "16", "--precision", "fp32"], cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    got = np.frombuffer(dst.read_bytes(), np.uint8).reshape(21, 512, 512, 3)
+    m = models["fp32"]
+    padded = torch.empty((23, 512, 512, 3), dtype=torch.uint8).pin_memory()
+    padded[1:22].copy_(torch.from_numpy(clip))
+    want = torch.empty((21, 512, 512, 3), dtype=torch.uint8).pin_memory()
+    restore_clip_host(WindowRunner(m, 1.0, use_graph=True, batch=8, lanes=2), padded, want)
+    torch.cuda.synchronize()
+    d = np.abs(got.astype(np.int16) - want.numpy().astype(np.int16))
+    _LOG["cli_stream/fp32"] = {"max_u8_diff": int(d.max()), "equal_fraction": float((d == 0).mean())}
+    assert d.max() <= 1 and (d == 0).mean() > 0.99, _LOG["cli_stream/fp32"]
