@@ -23,7 +23,7 @@ constexpr int KSTR = 144;   // K tile row stride in bytes (128 + 16 pad): confli
 constexpr int VSTR = 136;   // V^T row stride in bytes (64 keys * 2 + 8): conflict-free ds_read_b64
 
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf2(lo, hi); }   // v_cvt_pk_bf16_f32
-// raw v_exp_f32 (2^x): arguments here are <= 0 and results feed a bf16 operand, no range fix-up needed
+// raw v_exp_f32 (2^x): arguments here are <= 8 and results feed a bf16 operand, no range fix-up needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // X3: q, k, v and out are split-bf16 rows, lo planes qlo / klo / vlo / olo elements after the hi planes; S^T and O^T
@@ -142,9 +142,20 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m, mx);
-        const float alpha = fast_exp2((m - mnew) * c);
-        const float mc = mnew * c;
+        // Lazy rescale, exp2 domain (m = reference exponent of this query, scale folded in): the running sum and the
+        // accumulators are rescaled only when some query of the wave would exceed the reference by 2^8 - P <= 256 is as
+        // precise in bf16 / split-bf16 as P <= 1, and after the first tiles the 32 + 2 multiplies per tile disappear.
+        const float tmx = mx * c;
+        if (__any(tmx > m + 8.0f)) {
+            const float mnew = fmaxf(m, tmx);
+            const float alpha = fast_exp2(m - mnew);     // first tile: m = -inf -> 0 (l and o are 0)
+            l *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+            m = mnew;
+        }
         float lsum = 0.f;
         uint4 pf[2][2], pfl[X3 ? 2 : 1][2];   // P^T B-operands: [key block][k-step]
 #pragma unroll
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
             float p[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                p[e] = fast_exp2(X3 ? (s[kb][e] - mnew) * c : s[kb][e] * c - mc);
+                p[e] = fast_exp2(__builtin_fmaf(s[kb][e], c, -m));
                 lsum += p[e];
             }
             pf[kb][0] = make_uint4(pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7]));
@@ -170,12 +181,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
                 }
             }
         }
-        l = l * alpha + lsum;
-        m = mnew;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        l += lsum;
         // ---- O^T += V^T P^T : 2 head-dim blocks x (2 key blocks x 2 k-steps)
 #pragma unroll
         for (int d = 0; d < 2; ++d)
