@@ -10,7 +10,9 @@
 // contributes to k-step s if the keys inside each 16-key group are taken in the order
 // {4h..4h+3, 8+4h..8+4h+3}; V^T fragments are read with the same key order (two ds_read_b64), so the
 // contraction is unchanged and P never round-trips through LDS.
-// Workgroup = 4 waves x 32 queries; K/V streamed in 64-key tiles through a DOUBLE-buffered LDS stage: tile t+1 is
+// Workgroup = NW waves x 32 queries (NW = 8 for long sequences: the K / V staging - global loads, the V transpose through
+// 4-byte LDS stores, the barrier - is paid once per 256 queries instead of once per 128; measured on the L = 3072 layer:
+// staging 34 % of the kernel at NW = 4); K/V streamed in 64-key tiles through a DOUBLE-buffered LDS stage: tile t+1 is
 // fetched into registers while tile t is multiplied and written to the other stage afterwards - one barrier per tile.
 #include "common.h"
 #include "pgt_internal.h"
@@ -28,8 +30,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 // X3: q, k, v and out are split-bf16 rows, lo planes qlo / klo / vlo / olo elements after the hi planes; S^T and O^T
 // take three MFMAs per product (hi*hi + lo*hi + hi*lo), P is split in registers after the exp.
-template <bool X3>
-__global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k,
+template <bool X3, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k,
                                                        int ldk, const uint16_t* __restrict__ v, int ldv,
                                                        uint16_t* __restrict__ out, int ldo, int L, float c /* scale*log2(e) */,
                                                        int qlo, int klo, int vlo, int olo) {
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int qi = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int qi = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
     const long rowbase = (long)b * L;
 
     // Q^T fragments (B operand of S^T): 4 k-steps of 16 head-dims, this half's 8 dims each
@@ -54,22 +56,40 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
             if (qi < L) qfl[s] = *reinterpret_cast<const uint4*>(q + (rowbase + qi) * ldq + qlo + head * HD + s * 16 + h * 8);
         }
     }
-    // staging roles
-    const int k_r0 = tid >> 3, k_cc = tid & 7;      // K: rows k_r0, k_r0+32; 16-byte chunk k_cc
-    const int v_kp = tid >> 3, v_c = tid & 7;       // V: key pair (2kp, 2kp+1), head-dim chunk 8c..8c+7
-    uint4 rk[NP][2], rv[NP][2];
+    // staging roles.  K: 64 rows x 8 16-byte chunks = 512 pieces; V: 32 key pairs x 8 head-dim chunks, transposed on the
+    // way into LDS (dword = {V[2kp][d], V[2kp+1][d]} -> Vt[d][2kp..2kp+1]).  NW = 4: two K pieces and one whole V chunk
+    // per thread; NW = 8: one K piece and half a V chunk (4 head dims) per thread.
+    constexpr int KPT = 8 / NW;                     // K pieces per thread
+    constexpr int VH = NW / 4;                      // V chunk halves: 1 (8 dims per thread) or 2 (4 dims per thread)
+    const int k_r0 = tid >> 3, k_cc = tid & 7;      // K: rows k_r0 (+ 32 for the second piece at NW = 4); chunk k_cc
+    const int v_item = tid / VH, v_half = tid % VH;
+    const int v_kp = v_item >> 3, v_c = v_item & 7; // V: key pair (2kp, 2kp+1), head-dim chunk 8c..8c+7 (half v_half)
+    uint4 rk[NP][KPT], rv[NP][2];                   // rv: for VH = 2 only .x/.y (4 dims) are used
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < KPT; ++i) {
                 const int kj = k0 + k_r0 + 32 * i;
                 rk[pl][i] = make_uint4(0, 0, 0, 0);
                 if (kj < L) rk[pl][i] = *reinterpret_cast<const uint4*>(k + (rowbase + kj) * ldk + pl * klo + head * HD + k_cc * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
                 const int vj = k0 + 2 * v_kp + i;
                 rv[pl][i] = make_uint4(0, 0, 0, 0);
-                if (vj < L) rv[pl][i] = *reinterpret_cast<const uint4*>(v + (rowbase + vj) * ldv + pl * vlo + head * HD + v_c * 8);
+                if (vj < L) {
+                    const uint16_t* vp = v + (rowbase + vj) * ldv + pl * vlo + head * HD + v_c * 8 + v_half * 4;
+                    if constexpr (VH == 1) {
+                        rv[pl][i] = *reinterpret_cast<const uint4*>(vp);
+                    } else {
+                        const uint2 t2 = *reinterpret_cast<const uint2*>(vp);
+                        rv[pl][i].x = t2.x;
+                        rv[pl][i].y = t2.y;
+                    }
+                }
             }
+        }
     };
     auto sstore = [&](int buf) {
         char* Ks = smem + buf * STAGE;
@@ -77,16 +97,17 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const uint16_t* __restric
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(Ks + pl * PLANE + (k_r0 + 32 * i) * KSTR + k_cc * 16) = rk[pl][i];
+            for (int i = 0; i < KPT; ++i) *reinterpret_cast<uint4*>(Ks + pl * PLANE + (k_r0 + 32 * i) * KSTR + k_cc * 16) = rk[pl][i];
             // transpose V: dword = {V[2kp][d], V[2kp+1][d]} -> Vt[d][2kp..2kp+1]
             const uint32_t a[4] = {rv[pl][0].x, rv[pl][0].y, rv[pl][0].z, rv[pl][0].w};
             const uint32_t bb[4] = {rv[pl][1].x, rv[pl][1].y, rv[pl][1].z, rv[pl][1].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4 / VH; ++j) {
                 const uint32_t lo = (a[j] & 0xffffu) | (bb[j] << 16);
                 const uint32_t hi = (a[j] >> 16) | (bb[j] & 0xffff0000u);
-                *reinterpret_cast<uint32_t*>(Vt + pl * PLANE + (v_c * 8 + 2 * j) * VSTR + v_kp * 4) = lo;
-                *reinterpret_cast<uint32_t*>(Vt + pl * PLANE + (v_c * 8 + 2 * j + 1) * VSTR + v_kp * 4) = hi;
+                const int d0 = v_c * 8 + v_half * 4 + 2 * j;
+                *reinterpret_cast<uint32_t*>(Vt + pl * PLANE + d0 * VSTR + v_kp * 4) = lo;
+                *reinterpret_cast<uint32_t*>(Vt + pl * PLANE + (d0 + 1) * VSTR + v_kp * 4) = hi;
             }
         }
     };
@@ -241,13 +262,20 @@ int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void
     PGT_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "mha: row strides must be multiples of 8");
     PGT_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && ((uintptr_t)out & 7) == 0, "mha: misaligned pointer");
     PGT_CHECK(!x3 || (qlo % 8 == 0 && klo % 8 == 0 && vlo % 8 == 0 && olo % 4 == 0), "mha: misaligned lo planes");
-    const dim3 grid((L + 127) / 128, heads, B);
-    if (x3)
-        hipLaunchKernelGGL(mha_mfma_kernel<true>, grid, dim3(256), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
-                           (const uint16_t*)v, ldv, (uint16_t*)out, ldo, L, scale * 1.44269504088896340736f, qlo, klo, vlo, olo);
-    else
-        hipLaunchKernelGGL(mha_mfma_kernel<false>, grid, dim3(256), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk,
-                           (const uint16_t*)v, ldv, (uint16_t*)out, ldo, L, scale * 1.44269504088896340736f, 0, 0, 0, 0);
+    const float c = scale * 1.44269504088896340736f;
+    const int nw = L >= 512 ? 8 : 4;            // 256 queries per workgroup once the sequence is long enough to fill the chip
+    const dim3 grid((L + 32 * nw - 1) / (32 * nw), heads, B);
+#define MHA_GO(X3_, NW_, QLO, KLO, VLO, OLO)                                                                                  \
+    hipLaunchKernelGGL((mha_mfma_kernel<X3_, NW_>), grid, dim3(64 * NW_), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, \
+                       ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, L, c, QLO, KLO, VLO, OLO)
+    if (x3) {
+        if (nw == 8) MHA_GO(true, 8, qlo, klo, vlo, olo);
+        else MHA_GO(true, 4, qlo, klo, vlo, olo);
+    } else {
+        if (nw == 8) MHA_GO(false, 8, 0, 0, 0, 0);
+        else MHA_GO(false, 4, 0, 0, 0, 0);
+    }
+#undef MHA_GO
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -268,7 +268,7 @@ def test_window_attention(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("L", [192, 200])
+@pytest.mark.parametrize("L", [192, 200, 640, 777])
 def test_mha(dtype, L):
     b, heads, hd = 2, 8, 64
     e = heads * hd

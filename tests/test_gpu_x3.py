@@ -164,7 +164,7 @@ def test_window_attention_x3(case):
     check(f"winattn_x3{case}", ops().from_x3(got), want)
 
 
-@pytest.mark.parametrize("L", [192, 200, 3072])
+@pytest.mark.parametrize("L", [192, 200, 640, 777, 3072])
 def test_mha_x3(L):
     b, heads, hd = (2, 8, 64) if L < 1000 else (1, 8, 64)
     e = heads * hd

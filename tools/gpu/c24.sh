@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/c24; mkdir -p $O
+O=gpurun_out/c25; mkdir -p $O
 ( timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_x3.py -m gpu -q -k "mha or transformer or sa_layer" 2>&1 | tail -6 ) > $O/tests.log; tail -3 $O/tests.log
 ( timeout 900 python -m pytest tests/test_gpu_model.py -m gpu -q -k "default_mode or other_weights or f32_matches or golden" 2>&1 | tail -6 ) > $O/tests2.log; tail -3 $O/tests2.log
 cp profiles/r2_v8_autotune_table_b16.json $O/tune.json
