@@ -3,6 +3,11 @@
 #pragma once
 #include "igemm_common.h"
 
+#ifndef PGT_PROBE
+#define PGT_PROBE 0
+#endif
+// probe bits of tools/igemm4_probe.hip inside the epilogue: 64 no global stores, 128 no staging writes, 256 no staging reads
+
 namespace {
 
 template <int WR, int WC> constexpr int epi_stage_bytes() { return WR * 64 * (WC * 64 + 4) * 4; }
@@ -69,7 +74,7 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rl = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    stage[rl * SROW + cl] = acc[pass * 2 + i][j][e] + bv[j];
+                    if (!(PGT_PROBE & 128)) stage[rl * SROW + cl] = acc[pass * 2 + i][j][e] + bv[j];
                 }
         }
         __syncthreads();
@@ -111,8 +116,14 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
             const int m = m0 + (rl >> 6) * 128 + pass * 64 + (rl & 63), n = n0 + c8;
             if (m >= p.M || n >= p.Cout) continue;
             float v[8];
+            if (PGT_PROBE & 256) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)(c8 + e);
+            } else {
             *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8);
             *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(stage + rl * SROW + c8 + 4);
+            }
+            if ((PGT_PROBE & 64) && v[0] != 12345.f) continue;
             if (X3) {
                 if (res) {
                     float r[8];
