@@ -33,7 +33,12 @@ typedef void* pgt_stream_t; /* hipStream_t */
  * formed as hi*hi + lo*hi + hi*lo on the bf16 MFMA with fp32 accumulation (16 significand bits instead of 8): the
  * code-prediction branch runs in this type so that the arg-max codes reproduce the fp32 reference
  * (archs/pgtformer_arch.py:638-664) at bf16-MFMA speed. */
-enum { PGT_F32 = 0, PGT_BF16 = 1, PGT_BF16X3 = 2, PGT_F16 = 3 /* IEEE half storage: pgt_window_attention3d only */ };
+/* PGT_F16: IEEE half storage and operands (v_mfma_f32_32x32x16_f16, fp32 accumulate; fp32 -> half stores saturate at
+ * +-65504): the decoder-side type of the default precision mode - 11 significand bits on the same MFMA rate as bf16's 8,
+ * which is what holds |PSNR(build, GT) - PSNR(reference, GT)| under 1e-3 dB (reference decoder: fp32,
+ * archs/pgtformer_arch.py:684-712).  Accepted by conv2d / linear, the norms, channel statistics, window attention,
+ * embed_rows, copy2d, frame_to_u8, nhwc_to_nchw. */
+enum { PGT_F32 = 0, PGT_BF16 = 1, PGT_BF16X3 = 2, PGT_F16 = 3 };
 enum { PGT_ACT_NONE = 0, PGT_ACT_RELU = 1, PGT_ACT_GELU = 2, PGT_ACT_SILU = 3, PGT_ACT_LEAKY02 = 4, PGT_ACT_SIGMOID = 5 };
 enum { PGT_EPI_PLAIN = 0, PGT_EPI_SFT = 1 };
 
@@ -94,6 +99,8 @@ typedef struct pgt_conv_desc {
                                  * [w_hi | w_hi], rows 64..127 [w_lo | 0]; y[n] = acc[n] + acc[n + 64] before activation /
                                  * residual.  A 64-channel layer then fills the 128-column tile with 2/3 of the K steps
                                  * (the standard form leaves half of the tile idle for three segments).                  */
+    int32_t dec_lo, shift_lo;   /* PGT_BF16X3 with PGT_EPI_SFT: element offsets of the lo planes of sft_dec / sft_shift
+                                 * (0 = Cout): out = dec + sft_w * (dec * act(conv) + shift) on split operands       */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -202,6 +209,10 @@ int pgt_mha_x3(const void* q, int32_t ldq, int32_t q_lo, const void* k, int32_t 
 /* fp32 (rows, cols) <-> split-bf16 planes (hi = bf16(v), lo = bf16(v - hi)) */
 int pgt_x3_split(const float* src, int32_t lds, void* dst, int32_t ldd, int32_t dst_lo, int64_t rows,
                  int32_t cols, pgt_stream_t stream);
+/* split-bf16 planes -> IEEE half rows (the encoder-side feature maps entering the PGT_F16 decoder's fusion blocks,
+ * archs/pgtformer_arch.py:627-630: half keeps 11 of the 16 significand bits, the bf16 hi plane alone 8) */
+int pgt_x3_to_half(const void* src, int32_t lds, int32_t src_lo, void* dst, int32_t ldd, int64_t rows, int32_t cols,
+                   pgt_stream_t stream);
 int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float* dst, int32_t ldd, int64_t rows,
                  int32_t cols, pgt_stream_t stream);
 

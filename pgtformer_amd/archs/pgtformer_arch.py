@@ -482,7 +482,7 @@ class PGTFormer(TDCRQVAE3):
         # encoder.  bf16: the fusion blocks' [enc | dec | fut] concat buffers exist up front and the encoder levels / the
         # decoder levels write their feature maps straight into the enc / dec slices (no concat copies)
         cats, feat_out = {}, None
-        can_direct = (self.dec_dt == torch.bfloat16 and w > 0 and not code_only)
+        can_direct = (self.dec_dt in (torch.bfloat16, torch.float16) and w > 0 and not code_only)
         direct = can_direct if direct is None else (direct and can_direct)
         if direct:
             feat_out = {}
@@ -491,16 +491,17 @@ class PGTFormer(TDCRQVAE3):
                 if blk.w_mix is None:
                     continue
                 res = int(f_size)
-                cats[f_size] = blk.new_concat(bt, res, res, raw.device, torch.bfloat16)
+                cats[f_size] = blk.new_concat(bt, res, res, raw.device, self.dec_dt)
                 feat_out[self.fuse_encoder_indices[f_size]] = cats[f_size][..., :blk.in_ch]
         want = {self.fuse_encoder_indices[f] for f in self.connect_list}
-        z, feats = self.encoder(raw, return_multi_res_feats=True, feat_out=feat_out, win=win, want_feats=want)
+        z, feats = self.encoder(raw, return_multi_res_feats=True, feat_out=feat_out, win=win, want_feats=want,
+                                feat_dtype=self.dec_dt if self.dec_dt == torch.float16 else None)
         enc_feat = {}
         for f_size in self.connect_list:
             f = feats[self.fuse_encoder_indices[f_size]]
             enc_feat[str(f.shape[2])] = f
         lq_feat = self.quant_conv.run(z)                                     # (bt,32,32,512); x3: (bt,32,32,1024)
-        lq_style = lq_feat[..., :lq_feat.shape[3] // 2] if x3 else lq_feat   # AdaIN style statistics: the hi plane
+        lq_style = lq_feat       # AdaIN style statistics (fp32, from the merged hi + lo planes of a split tensor: below)
         # code-prediction transformer over the T*32*32 tokens of each window
         if side is not None:
             torch.cuda.current_stream(raw.device).wait_stream(side)          # join: pos is first used here
@@ -522,7 +523,7 @@ class PGTFormer(TDCRQVAE3):
         self.last_codes = codes.reshape(bt, th, tw, depth)
         quant = self.quantizer.embed_code(self.last_codes, self.dec_dt)      # (bt,32,32,512)
         if adain:
-            quant = adaptive_instance_normalization(quant, lq_style)
+            quant = adaptive_instance_normalization(quant, ops.from_x3(lq_style) if x3 else lq_style)
         z_q = self.post_quant_conv.run(quant)
 
         # the decoder's last temporal operation: a fusion block's temporal mix (w > 0) or an EncoderLayer

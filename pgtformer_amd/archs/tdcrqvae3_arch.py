@@ -19,6 +19,7 @@ import torch.nn as nn
 from .. import ops
 from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _is_x3, prepare_tree)
 from ..ops import ACT_SILU, X3
+from ..config import DEFAULT_PRECISION
 from ..registry import ARCH_REGISTRY
 
 
@@ -340,7 +341,7 @@ class Encoder(HipModule):
         assert _is_x3(cur) == _is_x3(want) and (_is_x3(cur) or cur == want), (cur, want)
         return h
 
-    def forward(self, x, return_multi_res_feats=False, feat_out=None, win=None, want_feats=None):
+    def forward(self, x, return_multi_res_feats=False, feat_out=None, win=None, want_feats=None, feat_dtype=None):
         """x: (F, H, W, 8) channel-padded input (reference: :540-573).  feat_out: {level: (B*T,h,w,C) view} - the
         level's feature map is delivered in that view (a channel slice of the decoder-side concat buffer): written
         in place by the producing kernel when the dtypes and frame order allow it, else copied / gathered into it.
@@ -352,7 +353,8 @@ class Encoder(HipModule):
         attn_resolutions starting at 128), so it runs once per frame and is gathered to window order (B*T frames) where
         the first EncoderLayer starts.  want_feats: levels whose feature maps the caller needs (None: all); the others
         are returned as None (a per-frame 512x512 map would otherwise be gathered for nothing).
-        Feature maps of split-bf16 levels are returned as their hi planes (bf16 views)."""
+        Feature maps of split-bf16 levels are returned as their hi planes (bf16 views), or - feat_dtype=torch.float16, the
+        IEEE-half decoder - as half tensors rounded once from hi + lo (11 significand bits instead of the hi plane's 8)."""
         feats = []
         cur = self.conv_in.dt
         # (the level-0 block starts with a GroupNorm: statistics from conv_in's epilogue unless a dtype conversion intervenes)
@@ -381,7 +383,12 @@ class Encoder(HipModule):
             if not wanted:
                 feats.append(None)
             else:
-                f = h[..., :h.shape[-1] // 2] if _is_x3(cur) else h              # hi plane of a split map
+                if not _is_x3(cur):
+                    f = h
+                elif feat_dtype == torch.float16:
+                    f = ops.x3_to_half(h)                                        # hi + lo -> half, on the unique frames
+                else:
+                    f = h[..., :h.shape[-1] // 2]                                # hi plane of a split map
                 if per_frame:     # per-frame level: cast on the unique frames, then gather to window order
                     if dst is not None and f.dtype != dst.dtype:
                         f = ops.cast(f, dst.dtype)
@@ -476,7 +483,9 @@ class Decoder(HipModule):
                 h = lvl.upsample(h)
         if self.give_pre_end:
             return h
-        return self.conv_out.run(self.norm_out.run(h, ACT_SILU))
+        # the restored frames leave the last conv in fp32 whatever the decoder's storage type (3 channels: free), so the
+        # 16-bit modes do not add an output rounding (2^-12 of [0, 1] in half) on top of their arithmetic
+        return self.conv_out.run(self.norm_out.run(h, ACT_SILU), out_f32=True)
 
 
 class HubMixin:
@@ -521,7 +530,7 @@ class HubMixin:
         return save_directory
 
     @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path, device=None, precision="bf16x3", **model_kwargs):
+    def from_pretrained(cls, pretrained_model_name_or_path, device=None, precision=DEFAULT_PRECISION, **model_kwargs):
         """`PGTFormer.from_pretrained("kepeng/pgtformer-base")` of the reference (inference.py:118).  A local directory
         holding config.json + model.safetensors is loaded directly; a hub id is resolved through huggingface_hub (needs
         network access or a populated cache).  With `device` the model is also prepared (weights repacked for the
@@ -571,16 +580,18 @@ class TDCRQVAE3(HubMixin, HipModule):
     ENC_SIDE = ("encoder", "quant_conv", "quantizer", "conditionnet", "convpos", "feat_emb", "ft_layers", "idx_pred_layer")
     F32_IN_X3 = ("conditionnet", "convpos", "quantizer")    # bf16x3 mode: per-frame BiSeNet + codebook stay exact fp32
 
-    def prepare(self, device="cuda", precision="bf16x3"):
+    def prepare(self, device="cuda", precision=DEFAULT_PRECISION):
         """Repack the weights for the kernels.  precision:
           "fp32"    exact-f32 MFMA everywhere (parity mode)
-          "bf16x3"  decoder / SFT fusion in bf16; the code-prediction branch on split-bf16 operands (3 bf16 MFMAs per
-                    product, 16 significand bits: the arg-max codes reproduce the fp32 reference) with its per-frame,
-                    HBM-bound front (BiSeNet, encoder levels below the first temporal attention) in exact fp32
+          "x3f16"   (default) the code-prediction branch on split-bf16 operands (3 bf16 MFMAs per product, 16 significand
+                    bits: the arg-max codes reproduce the fp32 reference) with its per-frame BiSeNet in fp32 storage;
+                    decoder / SFT fusion in IEEE half (11 significand bits at the bf16 MFMA rate): restored frames within
+                    1e-3 dB PSNR of the fp32 reference at a non-degenerate operating point (tests/golden/make_golden_r3.py)
+          "bf16x3"  as x3f16 with a bf16 decoder (8 significand bits: 5e-3 dB at that operating point; no half range limit)
           "mixed"   decoder bf16, the whole code-prediction branch in exact fp32
           "bf16"    bf16 everywhere (fastest; ~2 % of the codes differ from the fp32 reference with random weights)"""
         dts = {"fp32": (torch.float32, torch.float32), "bf16": (torch.bfloat16, torch.bfloat16),
-               "mixed": (torch.float32, torch.bfloat16), "bf16x3": (X3, torch.bfloat16)}
+               "mixed": (torch.float32, torch.bfloat16), "bf16x3": (X3, torch.bfloat16), "x3f16": (X3, torch.float16)}
         if precision not in dts:
             raise ValueError(f"precision must be one of {list(dts)}")
         self.enc_dt, self.dec_dt = dts[precision]

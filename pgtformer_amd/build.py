@@ -34,17 +34,23 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     hdr_m = max(os.path.getmtime(os.path.join(d, f)) for d in (CSRC, INCLUDE) for f in os.listdir(d)
                 if f.endswith(".h"))
-    objs, rebuilt = [], False
+    objs, todo = [], []
     for src in sources():
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_m):
-            cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
+            todo.append([_hipcc()] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op])
+    rebuilt = bool(todo)
+    if todo:   # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print("[pgt build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            rebuilt = True
+        with ThreadPoolExecutor(max_workers=min(len(todo), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(run, todo))
     if rebuilt or not os.path.exists(LIB):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -46,6 +46,9 @@ DEFAULT_NETWORK_G = {
     },
 }
 
+# precision mode of `model.prepare(device, precision)` when none is named (archs/tdcrqvae3_arch.py: TDCRQVAE3.prepare)
+DEFAULT_PRECISION = "x3f16"
+
 # PGTFormer.__init__ defaults (reference: archs/pgtformer_arch.py:491-495)
 PGTFORMER_DEFAULTS = {
     "dim_embd": 512,

@@ -398,8 +398,8 @@ extern "C" int pgt_window_attention(int32_t dtype, const void* qkv, int32_t ldqk
     const int N = T * wh * ww;
     const int hd = C / heads;
     PGT_CHECK(C % heads == 0 && (hd == 32 || hd == 64), "window_attention: head_dim=%d unsupported (32, 64)", hd);
-    if (dtype == PGT_BF16) {
-        const int rc = pgt_window_attn_mfma(0, qkv, ldqkv, out, ldo, bias, B, T, H, W, C, heads, T, wh, ww, 0, sh, sw,
+    if (dtype == PGT_BF16 || dtype == PGT_F16) {
+        const int rc = pgt_window_attn_mfma(dtype == PGT_F16 ? 2 : 0, qkv, ldqkv, out, ldo, bias, B, T, H, W, C, heads, T, wh, ww, 0, sh, sw,
                                             (hipStream_t)stream);
         if (rc <= 0) return rc;   // 0 = launched, < 0 = error, 1 = shape not covered by the MFMA kernel
     }
@@ -417,6 +417,9 @@ extern "C" int pgt_window_attention(int32_t dtype, const void* qkv, int32_t ldqk
     } else if (dtype == PGT_BF16) {
         if (hd == 32) { if (nmax == 48) WA_LAUNCH(bf16_t, 32, 48); else WA_LAUNCH(bf16_t, 32, 64); }
         else          { if (nmax == 48) WA_LAUNCH(bf16_t, 64, 48); else WA_LAUNCH(bf16_t, 64, 64); }
+    } else if (dtype == PGT_F16) {
+        if (hd == 32) { if (nmax == 48) WA_LAUNCH(half_t, 32, 48); else WA_LAUNCH(half_t, 32, 64); }
+        else          { if (nmax == 48) WA_LAUNCH(half_t, 64, 48); else WA_LAUNCH(half_t, 64, 64); }
     } else {
         PGT_CHECK(false, "window_attention: bad dtype %d", dtype);
     }
@@ -439,6 +442,7 @@ extern "C" int pgt_mha(int32_t dtype, const void* q, int32_t ldq, const void* k,
                        ldv, (TT*)out, ldo, L, scale)
     if (dtype == PGT_F32) { if (hd == 64) MHA_LAUNCH(float, 64); else MHA_LAUNCH(float, 32); }
     else if (dtype == PGT_BF16) { if (hd == 64) MHA_LAUNCH(bf16_t, 64); else MHA_LAUNCH(bf16_t, 32); }
+    else if (dtype == PGT_F16) { if (hd == 64) MHA_LAUNCH(half_t, 64); else MHA_LAUNCH(half_t, 32); }
     else PGT_CHECK(false, "mha: bad dtype %d", dtype);
 #undef MHA_LAUNCH
     PGT_LAUNCH_CHECK();

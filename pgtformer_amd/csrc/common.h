@@ -32,10 +32,19 @@ template <> struct ElemIO<bf16_t> {
     static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(p->v); }
     static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f2bf(v); }
 };
-struct half_t { _Float16 v; };   // IEEE half storage (pgt_window_attention3d, PGT_F16)
+// IEEE half storage (PGT_F16): the decoder-side activation / weight type of the default precision mode (11 significand
+// bits on the same 16-bit MFMA rate as bf16).  fp32 -> half conversions SATURATE at +-65504 instead of producing inf.
+struct half_t { _Float16 v; };
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float sat_half(float f) { return __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f); }
+__device__ __forceinline__ uint32_t f2h2(float lo, float hi) {   // {lo, hi} packed, round to nearest even, saturating
+    const halfx2 v = {(_Float16)sat_half(lo), (_Float16)sat_half(hi)};
+    return __builtin_bit_cast(uint32_t, v);
+}
 template <> struct ElemIO<half_t> {
     static __device__ __forceinline__ float ld(const half_t* p) { return (float)p->v; }
-    static __device__ __forceinline__ void st(half_t* p, float v) { p->v = (_Float16)v; }
+    static __device__ __forceinline__ void st(half_t* p, float v) { p->v = (_Float16)sat_half(v); }
 };
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return ElemIO<T>::ld(p); }
 template <typename T> __device__ __forceinline__ void stf(T* p, float v) { ElemIO<T>::st(p, v); }
@@ -64,6 +73,28 @@ template <> struct Vec16<bf16_t> {
         return make_uint4(f2bf2(f[0], f[1]), f2bf2(f[2], f[3]), f2bf2(f[4], f[5]), f2bf2(f[6], f[7]));
     }
 };
+
+template <> struct Vec16<half_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void unpack(const uint4& q, float* f) {
+        const halfx2 a = __builtin_bit_cast(halfx2, q.x), b = __builtin_bit_cast(halfx2, q.y);
+        const halfx2 c = __builtin_bit_cast(halfx2, q.z), d = __builtin_bit_cast(halfx2, q.w);
+        f[0] = (float)a.x; f[1] = (float)a.y; f[2] = (float)b.x; f[3] = (float)b.y;
+        f[4] = (float)c.x; f[5] = (float)c.y; f[6] = (float)d.x; f[7] = (float)d.y;
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(f2h2(f[0], f[1]), f2h2(f[2], f[3]), f2h2(f[4], f[5]), f2h2(f[6], f[7]));
+    }
+};
+
+// 16-bit MFMA, 32x32x16, fp32 accumulate: bf16 or IEEE half operands (8 elements of K per lane, identical layouts)
+template <typename T> __device__ __forceinline__ f32x16 mma16(const uint4& a, const uint4& b, const f32x16& c);
+template <> __device__ __forceinline__ f32x16 mma16<bf16_t>(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mma16<half_t>(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
+}
 
 // Split-bf16 ("bf16x3") storage: value = hi + lo with hi = bf16(v), lo = bf16(v - hi) - 16 significand bits in two bf16
 // planes.  A product of two split numbers is taken as hi*hi + lo*hi + hi*lo on the bf16 MFMA (the lo*lo term is below

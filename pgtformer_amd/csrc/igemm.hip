@@ -36,6 +36,9 @@ template <> struct Mma<bf16_t> {
                                                        __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
 };
+template <> struct Mma<half_t> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) { acc = mma16<half_t>(a, b, acc); }
+};
 template <> struct Mma<float> {
     // lane half h holds 4 consecutive k of an 8-wide k group; MFMA j pairs (j, 4+j): the k order is
     // the same for A and B so the contraction is unchanged.
@@ -425,8 +428,9 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
                              const void* residual, const void* sft_dec, const void* sft_shift, void* y,
                              void* workspace, size_t workspace_bytes, pgt_stream_t stream) {
     PGT_CHECK(d && x && w && y, "pgt_conv2d: null argument");
-    PGT_CHECK(d->dtype == PGT_F32 || d->dtype == PGT_BF16 || d->dtype == PGT_BF16X3, "pgt_conv2d: bad dtype %d", d->dtype);
+    PGT_CHECK(d->dtype == PGT_F32 || d->dtype == PGT_BF16 || d->dtype == PGT_BF16X3 || d->dtype == PGT_F16, "pgt_conv2d: bad dtype %d", d->dtype);
     const bool x3 = d->dtype == PGT_BF16X3;
+    const bool f16 = d->dtype == PGT_F16;
     const int es = d->dtype == PGT_F32 ? 4 : 2;
     const int ch = 16 / es;
     PGT_CHECK(d->Cin > 0 && d->Cin % ch == 0, "pgt_conv2d: Cin=%d must be a multiple of %d", d->Cin, ch);
@@ -468,6 +472,9 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         p.gn_part = g_gn_ws + 8 + ((long)d->gn_sub * nimg + d->gn_img0) * p.gn_maxblk * p.gn_G * 2;
     }
     p.x3 = x3 ? (d->x3_fold ? 2 : 1) : 0;
+    p.f16 = f16 ? 1 : 0;
+    p.dlo = d->dec_lo ? d->dec_lo : d->Cout;
+    p.slo = d->shift_lo ? d->shift_lo : d->Cout;
     p.nw = (x3 && d->x3_fold) ? 128 : d->Cout;
     PGT_CHECK(!d->x3_fold || (x3 && d->Cout == 64 && d->gn_groups == 0), "pgt_conv2d: x3_fold is the 64-output-channel form of dtype PGT_BF16X3 (no statistics epilogue)");
     p.res_f32 = (x3 && d->res_f32) ? 1 : 0;
@@ -489,8 +496,11 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     hipStream_t st = (hipStream_t)stream;
 
     if (x3) {   // split-bf16 operands: the phase-interleaved LDS-DMA kernel with the three-segment K order
-        PGT_CHECK(d->Cin % 64 == 0 && d->ups == 0 && d->epi == 0 && d->KH * d->KW <= 30,
-                  "pgt_conv2d: bf16x3 needs Cin %% 64 == 0 (Cin=%d), no up-sampling, the plain epilogue", d->Cin);
+        PGT_CHECK(d->Cin % 64 == 0 && d->ups == 0 && d->KH * d->KW <= 30,
+                  "pgt_conv2d: bf16x3 needs Cin %% 64 == 0 (Cin=%d) and no fused up-sampling", d->Cin);
+        PGT_CHECK(d->epi == 0 || (!d->out_f32 && !d->x3_fold && d->ld_dec >= p.dlo + d->Cout && d->ld_shift >= p.slo + d->Cout &&
+                                  p.dlo % 8 == 0 && p.slo % 8 == 0),
+                  "pgt_conv2d: bf16x3 SFT epilogue takes split dec / shift planes (dec_lo=%d ld_dec=%d shift_lo=%d ld_shift=%d)", p.dlo, d->ld_dec, p.slo, d->ld_shift);
         PGT_CHECK(d->ldx >= p.xlo + d->Cin && p.xlo % 8 == 0 && p.xlo >= d->Cin, "pgt_conv2d: bf16x3 x_lo=%d / ldx=%d do not hold [hi | lo] planes of %d channels", p.xlo, d->ldx, d->Cin);
         PGT_CHECK(d->out_f32 || (d->ldy >= p.ylo + d->Cout && p.ylo % 8 == 0 && p.ylo >= d->Cout), "pgt_conv2d: bf16x3 y_lo=%d / ldy=%d do not hold [hi | lo] planes of %d channels", p.ylo, d->ldy, d->Cout);
         PGT_CHECK(!residual || p.res_f32 || (d->ldr >= p.rlo + d->Cout && p.rlo % 8 == 0), "pgt_conv2d: bf16x3 residual planes");
@@ -515,12 +525,14 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         const int bk = d->dtype == PGT_F32 ? 32 : 64;
         const int nk = (p.K + bk - 1) / bk;
         ps.kt_per_split = (nk + slices - 1) / slices;
-        int rc = d->dtype == PGT_F32 ? launch<float, 64, 64>(ps, st) : launch<bf16_t, 64, 64>(ps, st);
+        int rc = d->dtype == PGT_F32 ? launch<float, 64, 64>(ps, st) : f16 ? launch<half_t, 64, 64>(ps, st) : launch<bf16_t, 64, 64>(ps, st);
         if (rc) return rc;
         const long nchunk = (long)p.M * (p.Cout / 8);
         const dim3 grid((unsigned)((nchunk + 255) / 256));
         if (d->dtype == PGT_F32)
             hipLaunchKernelGGL((splitk_epilogue_kernel<float>), grid, dim3(256), 0, st, p, (const float*)workspace, slices);
+        else if (f16)
+            hipLaunchKernelGGL((splitk_epilogue_kernel<half_t>), grid, dim3(256), 0, st, p, (const float*)workspace, slices);
         else
             hipLaunchKernelGGL((splitk_epilogue_kernel<bf16_t>), grid, dim3(256), 0, st, p, (const float*)workspace, slices);
         PGT_LAUNCH_CHECK();
@@ -530,6 +542,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     if (d->dtype == PGT_F32) return dispatch<float>(p, st, d->force_bm, d->force_bn);
     // v2 (LDS-DMA, 128-row tiles) is opt-in (kernel = 2); kernel: 0 auto, 1 v1, 2 v2
     const bool v2_legal = d->Cin % 64 == 0 && p.vec_epi && ((uintptr_t)x & 15) == 0 && d->ldx % 8 == 0;
+    PGT_CHECK(!f16 || (d->kernel != 2 && d->kernel != 3), "pgt_conv2d: kernels 2 and 3 are bf16-only tuning candidates");
     PGT_CHECK(d->kernel != 2 || v2_legal, "pgt_conv2d: kernel=2 needs bf16, Cin %% 64 == 0 and a 16-byte-legal epilogue");
     // v3 (large tiles, 8-16 waves): additionally stride 1, no up-sampling, <= 32 taps, 32-bit byte offsets
     const bool v3_legal = v2_legal && !placed && d->stride == 1 && d->ups == 0 && d->KH * d->KW <= 32 &&
@@ -566,12 +579,13 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         PGT_CHECK(rc != 1, "pgt_conv2d: kernel=3 tile %dx%d with %d stages is not built", d->force_bm, d->force_bn, d->stages);
         return rc;
     }
-    if (v2_legal && !placed && d->kernel != 1 && !p.gn_part) {
+    if (v2_legal && !placed && d->kernel != 1 && !p.gn_part && !f16) {
         const int bn = (d->force_bn == 64 || (d->force_bn == 0 && d->Cout <= 64)) ? 64 : 128;
         const long blocks = (long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
         if (d->kernel == 2 || (d->kernel == 0 && d->force_bm == 0 && d->force_bn == 0 && blocks >= kV2MinBlocks && p.K >= kV2MinK))
             return pgt_igemm2_launch(&p, bn, d->force_bm >= 2 && d->force_bm <= 4 ? d->force_bm : 3, st);
     }
+    if (f16) return dispatch<half_t>(p, st, d->force_bm, d->force_bn);
     return dispatch<bf16_t>(p, st, d->force_bm, d->force_bn);
 }
 

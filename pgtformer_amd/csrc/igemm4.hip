@@ -60,7 +60,7 @@ constexpr int lds_bytes4(int wr, int wc) {
     return stages > epi ? stages : epi;
 }
 
-template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false>
+template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T = bf16_t>
 __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     static_assert(WR * WC == 8, "8 waves");
     constexpr int BM = WR * 128, BN = WC * 64;
@@ -296,10 +296,9 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
         if (!(PGT_PROBE & 4)) __builtin_amdgcn_s_setprio(1);                                                           \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                               \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
-                acc[((Q) >> 1) * 2 + i][((Q) == 1 || (Q) == 2) ? 1 : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(     \
-                    __builtin_bit_cast(bf16x8, fa[i][ks]),                                                             \
-                    __builtin_bit_cast(bf16x8, ((Q) == 1 || (Q) == 2) ? fb1[ks] : fb0[ks]),                            \
-                    acc[((Q) >> 1) * 2 + i][((Q) == 1 || (Q) == 2) ? 1 : 0], 0, 0, 0);                                 \
+                acc[((Q) >> 1) * 2 + i][((Q) == 1 || (Q) == 2) ? 1 : 0] = mma16<T>(                                    \
+                    fa[i][ks], ((Q) == 1 || (Q) == 2) ? fb1[ks] : fb0[ks],                                             \
+                    acc[((Q) >> 1) * 2 + i][((Q) == 1 || (Q) == 2) ? 1 : 0]);                                          \
         if (!(PGT_PROBE & 4)) __builtin_amdgcn_s_setprio(0);                                                           \
         PGT_BARRIER();                                                                                                 \
     }
@@ -327,11 +326,11 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     return;
 #endif
 
-    epilogue_128x64<WR, WC, X3, GN>(p, acc, smem, m0, n0, tid, lane, wr, wc);
+    epilogue_128x64<WR, WC, X3, GN, T>(p, acc, smem, m0, n0, tid, lane, wr, wc);
     PGT_STAMP(3);
 }
 
-template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false> int launch4(const ConvP& p0, hipStream_t st) {
+template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T = bf16_t> int launch4(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     constexpr int BM = WR * 128, BN = WC * 64, bytes = lds_bytes4(WR, WC);
     const bool pow2 = (p.Wo & (p.Wo - 1)) == 0 && (p.Ho & (p.Ho - 1)) == 0;
@@ -345,12 +344,12 @@ template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false> int launch
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS, X3, GN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS, X3, GN, T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { pgt_set_error("igemm4: cannot reserve %d B of LDS: %s", bytes, hipGetErrorString(e)); return -12; }
         attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS, X3, GN>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
+    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS, X3, GN, T>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -370,6 +369,17 @@ int pgt_igemm4_launch(const void* pv, int bn, hipStream_t st) {
         }
         if (bn == 256) return launch4<2, 4, false, true>(p, st);
         if (bn == 128) return launch4<4, 2, false, true>(p, st);
+        return 1;
+    }
+    if (p.f16) {   // IEEE half operands (PGT_F16): the same schedule on v_mfma_f32_32x32x16_f16
+        if (p.gn_part) {
+            if (p.ups) return 1;
+            if (bn == 256) return launch4<2, 4, false, false, true, half_t>(p, st);
+            if (bn == 128) return launch4<4, 2, false, false, true, half_t>(p, st);
+            return 1;
+        }
+        if (bn == 256) return p.ups ? launch4<2, 4, true, false, false, half_t>(p, st) : launch4<2, 4, false, false, false, half_t>(p, st);
+        if (bn == 128) return p.ups ? launch4<4, 2, true, false, false, half_t>(p, st) : launch4<4, 2, false, false, false, half_t>(p, st);
         return 1;
     }
     if (p.gn_part) {   // epilogue statistics: plain (not up-sampled) inputs

@@ -76,6 +76,7 @@ constexpr int newest5(int p) {
 // byte offset of (row e, 16-byte chunk c) in the extended A image
 __device__ __forceinline__ int swzx(int e, int c) { return e * 128 + ((c ^ ((e >> 1) & 7)) << 4); }
 
+template <typename T>   // 16-bit operand type: bf16_t or half_t (PGT_F16)
 __global__ __launch_bounds__(512) void igemm5_kernel(ConvP p) {
     constexpr unsigned kOob = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // kLds5 bytes
@@ -266,10 +267,9 @@ __global__ __launch_bounds__(512) void igemm5_kernel(ConvP p) {
         __builtin_amdgcn_s_setprio(1);                                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                               \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
-                acc[(Q_ >> 1) * 2 + i][(Q_ == 1 || Q_ == 2) ? 1 : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(        \
-                    __builtin_bit_cast(bf16x8, fa[i][ks]),                                                             \
-                    __builtin_bit_cast(bf16x8, (Q_ == 1 || Q_ == 2) ? fb1[ks] : fb0[ks]),                              \
-                    acc[(Q_ >> 1) * 2 + i][(Q_ == 1 || Q_ == 2) ? 1 : 0], 0, 0, 0);                                    \
+                acc[(Q_ >> 1) * 2 + i][(Q_ == 1 || Q_ == 2) ? 1 : 0] = mma16<T>(                                       \
+                    fa[i][ks], (Q_ == 1 || Q_ == 2) ? fb1[ks] : fb0[ks],                                               \
+                    acc[(Q_ >> 1) * 2 + i][(Q_ == 1 || Q_ == 2) ? 1 : 0]);                                             \
         __builtin_amdgcn_s_setprio(0);                                                                                 \
         PGT_BARRIER();                                                                                                 \
     }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void igemm5_kernel(ConvP p) {
     PGT_VMWAIT(0);
     __syncthreads();
     PGT_STAMP(2);
-    epilogue_128x64<2, 4>(p, acc, smem, m0, n0, tid, lane, wr, wc);
+    epilogue_128x64<2, 4, false, false, T>(p, acc, smem, m0, n0, tid, lane, wr, wc);
     PGT_STAMP(3);
 }
 
@@ -312,12 +312,15 @@ int pgt_igemm5_launch(const void* pv, hipStream_t st) {
     p.nbn = (p.Cout + 255) / 256;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm5_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm5_kernel<bf16_t>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds5);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm5_kernel<half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds5);
         if (e != hipSuccess) { pgt_set_error("igemm5: cannot reserve %d B of LDS: %s", kLds5, hipGetErrorString(e)); return -12; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(igemm5_kernel, dim3(p.nbm * p.nbn), dim3(512), kLds5, st, p);
+    if (p.f16) hipLaunchKernelGGL(igemm5_kernel<half_t>, dim3(p.nbm * p.nbn), dim3(512), kLds5, st, p);
+    else hipLaunchKernelGGL(igemm5_kernel<bf16_t>, dim3(p.nbm * p.nbn), dim3(512), kLds5, st, p);
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -26,6 +26,7 @@ static_assert(128 * kSRow * 4 <= kLds6, "epilogue stage must fit");
 
 __device__ __forceinline__ int swz6(int e, int c) { return e * 128 + ((c ^ ((e >> 1) & 7)) << 4); }
 
+template <typename T>   // 16-bit operand type: bf16_t or half_t (PGT_F16)
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles) {
     constexpr unsigned kOob = 0x80000000u;
     __shared__ __attribute__((aligned(1024))) char smem[kLds6];
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
     const v4i rsrc_x = make_rsrc(p.x, (unsigned)((long)p.N * p.H * p.W * p.ldx * 2));
 
     // ---- weights of this wave's 32 output channels: B fragment of (tap, ks) = w[n][tap*64 + ks*16 + hh*8 .. +8]
-    bf16x8 wreg[9][4];
+    uint4 wreg[9][4];
     {
         const int n = wc * 32 + (lane & 31);
         const uint4* wp = reinterpret_cast<const uint4*>(p.w + ((long)n * p.K + hh * 8) * 2);
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
             for (int ks = 0; ks < 4; ++ks) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (n < p.Cout) v = wp[t * 8 + ks * 2];   // (t*64 + ks*16) elements = (t*8 + ks*2) x 16 bytes
-                wreg[t][ks] = __builtin_bit_cast(bf16x8, v);
+                wreg[t][ks] = v;
             }
     }
     const float bv = (p.bias && wc * 32 + (lane & 31) < p.Cout) ? p.bias[wc * 32 + (lane & 31)] : 0.f;
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
         const int r = wr * 64 + i * 32 + (lane & 31);
         e0[i] = (r >> s_shift) * S2 + (r & (S - 1));
     }
-    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
-    const bf16_t* dec = reinterpret_cast<const bf16_t*>(p.dec);
-    const bf16_t* shf = reinterpret_cast<const bf16_t*>(p.shift);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    const T* dec = reinterpret_cast<const T*>(p.dec);
+    const T* shf = reinterpret_cast<const T*>(p.shift);
     float* stage = reinterpret_cast<float*>(smem);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -121,8 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const uint4 fa = *reinterpret_cast<const uint4*>(smem + (ab[i] ^ (ks << 5)));
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
-                                                                         wreg[ky * 3 + kx][ks], acc[i], 0, 0, 0);
+                        acc[i] = mma16<T>(fa, wreg[ky * 3 + kx][ks], acc[i]);
                     }
             }
         __syncthreads();   // every wave is done with the images
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
                     if (p.post_relu) v = v > 0.f ? v : 0.f;
                 }
                 if (p.out_f32) reinterpret_cast<float*>(p.y)[(long)m * p.ldy + n] = v;
-                else stf(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + n, v);
+                else stf(reinterpret_cast<T*>(p.y) + (long)m * p.ldy + n, v);
             }
             continue;
         }
@@ -167,14 +167,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
             apply_act8(v, p.act);
             if (p.epi == 1) {
                 float d[8], s[8];
-                load8<bf16_t>(dec + (long)m * p.ld_dec + c8, d);
-                load8<bf16_t>(shf + (long)m * p.ld_shift + c8, s);
+                load8<T>(dec + (long)m * p.ld_dec + c8, d);
+                load8<T>(shf + (long)m * p.ld_shift + c8, s);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + s[e]);
             } else {
                 if (res) {
                     float r[8];
-                    load8<bf16_t>(res + (long)m * p.ldr + c8, r);
+                    load8<T>(res + (long)m * p.ldr + c8, r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r[e];
                 }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
                 }
             }
             if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + (long)m * p.ldy + c8, v);
-            else store8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + c8, v);
+            else store8<T>(reinterpret_cast<T*>(p.y) + (long)m * p.ldy + c8, v);
         }
     }
 }
@@ -208,7 +208,8 @@ int pgt_igemm6_launch(const void* pv, hipStream_t st) {
         n_cu = prop.multiProcessorCount;
     }
     const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), 0, st, p, ntiles);
+    if (p.f16) hipLaunchKernelGGL(conv3x3_c64_kernel<half_t>, dim3(grid), dim3(256), 0, st, p, ntiles);
+    else hipLaunchKernelGGL(conv3x3_c64_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, p, ntiles);
     PGT_LAUNCH_CHECK();
     return 0;
 }

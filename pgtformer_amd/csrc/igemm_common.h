@@ -9,6 +9,9 @@ template <typename T> __device__ __forceinline__ void load8(const T* p, float* f
 template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* f) {
     Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p), f);
 }
+template <> __device__ __forceinline__ void load8<half_t>(const half_t* p, float* f) {
+    Vec16<half_t>::unpack(*reinterpret_cast<const uint4*>(p), f);
+}
 template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) {
     *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p);
     *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p + 4);
@@ -16,6 +19,9 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float* 
 template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* f) {
     *reinterpret_cast<uint4*>(p) = Vec16<bf16_t>::pack(f);
+}
+template <> __device__ __forceinline__ void store8<half_t>(half_t* p, const float* f) {
+    *reinterpret_cast<uint4*>(p) = Vec16<half_t>::pack(f);
 }
 template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) {
     *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(f);
@@ -40,6 +46,8 @@ struct ConvP {
     int x3;                     // split-bf16 operands: x = [hi | lo] planes, K runs over [x_hi | x_lo | x_hi] per tap
     int xlo, ylo, rlo;          // element offset of the lo plane inside a pixel row of x / y / residual
     int res_f32;                // x3 with fp32 output: the residual is fp32 too (ldr counts floats)
+    int f16;                    // 16-bit operands are IEEE half (PGT_F16) instead of bf16
+    int dlo, slo;               // x3 with the SFT epilogue: element offsets of the lo planes of dec / shift
     int nw;                     // rows of the weight matrix = GEMM columns (Cout; 128 for the folded 64-channel x3 form, x3 == 2)
     // GroupNorm statistics of the OUTPUT from the epilogue (gn_part != nullptr): every workgroup tile writes the sum and
     // sum of squares of its outputs per channel group to gn_part[((img * gn_maxblk + k) * gn_G + g) * 2 + {0, 1}], k = the

@@ -13,9 +13,10 @@ namespace {
 template <int WR, int WC> constexpr int epi_stage_bytes() { return WR * 64 * (WC * 64 + 4) * 4; }
 
 // smem: at least epi_stage_bytes<WR, WC>() bytes, no DMA in flight, all waves past their last fragment read.
-// X3: split-bf16 output (hi at n, lo at n + p.ylo) and split residual (p.rlo); plain epilogue only.
+// X3: split-bf16 output (hi at n, lo at n + p.ylo), split residual (p.rlo) or split SFT operands (p.dlo / p.slo).
 // GN: also reduce the GroupNorm statistics of the tile's outputs (ConvP::gn_*).
-template <int WR, int WC, bool X3 = false, bool GN = false>
+// T: 16-bit storage type of residual / SFT operands / output (bf16_t, or half_t for PGT_F16 launches; X3 is bf16).
+template <int WR, int WC, bool X3 = false, bool GN = false, typename T = bf16_t>
 __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&acc)[4][2], char* smem, int m0, int n0,
                                                 int tid, int lane, int wr, int wc) {
     constexpr int BN = WC * 64;
@@ -27,9 +28,10 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
     constexpr int SROW = BN + 4, SROWS = WR * 64, CPT = SROWS * (BN / 8) / 512;
     static_assert(SROWS * (BN / 8) % 512 == 0, "chunks per thread");
     float* stage = reinterpret_cast<float*>(smem);
-    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
-    const bf16_t* dec = reinterpret_cast<const bf16_t*>(p.dec);
-    const bf16_t* shf = reinterpret_cast<const bf16_t*>(p.shift);
+    static_assert(!X3 || sizeof(T) == 2, "16-bit storage");
+    const T* res = reinterpret_cast<const T*>(p.res);
+    const T* dec = reinterpret_cast<const T*>(p.dec);
+    const T* shf = reinterpret_cast<const T*>(p.shift);
     float bv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -50,7 +52,8 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
             pre0[c] = pre1[c] = make_uint4(0, 0, 0, 0);
             if (m < p.M && n < p.Cout) {
                 if (X3) {
-                    if (res && p.res_f32) {      // 8 floats = 2 x 16 bytes
+                    if (p.epi == 1) {            // split SFT operands are fetched where they are used (4 x 16 bytes per chunk)
+                    } else if (res && p.res_f32) {      // 8 floats = 2 x 16 bytes
                         const float* rf = reinterpret_cast<const float*>(p.res) + (long)m * p.ldr + n;
                         pre0[c] = *reinterpret_cast<const uint4*>(rf);
                         pre1[c] = *reinterpret_cast<const uint4*>(rf + 4);
@@ -125,7 +128,15 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
             }
             if ((PGT_PROBE & 64) && v[0] != 12345.f) continue;
             if (X3) {
-                if (res) {
+                if (p.epi == 1) {    // out = dec + w * (dec * scale + shift) on split operands (reference: pgtformer_arch.py:478-479)
+                    const T* dp = dec + (long)m * p.ld_dec + n;
+                    const T* sp2 = shf + (long)m * p.ld_shift + n;
+                    float d[8], sh[8];
+                    merge8(*reinterpret_cast<const uint4*>(dp), *reinterpret_cast<const uint4*>(dp + p.dlo), d);
+                    merge8(*reinterpret_cast<const uint4*>(sp2), *reinterpret_cast<const uint4*>(sp2 + p.slo), sh);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + sh[e]);
+                } else if (res) {
                     float r[8];
                     if (p.res_f32) {
                         Vec16<float>::unpack(pre0[c], r);
@@ -147,21 +158,21 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
                 if (!p.out_f32) {
                     uint4 hi, lo;
                     split8(v, hi, lo);
-                    bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + out_row(p, m) * p.ldy + n;
+                    T* yp = reinterpret_cast<T*>(p.y) + out_row(p, m) * p.ldy + n;
                     *reinterpret_cast<uint4*>(yp) = hi;
                     *reinterpret_cast<uint4*>(yp + p.ylo) = lo;
                     continue;
                 }
             } else if (p.epi == 1) {
                 float d[8], sh[8];
-                Vec16<bf16_t>::unpack(pre0[c], d);
-                Vec16<bf16_t>::unpack(pre1[c], sh);
+                Vec16<T>::unpack(pre0[c], d);
+                Vec16<T>::unpack(pre1[c], sh);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + sh[e]);
             } else {
                 if (res) {
                     float r[8];
-                    Vec16<bf16_t>::unpack(pre0[c], r);
+                    Vec16<T>::unpack(pre0[c], r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r[e];
                 }
@@ -175,7 +186,7 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
                 for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gs[8 + e] += v[e] * v[e]; }
             }
             if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + out_row(p, m) * p.ldy + n, v);
-            else store8<bf16_t>(reinterpret_cast<bf16_t*>(p.y) + out_row(p, m) * p.ldy + n, v);
+            else store8<T>(reinterpret_cast<T*>(p.y) + out_row(p, m) * p.ldy + n, v);
         }
         if (pass == 0) __syncthreads();
     }

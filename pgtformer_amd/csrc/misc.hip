@@ -275,8 +275,9 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
     *reinterpret_cast<uint4*>(dst + r * ldd + c) = hi;
     *reinterpret_cast<uint4*>(dst + r * ldd + dlo + c) = lo;
 }
-// split-bf16 planes -> fp32
-__global__ __launch_bounds__(256) void x3_merge_kernel(const bf16_t* __restrict__ src, int lds, int slo, float* __restrict__ dst,
+// split-bf16 planes -> fp32 or IEEE half (hi + lo carries 16 significand bits: half keeps 11 of them, the bf16 hi plane alone 8)
+template <typename D>
+__global__ __launch_bounds__(256) void x3_merge_kernel(const bf16_t* __restrict__ src, int lds, int slo, D* __restrict__ dst,
                                                        int ldd, long rows, int cols8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols8) return;
@@ -284,8 +285,7 @@ __global__ __launch_bounds__(256) void x3_merge_kernel(const bf16_t* __restrict_
     const int c = (int)(i % cols8) * 8;
     float f[8];
     merge8(*reinterpret_cast<const uint4*>(src + r * lds + c), *reinterpret_cast<const uint4*>(src + r * lds + slo + c), f);
-    *reinterpret_cast<float4*>(dst + r * ldd + c) = *reinterpret_cast<const float4*>(f);
-    *reinterpret_cast<float4*>(dst + r * ldd + c + 4) = *reinterpret_cast<const float4*>(f + 4);
+    store8<D>(dst + r * ldd + c, f);
 }
 
 // ---- stage-I quantiser extras (reference: archs/tdcrqvae3_arch.py:330-352, :429-457) --------------------------------
@@ -372,6 +372,17 @@ inline dim3 grid1d(long n, int blk = 256) { return dim3((unsigned)((n + blk - 1)
         return 0;                                                  \
     } while (0)
 
+// the same over the three storage types, CALL written once with T_ as the element type
+#define DT_DISPATCH_T(dtype, NAME, ...)                                 \
+    do {                                                                \
+        if ((dtype) == PGT_F32) { using T_ = float; __VA_ARGS__; }       \
+        else if ((dtype) == PGT_BF16) { using T_ = bf16_t; __VA_ARGS__; } \
+        else if ((dtype) == PGT_F16) { using T_ = half_t; __VA_ARGS__; }  \
+        else PGT_CHECK(false, NAME ": bad dtype %d", (int)(dtype));      \
+        PGT_LAUNCH_CHECK();                                              \
+        return 0;                                                        \
+    } while (0)
+
 extern "C" int pgt_argmax_rows(const float* logits, int32_t ld, int32_t rows, int32_t K, int32_t* codes,
                                pgt_stream_t stream) {
     PGT_CHECK(logits && codes && K > 0, "argmax_rows: bad argument");
@@ -397,14 +408,12 @@ extern "C" int pgt_embed_rows(int32_t dtype, const float* codebook, int32_t D, c
                      (!resid || (ldres % 8 == 0 && ((uintptr_t)resid & 15) == 0));
     if (vec) {
         const dim3 g8 = grid1d((long)rows * (D / 8));
-        DT_DISPATCH(dtype, "embed_rows",
-                    hipLaunchKernelGGL((embed_rows_vec8_kernel<float>), g8, dim3(256), 0, st, codebook, D, codes, rows, (float*)out, ldo, accumulate, (float*)resid, ldres),
-                    hipLaunchKernelGGL((embed_rows_vec8_kernel<bf16_t>), g8, dim3(256), 0, st, codebook, D, codes, rows, (bf16_t*)out, ldo, accumulate, (bf16_t*)resid, ldres));
+        DT_DISPATCH_T(dtype, "embed_rows",
+                      hipLaunchKernelGGL((embed_rows_vec8_kernel<T_>), g8, dim3(256), 0, st, codebook, D, codes, rows, (T_*)out, ldo, accumulate, (T_*)resid, ldres));
     }
     const dim3 g = grid1d((long)rows * D);
-    DT_DISPATCH(dtype, "embed_rows",
-                hipLaunchKernelGGL((embed_rows_kernel<float>), g, dim3(256), 0, st, codebook, D, codes, rows, (float*)out, ldo, accumulate, (float*)resid, ldres),
-                hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), g, dim3(256), 0, st, codebook, D, codes, rows, (bf16_t*)out, ldo, accumulate, (bf16_t*)resid, ldres));
+    DT_DISPATCH_T(dtype, "embed_rows",
+                  hipLaunchKernelGGL((embed_rows_kernel<T_>), g, dim3(256), 0, st, codebook, D, codes, rows, (T_*)out, ldo, accumulate, (T_*)resid, ldres));
 }
 
 extern "C" int pgt_row_sumsq(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t C, float* out,
@@ -413,9 +422,8 @@ extern "C" int pgt_row_sumsq(int32_t dtype, const void* x, int32_t ldx, int32_t 
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((rows + 3) / 4);
     const int vec = C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0;
-    DT_DISPATCH(dtype, "row_sumsq",
-                hipLaunchKernelGGL((row_sumsq_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, rows, C, out, vec),
-                hipLaunchKernelGGL((row_sumsq_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, C, out, vec));
+    DT_DISPATCH_T(dtype, "row_sumsq",
+                  hipLaunchKernelGGL((row_sumsq_kernel<T_>), g, dim3(256), 0, st, (const T_*)x, ldx, rows, C, out, vec));
 }
 
 extern "C" int pgt_maxpool3x3s2(int32_t dtype, const void* x, int32_t N, int32_t H, int32_t W, int32_t C, void* y,
@@ -424,9 +432,8 @@ extern "C" int pgt_maxpool3x3s2(int32_t dtype, const void* x, int32_t N, int32_t
     hipStream_t st = (hipStream_t)stream;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const dim3 g = grid1d((long)N * Ho * Wo * C);
-    DT_DISPATCH(dtype, "maxpool",
-                hipLaunchKernelGGL((maxpool_kernel<float>), g, dim3(256), 0, st, (const float*)x, N, H, W, C, (float*)y),
-                hipLaunchKernelGGL((maxpool_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, N, H, W, C, (bf16_t*)y));
+    DT_DISPATCH_T(dtype, "maxpool",
+                  hipLaunchKernelGGL((maxpool_kernel<T_>), g, dim3(256), 0, st, (const T_*)x, N, H, W, C, (T_*)y));
 }
 
 extern "C" int pgt_gate_add(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
@@ -435,9 +442,8 @@ extern "C" int pgt_gate_add(int32_t dtype, const void* x, int32_t ldx, int32_t N
     PGT_CHECK(x && y, "gate_add: null argument");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g = grid1d((long)N * HW * C);
-    DT_DISPATCH(dtype, "gate_add",
-                hipLaunchKernelGGL((gate_add_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, N, HW, C, (const float*)gate, (const float*)addvec, (const float*)addt, ldt, (float*)y, ldy),
-                hipLaunchKernelGGL((gate_add_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, N, HW, C, (const bf16_t*)gate, (const bf16_t*)addvec, (const bf16_t*)addt, ldt, (bf16_t*)y, ldy));
+    DT_DISPATCH_T(dtype, "gate_add",
+                  hipLaunchKernelGGL((gate_add_kernel<T_>), g, dim3(256), 0, st, (const T_*)x, ldx, N, HW, C, (const T_*)gate, (const T_*)addvec, (const T_*)addt, ldt, (T_*)y, ldy));
 }
 
 extern "C" int pgt_resize_bilinear_ac(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t Hi, int32_t Wi,
@@ -445,9 +451,8 @@ extern "C" int pgt_resize_bilinear_ac(int32_t dtype, const void* x, int32_t ldx,
     PGT_CHECK(x && y, "resize_bilinear: null argument");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g = grid1d((long)N * Ho * Wo * C);
-    DT_DISPATCH(dtype, "resize_bilinear",
-                hipLaunchKernelGGL((resize_bilinear_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, N, Hi, Wi, C, (float*)y, ldy, Ho, Wo),
-                hipLaunchKernelGGL((resize_bilinear_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, N, Hi, Wi, C, (bf16_t*)y, ldy, Ho, Wo));
+    DT_DISPATCH_T(dtype, "resize_bilinear",
+                  hipLaunchKernelGGL((resize_bilinear_kernel<T_>), g, dim3(256), 0, st, (const T_*)x, ldx, N, Hi, Wi, C, (T_*)y, ldy, Ho, Wo));
 }
 
 extern "C" int pgt_copy2d(int32_t src_dtype, const void* src, int32_t lds, int32_t dst_dtype, void* dst, int32_t ldd,
@@ -464,6 +469,14 @@ extern "C" int pgt_copy2d(int32_t src_dtype, const void* src, int32_t lds, int32
         hipLaunchKernelGGL((copy2d_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, lds, (float*)dst, ldd, (long)rows, cols);
     else if (src_dtype == PGT_BF16 && dst_dtype == PGT_BF16)
         hipLaunchKernelGGL((copy2d_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, (long)rows, cols);
+    else if (src_dtype == PGT_F32 && dst_dtype == PGT_F16)
+        hipLaunchKernelGGL((copy2d_kernel<float, half_t>), g, b, 0, st, (const float*)src, lds, (half_t*)dst, ldd, (long)rows, cols);
+    else if (src_dtype == PGT_F16 && dst_dtype == PGT_F32)
+        hipLaunchKernelGGL((copy2d_kernel<half_t, float>), g, b, 0, st, (const half_t*)src, lds, (float*)dst, ldd, (long)rows, cols);
+    else if (src_dtype == PGT_F16 && dst_dtype == PGT_F16)
+        hipLaunchKernelGGL((copy2d_kernel<half_t, half_t>), g, b, 0, st, (const half_t*)src, lds, (half_t*)dst, ldd, (long)rows, cols);
+    else if (src_dtype == PGT_BF16 && dst_dtype == PGT_F16)
+        hipLaunchKernelGGL((copy2d_kernel<bf16_t, half_t>), g, b, 0, st, (const bf16_t*)src, lds, (half_t*)dst, ldd, (long)rows, cols);
     else
         PGT_CHECK(false, "copy2d: bad dtypes %d -> %d", src_dtype, dst_dtype);
     PGT_LAUNCH_CHECK();
@@ -476,9 +489,8 @@ extern "C" int pgt_prep_input(int32_t dtype, const void* src, int32_t src_kind, 
     PGT_CHECK(src_kind == 0 || src_kind == 1, "prep_input: src_kind must be 0 (u8 NHWC) or 1 (f32 NCHW)");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g = grid1d((long)N * H * W);
-    DT_DISPATCH(dtype, "prep_input",
-                hipLaunchKernelGGL((prep_input_kernel<float>), g, dim3(256), 0, st, src, src_kind, N, H, W, (float*)raw, (float*)norm),
-                hipLaunchKernelGGL((prep_input_kernel<bf16_t>), g, dim3(256), 0, st, src, src_kind, N, H, W, (bf16_t*)raw, (bf16_t*)norm));
+    DT_DISPATCH_T(dtype, "prep_input",
+                  hipLaunchKernelGGL((prep_input_kernel<T_>), g, dim3(256), 0, st, src, src_kind, N, H, W, (T_*)raw, (T_*)norm));
 }
 
 extern "C" int pgt_nhwc_to_nchw_f32(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t H, int32_t W,
@@ -486,9 +498,8 @@ extern "C" int pgt_nhwc_to_nchw_f32(int32_t dtype, const void* x, int32_t ldx, i
     PGT_CHECK(x && y, "nhwc_to_nchw: null argument");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g = grid1d((long)N * C * H * W);
-    DT_DISPATCH(dtype, "nhwc_to_nchw",
-                hipLaunchKernelGGL((nhwc_to_nchw_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, N, H, W, C, y),
-                hipLaunchKernelGGL((nhwc_to_nchw_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, N, H, W, C, y));
+    DT_DISPATCH_T(dtype, "nhwc_to_nchw",
+                  hipLaunchKernelGGL((nhwc_to_nchw_kernel<T_>), g, dim3(256), 0, st, (const T_*)x, ldx, N, H, W, C, y));
 }
 
 extern "C" int pgt_frame_to_u8(int32_t dtype, const void* x, int32_t ldx, int32_t H, int32_t W, uint8_t* y,
@@ -497,9 +508,8 @@ extern "C" int pgt_frame_to_u8(int32_t dtype, const void* x, int32_t ldx, int32_
     hipStream_t st = (hipStream_t)stream;
     const long npix = (long)H * W;
     const dim3 g = grid1d(npix * 3);
-    DT_DISPATCH(dtype, "frame_to_u8",
-                hipLaunchKernelGGL((frame_to_u8_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, npix, y),
-                hipLaunchKernelGGL((frame_to_u8_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, npix, y));
+    DT_DISPATCH_T(dtype, "frame_to_u8",
+                  hipLaunchKernelGGL((frame_to_u8_kernel<T_>), g, dim3(256), 0, st, (const T_*)x, ldx, npix, y));
 }
 
 extern "C" int pgt_gather_frames(const void* src, int64_t src_row_stride, void* dst, int64_t dst_row_stride,
@@ -533,8 +543,18 @@ extern "C" int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float*
                             int32_t cols, pgt_stream_t stream) {
     PGT_CHECK(src && dst && cols % 8 == 0 && lds % 8 == 0 && ldd % 4 == 0 && src_lo % 8 == 0 && lds >= src_lo + cols &&
               ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "x3_merge: bad argument / alignment");
-    hipLaunchKernelGGL(x3_merge_kernel, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(x3_merge_kernel<float>, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, lds, src_lo, dst, ldd, (long)rows, cols / 8);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_x3_to_half(const void* src, int32_t lds, int32_t src_lo, void* dst, int32_t ldd, int64_t rows,
+                              int32_t cols, pgt_stream_t stream) {
+    PGT_CHECK(src && dst && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && src_lo % 8 == 0 && lds >= src_lo + cols &&
+              ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "x3_to_half: bad argument / alignment");
+    hipLaunchKernelGGL(x3_merge_kernel<half_t>, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, lds, src_lo, (half_t*)dst, ldd, (long)rows, cols / 8);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -566,9 +586,8 @@ extern "C" int pgt_straight_through(int32_t dtype, const void* x, int32_t ldx, c
     PGT_CHECK(x && q && y, "straight_through: null argument");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g = grid1d((long)rows * cols);
-    DT_DISPATCH(dtype, "straight_through",
-                hipLaunchKernelGGL((straight_through_kernel<float>), g, dim3(256), 0, st, (const float*)x, ldx, (const float*)q, ldq, (float*)y, ldy, (long)rows, cols),
-                hipLaunchKernelGGL((straight_through_kernel<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)q, ldq, (bf16_t*)y, ldy, (long)rows, cols));
+    DT_DISPATCH_T(dtype, "straight_through",
+                  hipLaunchKernelGGL((straight_through_kernel<T_>), g, dim3(256), 0, st, (const T_*)x, ldx, (const T_*)q, ldq, (T_*)y, ldy, (long)rows, cols));
 }
 
 extern "C" int pgt_rq_soft_codes(const float* dot, int32_t ld, const float* xnorm, const float* enorm, int32_t rows,

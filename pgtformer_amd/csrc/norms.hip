@@ -317,6 +317,26 @@ template <int EPL> struct RowIO<bf16_t, EPL, true> {   // EPL in {4, 8, 16}
         }
     }
 };
+template <int EPL> struct RowIO<half_t, EPL, true> {   // EPL in {4, 8, 16}
+    static __device__ __forceinline__ void ld(const half_t* p, float* v) {
+        if constexpr (EPL == 4) {
+            const uint2 q = *reinterpret_cast<const uint2*>(p);
+            const halfx2 a = __builtin_bit_cast(halfx2, q.x), b = __builtin_bit_cast(halfx2, q.y);
+            v[0] = (float)a.x; v[1] = (float)a.y; v[2] = (float)b.x; v[3] = (float)b.y;
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL / 8; ++i) Vec16<half_t>::unpack(reinterpret_cast<const uint4*>(p)[i], v + 8 * i);
+        }
+    }
+    static __device__ __forceinline__ void st(half_t* p, const float* v) {
+        if constexpr (EPL == 4) {
+            *reinterpret_cast<uint2*>(p) = make_uint2(f2h2(v[0], v[1]), f2h2(v[2], v[3]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL / 8; ++i) reinterpret_cast<uint4*>(p)[i] = Vec16<half_t>::pack(v + 8 * i);
+        }
+    }
+};
 template <int EPL> struct RowIO<float, EPL, true> {    // EPL in {4, 8, 16}
     static __device__ __forceinline__ void ld(const float* p, float* v) {
 #pragma unroll
@@ -504,6 +524,7 @@ extern "C" int pgt_groupnorm_affine(int32_t dtype, const void* x, int32_t ldx, i
     PGT_CHECK(((uintptr_t)x & 15) == 0, "groupnorm: x must be 16-byte aligned");
     if (dtype == PGT_F32) return gn_affine_impl<float>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream);
     if (dtype == PGT_BF16) return gn_affine_impl<bf16_t>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream);
+    if (dtype == PGT_F16) return gn_affine_impl<half_t>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream);
     PGT_CHECK(false, "groupnorm: bad dtype %d", dtype);
 }
 
@@ -541,6 +562,7 @@ extern "C" int pgt_affine_act(int32_t dtype, const void* x, int32_t ldx, void* y
     PGT_CHECK((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "affine_act: x and y must be 16-byte aligned");
     if (dtype == PGT_F32) return affine_act_impl<float>(x, ldx, y, ldy, N, HW, C, scale, shift, act, (hipStream_t)stream);
     if (dtype == PGT_BF16) return affine_act_impl<bf16_t>(x, ldx, y, ldy, N, HW, C, scale, shift, act, (hipStream_t)stream);
+    if (dtype == PGT_F16) return affine_act_impl<half_t>(x, ldx, y, ldy, N, HW, C, scale, shift, act, (hipStream_t)stream);
     PGT_CHECK(false, "affine_act: bad dtype %d", dtype);
 }
 
@@ -606,6 +628,7 @@ extern "C" int pgt_layernorm(int32_t dtype, const void* x, int32_t ldx, int32_t 
     PGT_CHECK(!y2 || pos, "layernorm: y2 requested without pos");
     if (dtype == PGT_F32) return layernorm_impl<float>(x, ldx, rows, C, gamma, beta, eps, y, ldy, pos, ldpos, y2, ldy2, (hipStream_t)stream);
     if (dtype == PGT_BF16) return layernorm_impl<bf16_t>(x, ldx, rows, C, gamma, beta, eps, y, ldy, pos, ldpos, y2, ldy2, (hipStream_t)stream);
+    if (dtype == PGT_F16) return layernorm_impl<half_t>(x, ldx, rows, C, gamma, beta, eps, y, ldy, pos, ldpos, y2, ldy2, (hipStream_t)stream);
     PGT_CHECK(false, "layernorm: bad dtype %d", dtype);
 }
 
@@ -618,6 +641,8 @@ extern "C" int pgt_channel_stats(int32_t dtype, const void* x, int32_t ldx, int3
         hipLaunchKernelGGL((channel_stats_kernel<float>), grid, blk, 0, st, (const float*)x, ldx, HW, C, mean, var_unbiased);
     else if (dtype == PGT_BF16)
         hipLaunchKernelGGL((channel_stats_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, C, mean, var_unbiased);
+    else if (dtype == PGT_F16)
+        hipLaunchKernelGGL((channel_stats_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, C, mean, var_unbiased);
     else
         PGT_CHECK(false, "channel_stats: bad dtype %d", dtype);
     PGT_LAUNCH_CHECK();

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import parallel
+from .config import DEFAULT_PRECISION
 
 
 class WindowRunner:
@@ -50,10 +51,12 @@ class WindowRunner:
         self.graph = None
         self._pipe = None
         self._lane_streams = None
-        # per-shape kernel selection during the first eager passes (bf16 launches only); PGT_AUTOTUNE=0 keeps the
-        # library's static heuristic, PGT_AUTOTUNE_CACHE=<file> reloads / stores the tuned table across processes
+        # Kernel selection is DETERMINISTIC by default (the library's static per-shape heuristic): two processes produce
+        # bit-identical frames, as the reference does.  PGT_AUTOTUNE=1 opts in to timing-based per-shape selection during the
+        # first eager passes (bf16 launches only: the variants change fp32 summation orders, so runs then differ at the
+        # decoder's rounding level); PGT_AUTOTUNE_CACHE=<file> reloads / stores the tuned table across processes
         cache = os.environ.get("PGT_AUTOTUNE_CACHE")
-        tune = os.environ.get("PGT_AUTOTUNE", "1") != "0" and self.dev.type == "cuda"
+        tune = os.environ.get("PGT_AUTOTUNE", "0") == "1" and self.dev.type == "cuda"
         if tune:
             from . import ops
             if not (cache and os.path.exists(cache) and ops.load_autotune(cache)):
@@ -225,9 +228,15 @@ def restore_clip_host(runner, padded_host, out_host, rank=0, world=1, group=None
     """Streaming form for host-resident clips.  padded_host: pinned uint8 (n_local+2,H,W,3) whose rows 1..n_local hold this
     rank's own frames (rows 0 and -1 are filled here with the halo frames: one all_gather of boundary frames on the
     device, replicate padding at the clip ends); out_host: pinned uint8 (n_local,H,W,3).  H2D / forward / D2H are
-    pipelined per batch (WindowRunner._run_clip_pipelined)."""
+    pipelined per batch (WindowRunner._run_clip_pipelined).  Returns out_host with its last D2H copies possibly still in
+    flight on the runner's copy stream: synchronise (torch.cuda.synchronize(), or an event on that stream) before reading."""
     n_local = padded_host.shape[0] - 2
     dev = runner.dev
+    if n_local <= 0:
+        # a rank without frames (clip shorter than the world) still joins the collective - with an EMPTY tensor, so that its
+        # neighbours skip it (parallel.exchange_halo) instead of taking uninitialised pinned memory as their halos
+        parallel.exchange_halo(torch.empty((0,) + tuple(padded_host.shape[1:]), dtype=torch.uint8, device=dev), rank, world, group)
+        return out_host
     edge = torch.stack([padded_host[1], padded_host[n_local]]).to(dev, non_blocking=True)    # first / last own frame
     prev_halo, next_halo = parallel.exchange_halo(edge, rank, world, group)
     padded_host[0].copy_(prev_halo, non_blocking=True)
@@ -316,16 +325,25 @@ def iter_frames(path, width, height, chunk=32):
         raise ValueError(f"{path} is {pw}x{ph}; the model takes {width}x{height} frames (resize the clip first)")
     cmd = [ff, "-i", path, "-f", "image2pipe", "-pix_fmt", "rgb24", "-vcodec", "rawvideo", "-"]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, bufsize=fbytes * 4)
+    done, tail = False, b""
     try:
         while True:
-            buf = proc.stdout.read(fbytes * chunk)
+            buf = tail + proc.stdout.read(fbytes * chunk)
             if len(buf) < fbytes:
+                tail = buf
                 break
             k = len(buf) // fbytes
+            tail = buf[k * fbytes:]
             yield np.frombuffer(buf[:k * fbytes], np.uint8).reshape(k, height, width, 3)
+        done = True
     finally:
         proc.stdout.close()
-        proc.wait()
+        rc = proc.wait()
+    # a decoder that failed or a stream cut inside a frame must not pass for a short clip
+    if done and rc != 0:
+        raise RuntimeError(f"ffmpeg exited with status {rc} while decoding {path}")
+    if done and tail:
+        raise RuntimeError(f"{path}: the decoded stream ends {len(tail)} bytes into a {width}x{height} rgb24 frame")
 
 
 def read_frames(path, width, height):
@@ -368,7 +386,7 @@ def write_frames(path, frames, fps=30):
     wr.close()
 
 
-def load_architecture(precision="bf16x3", weights=None, device="cuda", seed=0, synthetic=False):
+def load_architecture(precision=DEFAULT_PRECISION, weights=None, device="cuda", seed=0, synthetic=False):
     """Counterpart of inference.py:109-121.  `weights`: a directory with config.json + model.safetensors (the layout of
     `PGTFormer.from_pretrained`), a hub id, or a .safetensors / .pth (`params_ema` | `params` | flat state dict)
     checkpoint of the reference model.  Deterministic synthetic weights only on explicit request (`synthetic=True`)."""
@@ -384,8 +402,8 @@ def load_architecture(precision="bf16x3", weights=None, device="cuda", seed=0, s
         model = PGTFormer(**cfg)
         model.load_state_dict(generate_state_dict(pgtformer_manifest(cfg), cfg, seed=seed), strict=True)
         return model.prepare(device, precision)
-    if os.path.isdir(weights) or not os.path.splitext(weights)[1]:
-        return PGTFormer.from_pretrained(weights, device=device, precision=precision)
+    if os.path.isdir(weights) or not weights.endswith((".safetensors", ".pth", ".pt", ".ckpt")):
+        return PGTFormer.from_pretrained(weights, device=device, precision=precision)     # a directory or a hub id ("org/name-v1.5")
     cfg = default_config()
     model = PGTFormer(**cfg)
     if weights.endswith(".safetensors"):
@@ -407,7 +425,7 @@ def main(argv=None):
     ap.add_argument("-o", "--output_video", default="exp/output_demo.mp4")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--fps", type=float, default=None, help="output frame rate (default: probed from the input, else 30)")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "mixed", "fp32"])
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["x3f16", "bf16x3", "bf16", "mixed", "fp32"])
     ap.add_argument("--weights", default=None, help="checkpoint: directory (config.json + model.safetensors), hub id, "
                                                     ".safetensors or .pth")
     ap.add_argument("--synthetic", action="store_true", help="random-init weights (smoke tests only)")

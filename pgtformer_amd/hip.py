@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                                    "ld_dec", "ld_shift")] + [("sft_w", f32)] + \
                [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue", "kernel", "splitk", "stages",
                                    "orow_mul", "orow_xmul", "orow_off", "x_lo", "y_lo", "r_lo", "gn_groups", "gn_sub",
-                                   "gn_nsub", "gn_img0", "gn_nimg", "res_f32", "x3_fold")]
+                                   "gn_nsub", "gn_img0", "gn_nimg", "res_f32", "x3_fold", "dec_lo", "shift_lo")]
 
 
 # name -> argtypes (restype is int32 unless listed in _RESTYPES); must cover every symbol of pgt_hip.h
@@ -52,6 +52,7 @@ SIGNATURES = {
     "pgt_mha_x3": [vp, i32, i32, vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp],
     "pgt_x3_split": [vp, i32, vp, i32, i32, i64, i32, vp],
     "pgt_x3_merge": [vp, i32, i32, vp, i32, i64, i32, vp],
+    "pgt_x3_to_half": [vp, i32, i32, vp, i32, i64, i32, vp],
     "pgt_argmax_rows": [vp, i32, i32, i32, vp, vp],
     "pgt_rq_argmin": [vp, i32, vp, vp, i32, i32, vp, vp],
     "pgt_rq_nearest": [i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp],

@@ -3,7 +3,8 @@ tensors (torch is used for memory, streams and views only — all arithmetic hap
 
 Tensors are channels-last: images (N,H,W,C), token matrices (rows,C); the last dim must be contiguous
 and the pixel/row stride may exceed C (channel slices of a wider buffer are valid inputs/outputs).
-dtype torch.float32 selects the exact-f32 kernels, torch.bfloat16 the bf16-MFMA kernels.
+dtype torch.float32 selects the exact-f32 kernels, torch.bfloat16 / torch.float16 the 16-bit MFMA kernels (bf16: 8
+significand bits; IEEE half: 11 - the decoder-side type of the default precision mode).
 """
 import ctypes as C
 
@@ -94,7 +95,20 @@ def to_x3(x, out=None):
     if out is None:
         out = torch.empty(tuple(x.shape[:-1]) + (2 * c,), device=x.device, dtype=torch.bfloat16)
     assert out.is_contiguous() and out.shape[-1] == 2 * c
-    hip.check(hip.lib().pgt_x3_split(_p(x), lds, _p(out), 2 * c, c, rows, c, _stream()), "pgt_x3_split")
+    with _Prof("x3_convert", 0, _nb(x, out)):
+        hip.check(hip.lib().pgt_x3_split(_p(x), lds, _p(out), 2 * c, c, rows, c, _stream()), "pgt_x3_split")
+    return out
+
+
+def x3_to_half(x, out=None):
+    """split-bf16 (..., 2C) -> IEEE half (..., C) (hi + lo rounded once: 11 significand bits; the hi plane alone has 8)."""
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 2 == 0
+    c = x.shape[-1] // 2
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (c,), device=x.device, dtype=torch.float16)
+    assert out.dtype == torch.float16 and out.is_contiguous() and out.shape[-1] == c
+    with _Prof("x3_convert", 0, _nb(x, out)):
+        hip.check(hip.lib().pgt_x3_to_half(_p(x), 2 * c, c, _p(out), c, x.numel() // (2 * c), c, _stream()), "pgt_x3_to_half")
     return out
 
 
@@ -103,13 +117,44 @@ def from_x3(x):
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 2 == 0
     c = x.shape[-1] // 2
     out = torch.empty(tuple(x.shape[:-1]) + (c,), device=x.device, dtype=torch.float32)
-    hip.check(hip.lib().pgt_x3_merge(_p(x), 2 * c, c, _p(out), c, x.numel() // (2 * c), c, _stream()), "pgt_x3_merge")
+    with _Prof("x3_convert", 0, _nb(x, out)):
+        hip.check(hip.lib().pgt_x3_merge(_p(x), 2 * c, c, _p(out), c, x.numel() // (2 * c), c, _stream()), "pgt_x3_merge")
     return out
 
 
-# When set to a list, conv2d brackets each launch with events on the launch stream and appends
-# {"kernel", "flops", "bytes", "shape", "events"} records (bench.py's live roofline measurement).
+# When set to a list, every op brackets its launch with events on the launch stream and appends
+# {"kernel", "flops", "bytes", "events", ...} records (bench.py's live per-kernel roofline measurement): `flops` counts every
+# reference product once (2 per multiply-add), `bytes` the algorithmic HBM traffic (operands once, results once).
 PROFILE = None
+
+
+class _Prof:
+    """with _Prof("layernorm", flops, bytes): <launch>   - no-op unless PROFILE is a list"""
+    __slots__ = ("rec", "e0")
+
+    def __init__(self, kernel, flops, nbytes, **extra):
+        self.rec = None
+        if PROFILE is not None:
+            self.rec = dict(kernel=kernel, flops=float(flops), bytes=float(nbytes), **extra)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None and exc[0] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.rec["events"] = (self.e0, e1)
+            PROFILE.append(self.rec)
+        return False
+
+
+def _nb(*ts):
+    """bytes of the logical contents of tensors / views (None skipped)"""
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 def _dt(t):
@@ -117,6 +162,8 @@ def _dt(t):
         return PGT_F32
     if t.dtype == torch.bfloat16:
         return PGT_BF16
+    if t.dtype == torch.float16:
+        return hip.PGT_F16
     raise TypeError(f"unsupported activation dtype {t.dtype}")
 
 
@@ -269,7 +316,14 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         per = max(1, ((1 << 31) - 1) // (h * wd * _ld_img(x) * x.element_size()))
         st = None
         if gn is not None and not isinstance(gn, tuple) and USE_EPILOGUE_GN and gn_ok(n, ho0 * wo0, cout, gn, cin, kh):
-            st = GnStats(n, 1, ho0 * wo0, cout, gn, x.device)
+            # the statistics workspace records ONE tile height for the whole tensor (gn_finalize_conv_kernel), and the
+            # kernel / tile choice depends on the launch's frame count: every chunk must therefore be the same launch
+            # shape.  Equal chunks (the largest divisor of n that fits); if n has no useful divisor the GroupNorm that
+            # follows takes its separate statistics pass instead.
+            eq = max(d for d in range(1, per + 1) if n % d == 0)
+            if 2 * eq > per or eq == n:
+                per = eq
+                st = GnStats(n, 1, ho0 * wo0, cout, gn, x.device)
         for i in range(0, n, per):
             sl = slice(i, min(n, i + per))
             conv2d(x[sl], w, bias, kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, act=act,
@@ -362,7 +416,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                      "bytes": float(n * h * wd * x.shape[-1] * es + m * out.shape[-1] * out.element_size() + w.numel() * es
                                     + (m * res.shape[-1] * es if res is not None else 0)),
                      "shape": (n, h, wd, cin, cout, kh, stride, int(ups)), "events": (e0, e1),
-                     "cfg": (d.kernel, d.force_bm, d.force_bn), "x3": bool(x3)})
+                     "cfg": (d.kernel, d.force_bm, d.force_bn), "x3": bool(x3), "dt": str(x.dtype).replace("torch.", "")})
     return out
 
 
@@ -406,15 +460,17 @@ def groupnorm_affine(x, gamma, beta, groups=32, eps=1e-6, x3=False):
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
         scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
         shift = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        hip.check(L.pgt_groupnorm_affine_x3(_p(x), _ld_img(x), c, n, h * w, c, groups, eps, _p(gamma), _p(beta),
-                                            _p(scale), _p(shift), _p(ws), nbytes, _stream()), "pgt_groupnorm_affine_x3")
+        with _Prof("groupnorm_stats", 0, _nb(x)):
+            hip.check(L.pgt_groupnorm_affine_x3(_p(x), _ld_img(x), c, n, h * w, c, groups, eps, _p(gamma), _p(beta),
+                                                _p(scale), _p(shift), _p(ws), nbytes, _stream()), "pgt_groupnorm_affine_x3")
         return scale, shift
     nbytes = L.pgt_groupnorm_workspace_bytes(n, h * w, c, groups)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     scale = torch.empty((n, c), dtype=torch.float32, device=x.device)
     shift = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    hip.check(L.pgt_groupnorm_affine(_dt(x), _p(x), _ld_img(x), n, h * w, c, groups, eps, _p(gamma), _p(beta),
-                                     _p(scale), _p(shift), _p(ws), nbytes, _stream()), "pgt_groupnorm_affine")
+    with _Prof("groupnorm_stats", 0, _nb(x)):
+        hip.check(L.pgt_groupnorm_affine(_dt(x), _p(x), _ld_img(x), n, h * w, c, groups, eps, _p(gamma), _p(beta),
+                                         _p(scale), _p(shift), _p(ws), nbytes, _stream()), "pgt_groupnorm_affine")
     return scale, shift
 
 
@@ -423,12 +479,13 @@ def affine_act(x, scale, shift, act=ACT_NONE, out=None, x3=False):
     n, h, w, c = x.shape
     if out is None:
         out = torch.empty((n, h, w, c), device=x.device, dtype=x.dtype)
-    if x3:
-        hip.check(hip.lib().pgt_affine_act_x3(_p(x), _ld_img(x), c // 2, _p(out), _ld_img(out), c // 2, n, h * w, c // 2,
-                                              _p(scale), _p(shift), act, _stream()), "pgt_affine_act_x3")
-        return out
-    hip.check(hip.lib().pgt_affine_act(_dt(x), _p(x), _ld_img(x), _p(out), _ld_img(out), n, h * w, c, _p(scale),
-                                       _p(shift), act, _stream()), "pgt_affine_act")
+    with _Prof("norm_apply_act", 0, _nb(x, out)):
+        if x3:
+            hip.check(hip.lib().pgt_affine_act_x3(_p(x), _ld_img(x), c // 2, _p(out), _ld_img(out), c // 2, n, h * w, c // 2,
+                                                  _p(scale), _p(shift), act, _stream()), "pgt_affine_act_x3")
+        else:
+            hip.check(hip.lib().pgt_affine_act(_dt(x), _p(x), _ld_img(x), _p(out), _ld_img(out), n, h * w, c, _p(scale),
+                                               _p(shift), act, _stream()), "pgt_affine_act")
     return out
 
 
@@ -444,15 +501,17 @@ def layernorm(x, gamma, beta, eps=1e-5, pos=None, x3=False):
         c //= 2
         y = torch.empty((rows, 2 * c), device=x.device, dtype=x.dtype)
         y2 = torch.empty((rows, 2 * c), device=x.device, dtype=x.dtype) if pos is not None else None
-        hip.check(hip.lib().pgt_layernorm_x3(_p(x), _ld_rows(x), c, rows, c, _p(gamma), _p(beta), eps, _p(y), 2 * c, c,
-                                             _p(pos), _ld_rows(pos) if pos is not None else 0, c, _p(y2), 2 * c, c,
-                                             _stream()), "pgt_layernorm_x3")
+        with _Prof("layernorm", 0, _nb(x, y, pos, y2)):
+            hip.check(hip.lib().pgt_layernorm_x3(_p(x), _ld_rows(x), c, rows, c, _p(gamma), _p(beta), eps, _p(y), 2 * c, c,
+                                                 _p(pos), _ld_rows(pos) if pos is not None else 0, c, _p(y2), 2 * c, c,
+                                                 _stream()), "pgt_layernorm_x3")
         return y if pos is None else (y, y2)
     y = torch.empty((rows, c), device=x.device, dtype=x.dtype)
     y2 = torch.empty((rows, c), device=x.device, dtype=x.dtype) if pos is not None else None
-    hip.check(hip.lib().pgt_layernorm(_dt(x), _p(x), _ld_rows(x), rows, c, _p(gamma), _p(beta), eps, _p(y), c,
-                                      _p(pos), _ld_rows(pos) if pos is not None else 0, _p(y2), c, _stream()),
-              "pgt_layernorm")
+    with _Prof("layernorm", 0, _nb(x, y, pos, y2)):
+        hip.check(hip.lib().pgt_layernorm(_dt(x), _p(x), _ld_rows(x), rows, c, _p(gamma), _p(beta), eps, _p(y), c,
+                                          _p(pos), _ld_rows(pos) if pos is not None else 0, _p(y2), c, _stream()),
+                  "pgt_layernorm")
     return y if pos is None else (y, y2)
 
 
@@ -480,15 +539,17 @@ def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
     if x3:
         assert tuple(qkv.shape) == (rows, 6 * C_) and qkv.dtype == torch.bfloat16
         out = torch.empty((rows, 2 * C_), device=qkv.device, dtype=qkv.dtype)
-        hip.check(hip.lib().pgt_window_attention_x3(_p(qkv), _ld_rows(qkv), 3 * C_, _p(out), 2 * C_, C_, _p(bias), B, T, H,
-                                                    W, C_, heads, win[0], win[1], shift[0], shift[1], _stream()),
-                  "pgt_window_attention_x3")
+        with _Prof("window_attention", 4.0 * rows * (T * win[0] * win[1]) * C_, _nb(qkv, out), x3=True):
+            hip.check(hip.lib().pgt_window_attention_x3(_p(qkv), _ld_rows(qkv), 3 * C_, _p(out), 2 * C_, C_, _p(bias), B, T, H,
+                                                        W, C_, heads, win[0], win[1], shift[0], shift[1], _stream()),
+                      "pgt_window_attention_x3")
         return out
     assert tuple(qkv.shape) == (rows, 3 * C_)
     out = torch.empty((rows, C_), device=qkv.device, dtype=qkv.dtype)
-    hip.check(hip.lib().pgt_window_attention(_dt(qkv), _p(qkv), _ld_rows(qkv), _p(out), C_, _p(bias), B, T, H, W,
-                                             C_, heads, win[0], win[1], shift[0], shift[1], _stream()),
-              "pgt_window_attention")
+    with _Prof("window_attention", 4.0 * rows * (T * win[0] * win[1]) * C_, _nb(qkv, out)):
+        hip.check(hip.lib().pgt_window_attention(_dt(qkv), _p(qkv), _ld_rows(qkv), _p(out), C_, _p(bias), B, T, H, W,
+                                                 C_, heads, win[0], win[1], shift[0], shift[1], _stream()),
+                  "pgt_window_attention")
     return out
 
 
@@ -500,7 +561,7 @@ def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift, pad_row=Non
     rows = B * D * H * W
     assert tuple(qkv.shape) == (rows, 3 * C_) and qkv.dtype in (torch.bfloat16, torch.float16, torch.float32)
     out = torch.empty((rows, C_), device=qkv.device, dtype=qkv.dtype)
-    dt = hip.PGT_F16 if qkv.dtype == torch.float16 else _dt(qkv)
+    dt = _dt(qkv)
     if pad_row is not None:
         pad_row = pad_row.to(device=qkv.device, dtype=qkv.dtype).contiguous()
         assert pad_row.numel() == 3 * C_
@@ -516,12 +577,14 @@ def mha(q, k, v, B, L, heads, hd, scale, x3=None):
     if x3 is not None:
         e = heads * hd
         out = torch.empty((B * L, 2 * e), device=q.device, dtype=q.dtype)
-        hip.check(hip.lib().pgt_mha_x3(_p(q), _ld_rows(q), x3[0], _p(k), _ld_rows(k), x3[1], _p(v), _ld_rows(v), x3[2],
-                                       _p(out), 2 * e, e, B, L, heads, hd, scale, _stream()), "pgt_mha_x3")
+        with _Prof("mha", 4.0 * B * L * L * e, 2 * 3 * B * L * e * q.element_size() + _nb(out), x3=True):
+            hip.check(hip.lib().pgt_mha_x3(_p(q), _ld_rows(q), x3[0], _p(k), _ld_rows(k), x3[1], _p(v), _ld_rows(v), x3[2],
+                                           _p(out), 2 * e, e, B, L, heads, hd, scale, _stream()), "pgt_mha_x3")
         return out
     out = torch.empty((B * L, heads * hd), device=q.device, dtype=q.dtype)
-    hip.check(hip.lib().pgt_mha(_dt(q), _p(q), _ld_rows(q), _p(k), _ld_rows(k), _p(v), _ld_rows(v), _p(out),
-                                heads * hd, B, L, heads, hd, scale, _stream()), "pgt_mha")
+    with _Prof("mha", 4.0 * B * L * L * heads * hd, 3 * B * L * heads * hd * q.element_size() + _nb(out)):
+        hip.check(hip.lib().pgt_mha(_dt(q), _p(q), _ld_rows(q), _p(k), _ld_rows(k), _p(v), _ld_rows(v), _p(out),
+                                    heads * hd, B, L, heads, hd, scale, _stream()), "pgt_mha")
     return out
 
 
@@ -658,7 +721,8 @@ def copy_into(src, dst):
     lds = _ld_img(src) if src.dim() == 4 else _ld_rows(src)
     ldd = _ld_img(dst) if dst.dim() == 4 else _ld_rows(dst)
     assert dst.shape == src.shape
-    hip.check(hip.lib().pgt_copy2d(_dt(src), _p(src), lds, _dt(dst), _p(dst), ldd, rows, c, _stream()), "pgt_copy2d")
+    with _Prof("copy_gather", 0, _nb(src, dst)):
+        hip.check(hip.lib().pgt_copy2d(_dt(src), _p(src), lds, _dt(dst), _p(dst), ldd, rows, c, _stream()), "pgt_copy2d")
     return dst
 
 
@@ -688,8 +752,9 @@ def gather_frames(src, idx, out=None):
         assert src.dim() == 4
         rows, row_bytes = src.shape[1] * src.shape[2], src.shape[3] * es
         lds, ldd = _ld_img(src) * es, _ld_img(out) * es
-    hip.check(hip.lib().pgt_gather_frames(_p(src), lds, _p(out), ldd, _p(idx), n, rows, row_bytes, _stream()),
-              "pgt_gather_frames")
+    with _Prof("copy_gather", 0, 2 * _nb(out)):
+        hip.check(hip.lib().pgt_gather_frames(_p(src), lds, _p(out), ldd, _p(idx), n, rows, row_bytes, _stream()),
+                  "pgt_gather_frames")
     return out
 
 
@@ -700,7 +765,8 @@ def zero_(t):
     rows = t.numel() // c
     ld = (_ld_img(t) if t.dim() == 4 else _ld_rows(t)) if rows > 1 else c
     es = t.element_size()
-    hip.check(hip.lib().pgt_zero2d(_p(t), ld * es, rows, c * es, _stream()), "pgt_zero2d")
+    with _Prof("copy_gather", 0, _nb(t)):
+        hip.check(hip.lib().pgt_zero2d(_p(t), ld * es, rows, c * es, _stream()), "pgt_zero2d")
     return t
 
 

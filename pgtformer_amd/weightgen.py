@@ -11,12 +11,33 @@ conv/linear weights ~ N(0, 1/fan_in), biases ~ N(0, 0.05^2), norm gains 1+0.1N, 
 BatchNorm running stats (mean 0.1N, var U(0.5,1.5)), relative-position-bias table 0.2N,
 codebook rows 0.3N with the padding row zero (nn.Embedding padding_idx; reference:
 archs/tdcrqvae3_arch.py:83-97).
+
+The last convs of the SFT `scale` / `shift` branches (`fuse_convs_dict.S.{scale,shift}.2`) carry the gains of SFT_GAINS:
+fused = dec + w (dec * scale + shift) is MULTIPLICATIVE in the decoder trunk (archs/pgtformer_arch.py:478-479), and with
+unit-gain random branches the trunk squares its magnitude at each of the four fusions (rms 3 -> 4.5e5 at 256x256, measured
+on the reference): no trained checkpoint behaves like that (the reference's constructor even carries a commented-out
+`last_zero_init` for exactly these convs, :450-451), it turns every decoder error figure into chaos-amplified noise and
+overflows IEEE half.  The gains were calibrated once on the reference (tests/golden/make_golden_r3.py re-measures them):
+rms(scale) = 0.25 and rms(shift) = rms(dec) at every fusion, so the trunk stays O(10).
 """
 import hashlib
 
 import numpy as np
 
 from .manifest import I64
+
+
+# (scale.2 gain, shift.2 gain) per fusion size; see the module docstring
+SFT_GAINS = {"32": (0.113, 1.48), "64": (0.086, 1.56), "128": (0.0541, 2.07), "256": (0.0408, 1.74)}
+
+
+def _sft_gain(name):
+    parts = name.split(".")
+    if len(parts) == 5 and parts[0] == "fuse_convs_dict" and parts[2] in ("scale", "shift") and parts[3] == "2":
+        g = SFT_GAINS.get(parts[1])
+        if g is not None:
+            return np.float32(g[0] if parts[2] == "scale" else g[1])
+    return None
 
 
 def _rng(name, seed):
@@ -59,6 +80,13 @@ def generate_tensor(name, shape, dtype, cfg, seed=0):
             frames = n // (win[0] * win[1])
             return relative_position_index(frames, win)
         return np.zeros(shape, np.int64)  # num_batches_tracked
+    gain = _sft_gain(name)
+    if gain is not None:
+        return (_generate_plain(name, shape, cfg, seed) * gain).astype(np.float32)
+    return _generate_plain(name, shape, cfg, seed)
+
+
+def _generate_plain(name, shape, cfg, seed):
     g = _rng(name, seed)
     leaf = name.split(".")[-1]
     if leaf == "running_mean":

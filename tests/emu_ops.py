@@ -64,6 +64,10 @@ def from_x3(x):
     return _merge(x).contiguous()
 
 
+def x3_to_half(x, out=None):
+    return _store(_merge(x), out, torch.float16)
+
+
 def gather_frames(src, idx, out=None):
     r = src[idx.long()]
     if out is None:
@@ -414,7 +418,7 @@ def frame_to_u8(x, out=None):
 ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "layernorm", "channel_stats",
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
-       "frame_to_u8", "to_x3", "from_x3", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
+       "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
        "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update"]
 
 

@@ -1,0 +1,232 @@
+"""Round-3 fixtures from the REFERENCE (imported from /root/reference in the build container):
+    python tests/golden/make_golden_r3.py  ->  tests/golden/r3_tail.npz, tests/golden/r3_golden.npz   (about 25 min)
+
+A NON-DEGENERATE OPERATING POINT for the restored frames.  With the purely random weights of pgtformer_amd.weightgen the
+reference's output is noise against the ground truth (PSNR 6.3 dB, range [-8, 13], most pixels saturate under clamp(0,1);
+the decoder trunk grows to rms 4e5 through the four multiplicative SFT fusions), so |PSNR(build, GT) - PSNR(reference, GT)|
+cannot see decoder arithmetic error.  Two things make the operating point sane:
+  (1) pgtformer_amd.weightgen draws the last convs of the SFT `scale` / `shift` branches with the gains SFT_GAINS
+      (calibrated so that rms(scale) = 0.25 and rms(shift) = rms(dec) at every fusion; this script re-measures them):
+      the decoder trunk stays O(10) instead of 4e5;
+  (2) the "fitted tail" weight scheme keeps every seed-0 weight upstream (codes, logits, lq_feat goldens are the ones of
+      full_golden.npz) and replaces the weights of the decoder's last stage - the 256x256 fusion block, the 256->512 up-sampling conv, the two 512x512
+      res blocks, `norm_out`, `conv_out` (archs/pgtformer_arch.py:684-712) - TRAINED here for a few hundred Adam steps
+      (torch CPU autograd over the oracle's functional restatement of those layers, random crops, MSE against the
+      ground-truth frames of the synthetic window), starting from the random weights and a ridge least-squares `conv_out`.
+With it the reference's restored frames sit inside [0, 1] at PSNR(reference, GT) >= 25 dB - the regime `north_star`'s
+"within 1e-3 dB PSNR" contract is about (a decoder error must stay ~36 dB below the reference's own error to GT to hold it).
+
+r3_tail.npz   : the trained tensors stored as halves; `tests/golden/r3_scheme.py` turns them into generic fp32 values
+                (v * (1 + 2^-11 u), u keyed by the tensor name) and applies them: THAT state dict is what the reference ran
+r3_golden.npz : the REFERENCE's outputs with that scheme on the golden window and on a second window of the clip (held out
+                from the fit): fp16 frames sub-sampled x2, fp32 middle crop and every 8th row of the middle frame, codes, the
+                exact sums of squares needed to evaluate PSNR(build, GT) - PSNR(reference, GT) from a build output.
+The script also checks the oracle against the reference with the fitted tail (bit-identical).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(HERE, "_refshim"))
+sys.path.insert(0, HERE)
+REF = "/root/reference"
+RIDGE = 1e-3          # relative ridge (x mean diagonal of the normal matrix): keeps the read-out weights O(1)
+
+
+def fit_tail(feat, gt, ridge=RIDGE):
+    """feat (N,64,H,W) fp32 = input of decoder.conv_out; gt (N,3,H,W).  Ridge least squares for a 3x3 conv + bias,
+    normal equations accumulated in float64 per image row block."""
+    n, c, h, w = feat.shape
+    k = c * 9 + 1
+    ata = torch.zeros((k, k), dtype=torch.float64)
+    atb = torch.zeros((k, 3), dtype=torch.float64)
+    for i in range(n):
+        for y0 in range(0, h, 64):
+            y1 = min(h, y0 + 64)
+            # rows y0-1 .. y1 with zero padding (conv padding=1)
+            lo, hi = max(0, y0 - 1), min(h, y1 + 1)
+            blk = feat[i:i + 1, :, lo:hi]
+            blk = F.pad(blk, (1, 1, 1 if y0 == 0 else 0, 1 if y1 == h else 0))
+            cols = F.unfold(blk, 3)[0].double()                       # (c*9, (y1-y0)*w), (c, ky, kx)-major rows
+            a = torch.cat([cols, torch.ones((1, cols.shape[1]), dtype=torch.float64)], 0)
+            b = gt[i, :, y0:y1].reshape(3, -1).double()
+            ata += a @ a.T
+            atb += a @ b.T
+    lam = ridge * ata.diagonal()[:-1].mean()
+    reg = torch.eye(k, dtype=torch.float64) * lam
+    reg[-1, -1] = 0.0
+    sol = torch.linalg.solve(ata + reg, atb)                          # (k, 3)
+    wgt = sol[:-1].T.reshape(3, c, 3, 3).float().contiguous()
+    bias = sol[-1].float().contiguous()
+    return wgt, bias
+
+
+def psnr(a, b):
+    return float(-10.0 * torch.log10(((a.double() - b.double()) ** 2).mean()))
+
+
+SCALE_RMS, SHIFT_REL = 0.25, 1.0
+TAIL_PREFIXES = ("fuse_convs_dict.256.", "decoder.up.1.upsample.", "decoder.up.0.", "decoder.norm_out.", "decoder.conv_out.")
+STEPS, CROP, LR = int(os.environ.get("R3_STEPS", "700")), 64, 1e-3
+
+
+def rms(t):
+    return float(t.double().pow(2).mean().sqrt())
+
+
+def measure_and_capture(O, sd, cfg, x):
+    """One oracle forward that (1) re-measures what weightgen.SFT_GAINS was calibrated for - rms(scale) = 0.25, rms(shift) =
+    rms(dec) at the four fusions - and (2) captures the inputs of the 256x256 fusion block.  Returns (enc256, dec256)."""
+    held = {}
+    orig_fuse, orig_conv = O.fuse_sft, O._conv
+
+    def fuse(sd_, p, enc, dec, w, tcc=32):
+        raw = {}
+
+        def conv(sd2, q, xx, stride=1, padding=0):
+            y = orig_conv(sd2, q, xx, stride, padding)
+            if q in (p + ".scale.2", p + ".shift.2"):
+                raw[q] = y
+            return y
+        O._conv = conv
+        out = orig_fuse(sd_, p, enc, dec, w, tcc)
+        O._conv = orig_conv
+        a, b = rms(raw[p + ".scale.2"]) / SCALE_RMS, rms(raw[p + ".shift.2"]) / (SHIFT_REL * rms(dec))
+        print(f"  {p}: rms dec {rms(dec):.2f} scale {rms(raw[p + '.scale.2']):.3f} shift {rms(raw[p + '.shift.2']):.2f} "
+              f"(ratio to the calibration targets {a:.3f} {b:.3f})")
+        assert 0.97 < a < 1.03 and 0.97 < b < 1.03, "weightgen.SFT_GAINS no longer match their calibration targets"
+        if p.endswith(".256"):
+            held["enc"], held["dec"] = enc.clone(), dec.clone()
+        return out
+
+    O.fuse_sft = fuse
+    try:
+        O.pgtformer_forward(sd, cfg, x, w=1.0)
+    finally:
+        O.fuse_sft, O._conv = orig_fuse, orig_conv
+    return held["enc"], held["dec"]
+
+
+def tail_forward(O, sd, enc, dec, upto_features=False):
+    """the decoder's last stage on (1,T,128,h,w) inputs of the 256x256 fusion block (reference: pgtformer_arch.py:700-712)"""
+    h = O.fuse_sft(sd, "fuse_convs_dict.256", enc, dec, 1.0)
+    h = O.upsample(sd, "decoder.up.1.upsample", h)
+    h = O.td_resblock(sd, "decoder.up.0.block.0", h)
+    h = O.td_resblock(sd, "decoder.up.0.block.1", h)
+    b, d, c, hh, ww = h.shape
+    y = F.silu(O._gn(sd, "decoder.norm_out", h.reshape(b * d, c, hh, ww)))
+    return y if upto_features else O._conv(sd, "decoder.conv_out", y, padding=1)
+
+
+def train_tail(O, sd, enc, dec, gt, steps=STEPS):
+    """Adam on the tail tensors; gt (T,3,512,512).  Deterministic: fixed seeds, fixed crop sequence."""
+    names = [k for k in sd if k.startswith(TAIL_PREFIXES) and sd[k].dtype == torch.float32]
+    params = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(params)
+    opt = torch.optim.Adam(list(params.values()), lr=LR)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=LR, total_steps=steps, pct_start=0.1)
+    g = torch.Generator().manual_seed(0)
+    hw = enc.shape[-1]
+    t0 = time.time()
+    for it in range(steps):
+        cs = CROP if it < steps - 60 else 128                       # the last steps see larger crops (GroupNorm statistics)
+        y0, x0 = (int(v) for v in torch.randint(0, hw - cs + 1, (2,), generator=g))
+        out = tail_forward(O, work, enc[..., y0:y0 + cs, x0:x0 + cs], dec[..., y0:y0 + cs, x0:x0 + cs])
+        loss = F.mse_loss(out, gt[:, :, 2 * y0:2 * (y0 + cs), 2 * x0:2 * (x0 + cs)])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        opt.step()
+        sched.step()
+        if it % 25 == 0 or it == steps - 1:
+            print(f"  step {it}: crop PSNR {-10 * np.log10(loss.item()):.2f} dB  ({time.time() - t0:.0f} s)", flush=True)
+    return {k: v.detach().half() for k, v in params.items()}      # the fixture stores halves (r3_scheme de-quantises them)
+
+
+def main():
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    from archs.pgtformer_arch import PGTFormer                       # reference
+
+    from oracle import pgt_oracle as O
+    from pgtformer_amd.config import default_config
+    from pgtformer_amd.manifest import pgtformer_manifest
+    from pgtformer_amd.synth import make_clip, window_from_clip
+    from pgtformer_amd.weightgen import generate_state_dict
+
+    torch.manual_seed(0)
+    torch.use_deterministic_algorithms(True)
+    cfg = default_config()
+    model = PGTFormer(**cfg)
+    model.eval()
+    sd0 = generate_state_dict(pgtformer_manifest(cfg), cfg, seed=0)
+    lq_u8, gt = make_clip(4, 512, seed=1234)
+
+    def window(i):
+        win = window_from_clip(lq_u8, i)
+        n = lq_u8.shape[0]
+        idx = [max(i - 1, 0), i, min(i + 1, n - 1)]
+        x = torch.from_numpy(win.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+        return x, torch.from_numpy(gt[idx]).permute(0, 3, 1, 2).contiguous()
+
+    x1, gt1 = window(1)                                               # the golden window of full_golden.npz
+    x2, gt2 = window(2)                                               # held out
+    print("PSNR(LQ input, GT) = %.2f dB" % psnr(x1, gt1))
+    # (1) SFT gains of weightgen re-measured
+    sd = dict(sd0)
+    print("SFT branch magnitudes with weightgen.SFT_GAINS (one oracle forward):")
+    enc, dec = measure_and_capture(O, sd, cfg, x1)
+    # (2) the trained tail, starting from the least-squares read-out of the random tail's features
+    with torch.no_grad():
+        feat = tail_forward(O, sd, enc, dec, upto_features=True)
+    sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"] = fit_tail(feat, gt1)
+    with torch.no_grad():
+        print("least-squares read-out of the random tail: PSNR(ref, GT) = %.2f dB" % psnr(tail_forward(O, sd, enc, dec), gt1))
+    print(f"training the tail ({STEPS} Adam steps on {CROP}x{CROP} crops of the 256x256 maps):")
+    trained = train_tail(O, sd, enc, dec, gt1)
+    np.savez_compressed(os.path.join(HERE, "r3_tail.npz"), **{k: v.numpy() for k, v in trained.items()})
+    print("tail tensors:", len(trained), "with", sum(v.numel() for v in trained.values()), "values")
+    # the scheme as the tests apply it: halves de-quantised to generic fp32 values (r3_scheme._dither), so that no 16-bit
+    # decoder finds the trained weights exactly representable in its storage type
+    from r3_scheme import fitted_tail_state_dict
+    sd = fitted_tail_state_dict(sd0)
+    n_exact = sum(int((sd[k].half().float() == sd[k]).sum()) for k in trained)
+    print("trained values exactly representable in half after de-quantisation:", n_exact)
+
+    model.load_state_dict(sd, strict=True)
+    full = {}
+    for tag, x, g in (("w1", x1, gt1), ("w2", x2, gt2)):
+        with torch.no_grad():
+            out, logits, lq = model(x.clone(), w=1.0)
+            out_b = model(x.clone(), w=1.0)[0]
+        o_out, o_logits, _ = O.pgtformer_forward(sd, cfg, x, w=1.0)
+        sat = float(((out < 0) | (out > 1)).float().mean())
+        print(f"{tag}: out range [{out.min().item():.3f}, {out.max().item():.3f}], saturated fraction {sat:.2e}, "
+              f"PSNR(ref, GT) unclamped {psnr(out, g):.3f} dB, clamped {psnr(out.clamp(0, 1), g):.3f} dB; "
+              f"repeat diff {(out - out_b).abs().max().item():.1e}; ref-vs-oracle max|d| {(out - o_out).abs().max().item():.3e}")
+        sub = out.numpy().astype(np.float16)[:, :, ::2, ::2]
+        full[f"{tag}.out_f16_sub2"] = sub if tag == "w1" else sub[1:2]         # held-out window: the middle frame only
+        full[f"{tag}.out_mid_crop"] = out[1, :, 192:320, 192:320].numpy()
+        full[f"{tag}.out_mid_rows"] = out[1, :, ::8, :].numpy()                # every 8th row of the middle frame, fp32
+        full[f"{tag}.codes"] = logits.argmax(-1).numpy().astype(np.int16)
+        full[f"{tag}.psnr_ref_vs_gt_db"] = np.array([psnr(out, g), psnr(out.clamp(0, 1), g)])
+        full[f"{tag}.out_stats"] = np.array([[o.mean().item(), o.std().item(), o.min().item(), o.max().item()] for o in out])
+        # what a build output needs to evaluate PSNR(build, GT) - PSNR(ref, GT) exactly: sum (ref - gt)^2 per frame (fp64)
+        full[f"{tag}.sse_ref_vs_gt"] = np.array([float(((out[i].double() - g[i].double()) ** 2).sum()) for i in range(3)])
+        full[f"{tag}.sse_ref_clamped_vs_gt"] = np.array([float(((out[i].clamp(0, 1).double() - g[i].double()) ** 2).sum())
+                                                         for i in range(3)])
+    np.savez_compressed(os.path.join(HERE, "r3_golden.npz"), **full)
+    for fn in ("r3_tail.npz", "r3_golden.npz"):
+        print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -5,10 +5,12 @@ Metrics are also written to gpurun_out/parity_model.json.
 
 Tolerances:  f32 path: max|d| <= 1e-3*max|ref| per module, whole-model PSNR(build, reference) >= 80 dB on
 the clamped middle frame and 100 % code agreement except tokens whose reference top-2 logit margin is
-< 1e-3.  bf16x3 (the default / benchmarked mode: split-bf16 code branch, bf16 decoder): the SAME code criterion
-(every code equal to the reference's except where the reference's own top-2 margin is < 1e-3), logits within 2e-3,
-PSNR(build, reference) >= 35 dB on the clamped sub-sampled output and >= 34.5 dB on the 128x128 middle crop.
-mixed: as bf16x3.  Pure bf16 (opt-in speed mode): reported, plus a teacher-forced decoder check (reference codes fed
+< 1e-3.  x3f16 (the default / benchmarked mode: split-bf16 code branch, IEEE-half decoder): the SAME code criterion
+(every code equal to the reference's except where the reference's own top-2 margin is < 1e-3), logits within 2e-3, and
+north_star's PSNR contract at the fitted-tail operating point (tests/golden/make_golden_r3.py: reference frames inside
+[0, 1], PSNR(reference, GT) = 28.7 dB): |PSNR(build, GT) - PSNR(reference, GT)| <= 1e-3 dB with UNCLAMPED
+PSNR(build, reference) >= 70 dB.  bf16x3 / mixed (bf16 decoder): same code criterion, PSNR(build, reference) >= 35 dB;
+their PSNR-contract figure is reported (5e-3 dB: the reason they are not the default).  Pure bf16 (opt-in speed mode): reported, plus a teacher-forced decoder check (reference codes fed
 in: PSNR >= 30 dB) and bit-equality of the in-place concat path with the copying path.
 """
 import json
@@ -54,7 +56,7 @@ def models(cfg, full_sd):
     from pgtformer_amd import PGTFormer
 
     out = {}
-    for prec in ("fp32", "bf16", "mixed", "bf16x3"):
+    for prec in ("fp32", "bf16", "mixed", "bf16x3", "x3f16"):
         m = PGTFormer(**cfg)
         m.load_state_dict(full_sd, strict=True)
         out[prec] = m.prepare(DEV, prec)
@@ -173,11 +175,13 @@ def _reduced_record(out, logits, lq, codes, g, gt):
             "lq_feat_err": float(np.abs(lq[:, 12:20, 12:20, :].numpy() - g["lq_feat_crop"]).max())}
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "mixed"])
+@pytest.mark.parametrize("prec", ["x3f16", "bf16x3", "mixed"])
 def test_whole_model_default_mode_matches_reference(models, golden_window, prec):
-    """The benchmarked mode reproduces the reference: every arg-max code (archs/pgtformer_arch.py:663) equals the fp32
-    reference's except where the reference's own top-2 logit margin is < 1e-3, logits / lq_feat to fp32-class error, and
-    the restored frames to >= 35 dB (bf16 decoder arithmetic on identical codes)."""
+    """The modes with a split-bf16 (or fp32) code branch reproduce the reference: every arg-max code
+    (archs/pgtformer_arch.py:663) equals the fp32 reference's except where the reference's own top-2 logit margin is < 1e-3,
+    logits / lq_feat to fp32-class error, and the restored frames to >= 55 dB with the IEEE-half decoder (x3f16, the
+    default), >= 35 dB with the bf16 decoder.  (Random-tail weights: the frames are noise against the GT - the PSNR contract
+    is asserted at the fitted-tail operating point, test_psnr_contract_at_the_operating_point.)"""
     g = np.load(os.path.join(GOLD, "full_golden.npz"))
     x, _, gt = golden_window
     out, logits, lq, codes = _full(models, prec, x)
@@ -188,15 +192,83 @@ def test_whole_model_default_mode_matches_reference(models, golden_window, prec)
     assert rec["max_mismatch_margin"] < 1e-3, rec
     assert rec["code_agreement"] >= 0.997, rec
     assert rec["logits_err"] < 2e-3 and rec["lq_feat_err"] < 1e-3, rec
-    assert rec["psnr_full_sub4_clamped_db"] >= 35.0 and rec["psnr_mid_crop_clamped_db"] >= 34.5, rec
-    # PSNR against the ground truth: the north_star's "within 1e-3 dB" contract.  With random-init weights both PSNRs are
-    # 6.34 dB (noise against the GT), so the difference only measures how the bf16 decoder noise (35.5 dB below the
-    # reference output) happens to correlate with the GT: measured 2e-4 .. 1.2e-3 dB from run to run (the kernel variants the
-    # autotuner picks change fp32 summation orders).  Reported in the log; asserted with that spread in mind.
-    rec["psnr_vs_gt_abs_diff_db"] = abs(rec["psnr_build_vs_gt_db"] - rec["psnr_ref_vs_gt_db"])
-    assert rec["psnr_vs_gt_abs_diff_db"] <= 3e-3, rec
+    floor = 55.0 if prec == "x3f16" else 35.0
+    assert rec["psnr_full_sub4_clamped_db"] >= floor and rec["psnr_mid_crop_clamped_db"] >= floor - 0.5, rec
+    rec["psnr_vs_gt_abs_diff_db"] = abs(rec["psnr_build_vs_gt_db"] - rec["psnr_ref_vs_gt_db"])   # reported only: noise vs GT here
     out2, _, _, codes2 = _full(models, prec, x)                      # run-to-run determinism
     assert torch.equal(out, out2) and np.array_equal(codes, codes2)
+
+
+@pytest.fixture(scope="module")
+def tail_models(cfg, full_sd):
+    """the fitted-tail weight scheme (tests/golden/r3_scheme.py) in the default mode, the bf16-decoder mode and fp32"""
+    from pgtformer_amd import PGTFormer
+    from tests.golden.r3_scheme import fitted_tail_state_dict
+
+    sd = fitted_tail_state_dict(full_sd)
+    out = {}
+    for prec in ("x3f16", "bf16x3", "fp32"):
+        m = PGTFormer(**cfg)
+        m.load_state_dict(sd, strict=True)
+        out[prec] = m.prepare(DEV, prec)
+    return out
+
+
+def _op_point_record(out, codes, g, tag, gt_frames):
+    """out (3,3,512,512) fp32 (unclamped) against the reference fixtures of window `tag` at the fitted-tail operating point"""
+    ref_rows = torch.from_numpy(g[f"{tag}.out_mid_rows"]).double()              # every 8th row of the middle frame, fp32
+    rows = out[1][:, ::8, :].double()
+    gt_rows = torch.from_numpy(gt_frames[1]).permute(2, 0, 1)[:, ::8, :].double()
+    p_ref, p_build = psnr(ref_rows, gt_rows), psnr(rows, gt_rows)
+    sub = torch.from_numpy(g[f"{tag}.out_f16_sub2"].astype(np.float32))
+    mine = out[:, :, ::2, ::2] if sub.shape[0] == 3 else out[1:2, :, ::2, ::2]
+    d = (mine.double() - sub.double())
+    return {"psnr_ref_vs_gt_db": p_ref, "psnr_build_vs_gt_db": p_build, "dpsnr_db": p_build - p_ref,
+            "psnr_build_vs_ref_unclamped_db": psnr(rows, ref_rows),
+            "rel_rms_unclamped": float(d.pow(2).mean().sqrt() / sub.double().pow(2).mean().sqrt()),
+            "psnr_build_vs_ref_f16_sub2_db": psnr(mine, sub), "out_min": float(out.min()), "out_max": float(out.max()),
+            "saturated_fraction": float(((out < 0) | (out > 1)).float().mean()),
+            "code_agreement": float((codes == g[f"{tag}.codes"]).mean())}
+
+
+@pytest.mark.parametrize("tag", ["w1", "w2"])
+def test_psnr_contract_at_the_operating_point(tail_models, tag):
+    """north_star: "outputs match the reference within 1e-3 PSNR on identical 512x512 inputs".  Operating point: the
+    fitted-tail weight scheme (tests/golden/make_golden_r3.py) - the REFERENCE's restored frames sit inside [0, 1] (1.6 % of
+    the pixels outside) at PSNR(reference, GT) = 28.7 dB on the middle frame, the frame the driver keeps
+    (inference.py:15).  w1 = the golden window (the tail was fitted on it), w2 = the next window of the clip (held out).
+    Default mode (x3f16): |PSNR(build, GT) - PSNR(reference, GT)| <= 1e-3 dB on the exact fp32 rows of the middle frame,
+    every code equal, unclamped PSNR(build, reference) >= 70 dB.  The bf16-decoder mode is measured on the same footing
+    and reported (CPU emulation: 57.6 dB / 4.8e-3 dB - why it is not the default); fp32: round-off."""
+    from pgtformer_amd.synth import make_clip, window_from_clip
+
+    g = np.load(os.path.join(GOLD, "r3_golden.npz"))
+    i = 1 if tag == "w1" else 2
+    lq_u8, gt = make_clip(4, 512, seed=1234)
+    win = window_from_clip(lq_u8, i)
+    x = torch.from_numpy(win.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    gt_frames = gt[[i - 1, i, i + 1]]
+    for prec in ("x3f16", "bf16x3", "fp32"):
+        m = tail_models[prec]
+        out = m(x.to(DEV), w=1.0)[0].float().cpu()
+        codes = m.last_codes.cpu().numpy().astype(np.int16)
+        rec = _op_point_record(out, codes, g, tag, gt_frames)
+        _LOG[f"operating_point/{tag}/{prec}"] = rec
+        assert rec["psnr_ref_vs_gt_db"] >= 25.0 and rec["saturated_fraction"] < 0.05, rec
+        assert rec["code_agreement"] == 1.0, rec
+        if prec == "x3f16":
+            assert abs(rec["dpsnr_db"]) <= 1e-3, rec
+            assert rec["psnr_build_vs_ref_unclamped_db"] >= 70.0, rec
+            # the u8 frame the driver writes: floor(clamp(x, 0, 1) * 255) of the middle frame (inference.py:16-18)
+            u8 = m.restore_middle_u8(torch.from_numpy(win).to(DEV), w=1.0).cpu()
+            ref_u8 = (torch.from_numpy(g[f"{tag}.out_mid_rows"]).clamp(0, 1) * 255).to(torch.uint8).permute(1, 2, 0)
+            du = (u8[::8].int() - ref_u8.int()).abs()
+            _LOG[f"operating_point/{tag}/{prec}"].update(u8_max_diff=int(du.max()), u8_equal_fraction=float((du == 0).float().mean()))
+            assert du.max() <= 1 and (du == 0).float().mean() >= 0.97
+        elif prec == "fp32":
+            assert abs(rec["dpsnr_db"]) <= 1e-4 and rec["psnr_build_vs_ref_unclamped_db"] >= 90.0, rec
+        else:
+            assert rec["psnr_build_vs_ref_unclamped_db"] >= 50.0, rec
 
 
 def test_whole_model_pure_bf16_report(models, golden_window):
@@ -210,7 +282,7 @@ def test_whole_model_pure_bf16_report(models, golden_window):
     assert rec["lq_feat_err"] < 0.5 and rec["code_agreement"] > 0.9
 
 
-@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "x3f16"])
 def test_teacher_forced_decoder_and_concat_paths(models, golden_window, prec):
     """Decoder-side arithmetic separated from code flips: the reference's codes are fed in (forward_nhwc(codes=...)), so
     quantiser gather -> AdaIN -> decoder -> SFT fusion (incl. the in-place [enc | dec | fut] concat writes of the bf16
@@ -235,7 +307,7 @@ def test_teacher_forced_decoder_and_concat_paths(models, golden_window, prec):
            "psnr_full_sub4_clamped_db": psnr(out[:, :, ::4, ::4].clamp(0, 1), f16.clamp(0, 1))}
     _LOG[f"teacher_forced/{prec}"] = rec
     assert same, rec
-    floor = 35.0 if prec == "bf16x3" else 30.0
+    floor = {"x3f16": 55.0, "bf16x3": 35.0, "bf16": 30.0}[prec]
     assert rec["psnr_full_sub4_clamped_db"] >= floor, rec
 
 
@@ -246,7 +318,7 @@ def test_overlap_aware_windows_equal_stacked_windows(models):
 
     lq, _ = make_clip(4, 512, seed=5)
     frames = torch.from_numpy(lq).to(DEV)
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("fp32", "bf16x3", "x3f16"):
         m = models[prec]
         win = m.window_index(2, 3, DEV)
         a, la, _ = m.forward_nhwc(frames, w=1.0, win=win)
@@ -262,7 +334,7 @@ def test_overlap_aware_windows_equal_stacked_windows(models):
         # of this random-init network amplifies flipped bf16 roundings of its inputs to its own noise floor (PSNR(build,
         # reference) is 35.4 dB for the same reason), so the two outputs are held to that floor, not to bit equality
         assert d_log <= 2e-4 and same_codes, (prec, d_log)
-        assert (d_out <= 2e-3) if prec == "fp32" else (p_db >= 33.0), (prec, d_out, p_db)
+        assert (d_out <= 2e-3) if prec == "fp32" else (p_db >= (50.0 if prec == "x3f16" else 33.0)), (prec, d_out, p_db)
 
 
 def test_parsing_map_and_public_paths_match_host_oracle(models, cfg, full_sd, golden_window):
@@ -330,7 +402,7 @@ def test_default_mode_codes_with_other_weights_and_inputs(cfg, seed):
     o_out, o_logits, o_lq = O.pgtformer_forward(sd, cfg, x, w=1.0, taps=taps)
     m = PGTFormer(**cfg)
     m.load_state_dict(sd, strict=True)
-    m.prepare(DEV, "bf16x3")
+    m.prepare(DEV)                       # the default mode
     out, logits, lq = m(x.to(DEV))
     codes = m.last_codes.cpu().numpy().reshape(-1)
     want = taps["codes"].numpy().reshape(-1)
@@ -342,7 +414,7 @@ def test_default_mode_codes_with_other_weights_and_inputs(cfg, seed):
            "max_mismatch_margin": float(margin[bad].max()) if bad.any() else 0.0, "min_margin": float(margin.min()),
            "logits_err": float((logits.cpu() - o_logits).abs().max()),
            "psnr_db": float(-10.0 * torch.log10(d.pow(2).mean()))}
-    _LOG[f"whole/bf16x3_seed{seed}_vs_host_oracle"] = rec
+    _LOG[f"whole/x3f16_seed{seed}_vs_host_oracle"] = rec
     assert rec["max_mismatch_margin"] < 1e-3 and rec["code_agreement"] >= 0.997, rec
     assert rec["logits_err"] < 2e-3, rec
     if not bad.any():
@@ -416,7 +488,7 @@ def test_middle_only_tail_equals_full_forward(models):
 
     lq, _ = make_clip(4, 512, seed=9)
     frames = torch.from_numpy(lq).to(DEV)
-    for prec, wv in (("fp32", 1.0), ("fp32", 0), ("bf16x3", 1.0)):
+    for prec, wv in (("fp32", 1.0), ("fp32", 0), ("bf16x3", 1.0), ("x3f16", 1.0)):
         m = models[prec]
         win = m.window_index(2, 3, DEV)
         full, lf, _ = m.forward_nhwc(frames, w=wv, win=win)
@@ -428,7 +500,7 @@ def test_middle_only_tail_equals_full_forward(models):
         p_db = psnr(mid.float().clamp(0, 1).cpu(), want.clamp(0, 1).cpu())
         _LOG[f"middle_only/{prec}/w{wv}"] = {"max_abs": d, "psnr_db": p_db, "logits_equal": bool(torch.equal(lf, lm))}
         assert torch.equal(lf, lm)
-        assert (d <= 2e-3) if prec == "fp32" else (p_db >= 33.0), (prec, wv, d, p_db)
+        assert (d <= 2e-3) if prec == "fp32" else (p_db >= (50.0 if prec == "x3f16" else 33.0)), (prec, wv, d, p_db)
 
 
 def test_driver_119_frame_clip_through_the_real_model(models):
@@ -473,8 +545,9 @@ def test_driver_119_frame_clip_through_the_real_model(models):
 def test_cli_streams_a_raw_clip_end_to_end(models, tmp_path):
     """`python -m pgtformer_amd.driver -i clip.rgb -o out.rgb --synthetic` (the counterpart of `python inference.py -i .. -o ..`):
     decode in chunks -> segments with 1-frame halos -> pipelined restore -> sink; 21 frames in segments of 16, 8 windows per
-    forward, against one pass of the in-process driver over the whole clip (same synthetic weights, fp32 mode: u8 within
-    +-1; in the bf16 modes two processes that tune to different kernel variants differ at the decoder's 35 dB bf16 floor)."""
+    forward, against one pass of the in-process driver over the whole clip (same synthetic weights; u8 within +-1).
+    Kernel selection is deterministic (static heuristic; timing-based tuning is opt-in), so two PROCESSES write bit-identical
+    frames - in fp32 and in the default mode - as two runs of the reference do (make_golden.py: repeat diff 0)."""
     import subprocess
     import sys
 
@@ -483,19 +556,28 @@ def test_cli_streams_a_raw_clip_end_to_end(models, tmp_path):
 
     base, _ = make_clip(7, 512, seed=21)
     clip = np.concatenate([base] * 3, 0)
-    src, dst = tmp_path / "clip.rgb", tmp_path / "out" / "restored.rgb"
+    src = tmp_path / "clip.rgb"
     src.write_bytes(clip.tobytes())
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pgtformer_amd.driver", "-i", str(src), "-o", str(dst), "--synthetic", "--batch", "8",
-                        "--segment", "16", "--precision", "fp32"], cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    assert r.returncode == 0, r.stdout.decode()[-2000:]
-    got = np.frombuffer(dst.read_bytes(), np.uint8).reshape(21, 512, 512, 3)
-    m = models["fp32"]
-    padded = torch.empty((23, 512, 512, 3), dtype=torch.uint8).pin_memory()
-    padded[1:22].copy_(torch.from_numpy(clip))
-    want = torch.empty((21, 512, 512, 3), dtype=torch.uint8).pin_memory()
-    restore_clip_host(WindowRunner(m, 1.0, use_graph=True, batch=8, lanes=2), padded, want)
-    torch.cuda.synchronize()
-    d = np.abs(got.astype(np.int16) - want.numpy().astype(np.int16))
-    _LOG["cli_stream/fp32"] = {"max_u8_diff": int(d.max()), "equal_fraction": float((d == 0).mean())}
-    assert d.max() <= 1 and (d == 0).mean() > 0.99, _LOG["cli_stream/fp32"]
+    env = {k: v for k, v in os.environ.items() if k not in ("PGT_AUTOTUNE", "PGT_AUTOTUNE_CACHE")}
+
+    def cli(prec, tag):
+        dst = tmp_path / f"out_{prec}_{tag}" / "restored.rgb"
+        r = subprocess.run([sys.executable, "-m", "pgtformer_amd.driver", "-i", str(src), "-o", str(dst), "--synthetic", "--batch", "8",
+                            "--segment", "16", "--precision", prec], cwd=repo, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        return np.frombuffer(dst.read_bytes(), np.uint8).reshape(21, 512, 512, 3)
+
+    for prec in ("fp32", "x3f16"):
+        got, again = cli(prec, "a"), cli(prec, "b")
+        assert np.array_equal(got, again), f"{prec}: two processes wrote different frames"
+        m = models[prec]
+        padded = torch.empty((23, 512, 512, 3), dtype=torch.uint8).pin_memory()
+        padded[1:22].copy_(torch.from_numpy(clip))
+        want = torch.empty((21, 512, 512, 3), dtype=torch.uint8).pin_memory()
+        restore_clip_host(WindowRunner(m, 1.0, use_graph=True, batch=8, lanes=2), padded, want)
+        torch.cuda.synchronize()
+        d = np.abs(got.astype(np.int16) - want.numpy().astype(np.int16))
+        _LOG[f"cli_stream/{prec}"] = {"max_u8_diff": int(d.max()), "equal_fraction": float((d == 0).mean()),
+                                      "two_processes_bit_equal": True}
+        assert d.max() <= 1 and (d == 0).mean() > 0.99, _LOG[f"cli_stream/{prec}"]

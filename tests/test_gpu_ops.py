@@ -1,11 +1,12 @@
 """GPU parity tests, operator level: every HIP kernel (called through the C-ABI via pgtformer_amd.ops)
 against the torch-CPU operator emulation (tests/emu_ops.py) on the same seeded inputs, in f32 (exact
-MFMA, tight tolerance) and bf16 (bf16 MFMA, fp32 accumulate).  Each comparison is also logged to
+MFMA, tight tolerance), bf16 and IEEE half (16-bit MFMA, fp32 accumulate).  Each comparison is also logged to
 gpurun_out/parity_ops.json.
 
 Tolerances (written here, per the parity contract):
   f32 : max|got-want| <= 2e-4 * max(1, max|want|)     (fp32 accumulation-order differences)
   bf16: max|got-want| <= 4e-2 * max(1, max|want|)     (inputs/outputs rounded to bf16, 8-bit mantissa)
+  f16 : max|got-want| <= 5e-3 * max(1, max|want|)     (inputs/outputs rounded to IEEE half, 11-bit mantissa)
   integer results (codes, u8 frames): bit-exact (u8: +-1 allowed only where noted)
 """
 import json
@@ -20,8 +21,9 @@ from tests import emu_ops as E
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
-TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
-DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 4e-2, torch.float16: 5e-3}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+H16 = [torch.bfloat16, torch.float16]       # the two 16-bit MFMA operand types
 _LOG = []
 
 
@@ -416,14 +418,14 @@ V4_SHAPES = [(n, a, b, c, d, e, f, 1, False) for (n, a, b, c, d, e, f) in V3_SHA
     ("v4_ups_odd", 1, 9, 13, 64, 72, 3, 1, True), ("v4_stride2", 2, 32, 40, 128, 128, 3, 2, False)]
 
 
+@pytest.mark.parametrize("dtype", H16, ids=["bf16", "f16"])
 @pytest.mark.parametrize("bn", [256, 128])
 @pytest.mark.parametrize("shape", V4_SHAPES, ids=[s[0] for s in V4_SHAPES])
-def test_conv2d_phased_kernel(shape, bn):
+def test_conv2d_phased_kernel(shape, bn, dtype):
     """igemm4 (256x256 / 512x128 tiles, 8 waves, phase-interleaved LDS-DMA schedule, strided and up-sampled inputs)
     against the emulation and v1, plus a repeat-run screen: the hand-placed vmcnt/barrier schedule must give
     bit-identical results on every launch."""
     name, n, h, w_, cin, cout, k, stride, ups = shape
-    dtype = torch.bfloat16
     x = rnd((n, h, w_, cin), 310, dtype)
     wt = rnd((cout, k * k * cin), 311, dtype, 1.0 / np.sqrt(k * k * cin))
     wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
@@ -453,13 +455,13 @@ V5_SHAPES = [("v5_w32", 2, 32, 32, 64, 256, 3), ("v5_w64_c128", 1, 64, 64, 128, 
              ("v5_1x3", 1, 32, 64, 128, 128, (1, 3))]
 
 
+@pytest.mark.parametrize("dtype", H16, ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", V5_SHAPES, ids=[s[0] for s in V5_SHAPES])
-def test_conv2d_tap_reuse_kernel(shape):
+def test_conv2d_tap_reuse_kernel(shape, dtype):
     """igemm5 (igemm4 schedule, one LDS input image shared by the three horizontal taps, reads shifted by kx) against
     the emulation and v1, all epilogues, plus the repeat-run determinism screen of the hand-placed schedule."""
     name, n, h, w_, cin, cout, k = shape
     kh, kw_ = k if isinstance(k, tuple) else (k, k)
-    dtype = torch.bfloat16
     x = rnd((n, h, w_, cin), 410, dtype)
     wt = rnd((cout, kh * kw_ * cin), 411, dtype, 1.0 / np.sqrt(kh * kw_ * cin))
     wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
@@ -486,12 +488,12 @@ V6_SHAPES = [("v6_w32", 2, 32, 32, 64, 64), ("v6_w64_c40", 1, 16, 64, 64, 40), (
              ("v6_w512_ragged_m", 1, 2, 512, 64, 64), ("v6_many_tiles", 6, 128, 128, 64, 64), ("v6_c8", 1, 32, 64, 64, 8), ("v6_c3_scalar_epilogue", 2, 32, 64, 64, 3)]
 
 
+@pytest.mark.parametrize("dtype", H16, ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", V6_SHAPES, ids=[s[0] for s in V6_SHAPES])
-def test_conv2d_c64_kernel(shape):
+def test_conv2d_c64_kernel(shape, dtype):
     """igemm6 (3x3, Cin = 64, Cout <= 64: register-resident weights, persistent workgroups, halo images) against the
     emulation and v1, all epilogues, repeat-run determinism."""
     name, n, h, w_, cin, cout = shape
-    dtype = torch.bfloat16
     x = rnd((n, h, w_, cin), 510, dtype)
     wt = rnd((cout, 9 * cin), 511, dtype, 1.0 / np.sqrt(9 * cin))
     wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
@@ -535,11 +537,11 @@ def test_conv2d_output_parity_placement_splitk():
     assert float(guard.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", H16, ids=["bf16", "f16"])
 @pytest.mark.parametrize("kernel", [0, 1, 4])
-def test_conv2d_output_parity_placement(kernel):
+def test_conv2d_output_parity_placement(kernel, dtype):
     """2x2 sub-pixel convolution written to out[:, py::2, px::2, :] (pgt_conv_desc::orow_*) for all four parities; the
     merged-tap decomposition reproduces nearest-x2 + conv3x3."""
-    dtype = torch.bfloat16
     n, h, w_, cin, cout = 2, 12, 32, 64, 128
     x = rnd((n, h, w_, cin), 610, dtype)
     w3 = rnd((cout, 3, 3, cin), 611, torch.float32, 1.0 / np.sqrt(9 * cin))
