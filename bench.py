@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, physical cores))")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--clip-frames", type=int, default=0,
+                    help="BASELINE.json configs[2]: ONE synthetic clip of this many frames (256 in the config), sharded by "
+                         "output-frame range over the --gpus ranks with one all_gather of boundary frames, restored frames gathered "
+                         "to rank 0; time = first H2D -> last D2H; a step = one pass over the clip (strong scaling)")
     return ap.parse_args()
 
 
@@ -148,7 +152,7 @@ def live_roofline(runner, frames, precision, nwin):
                 f.write(f"{shape} {cfg} {dt} {cnt} {us:.1f} {us / cnt:.1f} {fl / us / 1e6:.1f} {by / us / 1e3:.0f}\n")
     # HBM traffic of the igemm family from separate rocprofv3 --pmc passes (tools/pmc_traffic.py): only a measurement taken
     # with THIS library build (sha256 of libpgt_hip.so) in this configuration is quoted - a stale file is refused
-    traffic, tsrc = None, None
+    traffic, tsrc, wf_pmc = None, None, None
     sha = _lib_sha16()
     for name in sorted(os.listdir(os.path.join(REPO, "profiles")), reverse=True):
         if not name.endswith("igemm_traffic_pmc.json"):
@@ -157,6 +161,7 @@ def live_roofline(runner, frames, precision, nwin):
         if tj.get("windows_per_forward") == nwin and tj.get("precision") == precision:
             if tj.get("lib_sha16") == sha:
                 traffic, tsrc = round(tj["hbm_bytes_per_launch"] / 1e9, 4), f"profiles/{name} (GB per launch, same library build)"
+                wf_pmc = tj.get("whole_forward", {}).get("hbm_gb_per_window")
                 break
             tsrc = f"profiles/{name} is stale (library {tj.get('lib_sha16')} != {sha}): not quoted"
     x3 = [r for r in ig if r.get("x3")]
@@ -178,7 +183,8 @@ def live_roofline(runner, frames, precision, nwin):
             "whole_forward": {"kernel_ms_per_step": round(all_ms, 2), "launches": len(recs),
                               "algorithmic_gb_per_window": round(all_by / nwin / 1e9, 3),
                               "algorithmic_tflop_per_window": round(all_fl / nwin / 1e12, 3),
-                              "hbm_gbs_over_the_step": round(all_by / (all_ms * 1e-3) / 1e9, 1)},
+                              "hbm_gbs_over_the_step": round(all_by / (all_ms * 1e-3) / 1e9, 1),
+                              "pmc_hbm_gb_per_window": None if wf_pmc is None else round(wf_pmc, 3)},
             "lib_sha16": sha,
             "slowest_launches": [{"shape_NHWCinCoutKSU": list(r["shape"]), "dtype": r["dt"] + ("x3" if r["x3"] else ""),
                                   "us": round(r["ms"] * 1e3, 1), "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1)}
@@ -230,6 +236,64 @@ def cpu_baseline(cfg, sd, window_u8, budget_s=30.0, threads=0):
             "cpu_model": _cpu_model_name(), "host_logical_cpus": os.cpu_count()}
 
 
+def clip_mode(args, model, dev, rank, world):
+    """configs[2]: "pgtformer-base, 8xMI355X, 256-frame synthetic clip sharded by window with xGMI boundary all-gather"
+    (SURVEY 8d config 3 / 8e).  Every rank holds only its own frame range (pinned host, uint8) - frame_range shard, the
+    synthetic generator is per-frame - and per pass: H2D of its frames, ONE all_gather of first / last frames (the halos),
+    its forwards, gather of the restored frames to rank 0, D2H of the whole restored clip on rank 0."""
+    from pgtformer_amd import parallel
+    from pgtformer_amd.driver import WindowRunner, restore_clip
+    from pgtformer_amd.synth import make_clip
+
+    F, B = args.clip_frames, args.windows_per_forward
+    s0, e0 = parallel.frame_range(F, rank, world)
+    lq_u8, _ = make_clip(e0 - s0, 512, seed=1234, start=s0)
+    mine = torch.from_numpy(lq_u8).pin_memory()
+    out_host = torch.empty((F, 512, 512, 3), dtype=torch.uint8).pin_memory() if rank == 0 else None
+    runner = WindowRunner(model, 1.0, not args.no_graph, 512, 512, batch=min(B, max(1, e0 - s0)), overlap=not args.no_overlap,
+                          full_tail=args.full_tail, lanes=args.lanes)
+
+    def one_pass():
+        allf = restore_clip(runner, mine, rank, world, gather=True, n_total=F)   # H2D, halo all_gather, forwards, gather to rank 0
+        if rank == 0:
+            out_host.copy_(allf, non_blocking=True)                       # D2H of the restored clip
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        one_pass()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return {"metric": "restored 512x512 frames/sec", "value": round(F * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision], "data": "synthetic",
+            "config": {"workload": f"pgtformer-base, ONE {F}-frame synthetic degraded 512x512 clip sharded by output-frame range over "
+                                   f"{world} GPU(s) ({e0 - s0} frames on rank 0), 1 all_gather of boundary frames, restored frames "
+                                   "gathered to rank 0 (BASELINE.json configs[2]); a step = one pass over the clip, timed from the "
+                                   "first H2D to the last D2H",
+                       "precision": args.precision, "clip_frames": F, "frames_per_rank": e0 - s0, "windows_per_forward": runner.batch,
+                       "hip_graph": not args.no_graph, "steps_in_flight": runner.lanes,
+                       "clip_location": "pinned host memory on every rank (H2D / D2H inside the timed region)",
+                       "parallelism": f"frame-range shard x{world}, 1 all_gather of boundary frames + 1 gather of restored frames"}}
+
+
+DTYPE_NAMES = {"x3f16": "f16 / bf16 (16-bit MFMA, fp32 accumulate: IEEE-half decoder, code branch on split-bf16 operands)",
+               "bf16x3": "bf16 (bf16 MFMA, fp32 accumulate; code branch on split-bf16 operands)", "bf16": "bf16",
+               "mixed": "bf16 (decoder) / f32 (code branch)", "fp32": "f32"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -254,6 +318,15 @@ def main():
     model = PGTFormer(**cfg)
     model.load_state_dict(sd, strict=True)
     model.prepare(dev, args.precision)
+
+    if args.clip_frames:
+        res = clip_mode(args, model, dev, rank, world)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
 
     # this rank's slice of the synthetic clip.  One step = one forward of B windows, so a rank restores steps*B frames
     # (weak scaling: the per-rank clip is fixed as ranks are added).
@@ -311,9 +384,7 @@ def main():
     res = {"metric": "restored 512x512 frames/sec", "value": round(n_local * world / dt, 3), "unit": "frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": {"x3f16": "f16 / bf16 (16-bit MFMA, fp32 accumulate: IEEE-half decoder, code branch on split-bf16 operands)",
-                     "bf16x3": "bf16 (bf16 MFMA, fp32 accumulate; code branch on split-bf16 operands)", "bf16": "bf16",
-                     "mixed": "bf16 (decoder) / f32 (code branch)", "fp32": "f32"}[args.precision],
+           "dtype": DTYPE_NAMES[args.precision],
            "data": "synthetic",
            "config": {"workload": "pgtformer-base, 3-frame 512x512 window -> 1 restored frame, synthetic degraded "
                                   "VFHQ-shape clip, random-init weights (BASELINE.json configs[1])",

@@ -41,8 +41,19 @@ __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __res
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int qi = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
+    // XCD-aware order over the flat (batch, head, query block) index: the query blocks of one (batch, head) stream the
+    // same K / V rows - a contiguous run of ids per XCD keeps them behind one L2 (dispatch is round-robin over the 8 XCDs)
+    int qblk, head, b;
+    {
+        const int nqb = gridDim.x, nh = gridDim.y, nblk = nqb * nh * gridDim.z;
+        const int b0 = blockIdx.x + nqb * (blockIdx.y + nh * blockIdx.z);
+        const int xcd = b0 & 7, q8 = nblk >> 3, r8 = nblk & 7;
+        int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b0 >> 3);
+        qblk = id % nqb; id /= nqb;
+        head = id % nh;
+        b = id / nh;
+    }
+    const int qi = qblk * (32 * NW) + wave * 32 + (lane & 31);
     const long rowbase = (long)b * L;
 
     // Q^T fragments (B operand of S^T): 4 k-steps of 16 head-dims, this half's 8 dims each

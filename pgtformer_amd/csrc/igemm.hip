@@ -391,7 +391,7 @@ template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm,
     // layers at 512x512 / 256x256 amortise their weight tile better with BM=128.
     int bm = 64, bn = 64;
     if (p.Cout <= 64) {
-        if (p.K >= 512 && p.M >= 65536) bm = 128;
+        if (p.K >= 128 && p.M >= 65536) bm = 128;
     } else if (p.K >= 1024 && (long)((p.M + 63) / 64) * ((p.Cout + 127) / 128) >= 512) {
         bn = 128;
     }
@@ -568,6 +568,22 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
                           d->Ho == d->H && d->Wo == d->W && pow2(d->W) && pow2(d->H) && d->W >= 32 && d->ldx % 8 == 0;
     PGT_CHECK(d->kernel != 6 || v6_legal, "pgt_conv2d: kernel=6 needs a 3x3 stride-1 same-size conv, Cin == 64, Cout <= 64, power-of-two maps");
     if (d->kernel == 6) return pgt_igemm6_launch(&p, st);
+    // ---- automatic selection (kernel = 0, no pinned tile): a STATIC function of the launch shape, so that two processes
+    //      run the same kernels and write the same bits.  The rules restate what timing-based tuning picked on MI355X for
+    //      the model's shapes (profiles/r2_v9_autotune_table_b16.json): the register-weight kernel for the 64-channel
+    //      3x3 layers; the phase-interleaved LDS-DMA kernel wherever it is legal and its 256x256 / 512x128 tiles cover at
+    //      least half of the chip's 256 CUs (Cout <= 128: the 512x128 tile); 128x64 tiles for the remaining <= 64-channel
+    //      outputs of the full-resolution maps; the register-staged 64-wide tiles otherwise.
+    if (d->kernel == 0 && d->force_bm == 0 && d->force_bn == 0) {
+        if (v6_legal && !p.gn_part) return pgt_igemm6_launch(&p, st);
+        const int bn4 = d->Cout <= 128 ? 128 : 256, bm4 = bn4 == 256 ? 256 : 512;
+        const long tiles4 = (long)((p.M + bm4 - 1) / bm4) * ((d->Cout + bn4 - 1) / bn4);
+        const bool gn4 = !p.gn_part || (p.gn_hw % bm4 == 0 && bn4 % p.gn_cpg == 0 && d->ups == 0);
+        if (v4_legal && d->Cout > 64 && tiles4 >= 128 && gn4) {
+            const int rc = pgt_igemm4_launch(&p, bn4, st);
+            if (rc != 1) return rc;
+        }
+    }
     if (d->kernel == 4) {
         const int rc = pgt_igemm4_launch(&p, d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256), st);
         PGT_CHECK(rc != 1, "pgt_conv2d: kernel=4 has no %d-column tile (128, 256)", d->force_bn);

@@ -67,7 +67,14 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
 
     const int tid = threadIdx.x;
     const int nwx = W / ww, nwy = H / wh;
-    int bid = blockIdx.x;
+    // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), but the heads of one
+    // window read ADJACENT 64 / 128-byte slices of the same token rows - give every XCD a contiguous run of (window, head)
+    // ids so that those slices meet in one L2 (bijective for any grid size, as in the conv kernels)
+    int bid;
+    {
+        const int nblk = gridDim.x, b0 = blockIdx.x, xcd = b0 & 7, q8 = nblk >> 3, r8 = nblk & 7;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b0 >> 3);
+    }
     const int head = bid % heads; bid /= heads;
     const int wx = bid % nwx; bid /= nwx;
     const int wy = bid % nwy; bid /= nwy;

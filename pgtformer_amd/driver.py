@@ -210,17 +210,20 @@ class WindowRunner:
         return out_host
 
 
-def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True):
-    """frames_u8: this rank's OWN output-range frames (n_local,H,W,3) uint8 (host or device).
-    Returns restored frames: all of them on rank 0 if `gather`, else this rank's range."""
+def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True, n_total=None):
+    """frames_u8: this rank's OWN output-range frames (n_local,H,W,3) uint8 (host or device), ranges as
+    parallel.frame_range(n_total, rank, world).  Returns restored frames: all of them on rank 0 if `gather`, else this rank's
+    range.  n_total: the clip's frame count when the caller knows it (otherwise the ranks' counts are summed first)."""
     local = frames_u8.to(runner.dev, non_blocking=True)
     n_local = local.shape[0]
     padded = parallel.padded_local_clip(local, rank, world, group)   # one all_gather of boundary frames
     out = runner.run_clip(padded, torch.empty_like(local)) if n_local else torch.empty_like(local)
     if world > 1 and gather:
-        n_total = torch.tensor([n_local], device=runner.dev)
-        torch.distributed.all_reduce(n_total, group=group)
-        return parallel.gather_outputs(out, int(n_total.item()), rank, world, 0, group)
+        if n_total is None:
+            cnt = torch.tensor([n_local], device=runner.dev)
+            torch.distributed.all_reduce(cnt, group=group)
+            n_total = int(cnt.item())
+        return parallel.gather_outputs(out, n_total, rank, world, 0, group)
     return out
 
 

@@ -43,24 +43,26 @@ def _gt_field(rng, size, n_frames, margin=64):
     return np.clip(field, 0.0, 1.0), margin
 
 
-def make_clip(n_frames, size=512, seed=1234):
-    """Return (lq_u8 (N,size,size,3) uint8, gt (N,size,size,3) float32 in [0,1])."""
+def make_clip(n_frames, size=512, seed=1234, start=0):
+    """Return (lq_u8 (N,size,size,3) uint8, gt (N,size,size,3) float32 in [0,1]): frames start .. start+N-1 of the clip
+    `seed` (a frame depends on the seed and its own index only, so ranks generate their own frame ranges)."""
     rng = np.random.default_rng(seed)
     field, margin = _gt_field(rng, size, n_frames)
     lq = np.empty((n_frames, size, size, 3), np.uint8)
     gt = np.empty((n_frames, size, size, 3), np.float32)
-    for i in range(n_frames):
+    for j in range(n_frames):
+        i = start + j
         # +-2 px inter-frame translation, periodic so long clips stay inside the margin
         dx = int(round(2 * ((i % 32) - 16) * (1 if (i // 32) % 2 == 0 else -1)))
         dy = int(round(2 * (((i * 7) % 32) - 16)))
         y0, x0 = margin + dy, margin + dx
         g = field[y0:y0 + size, x0:x0 + size]
-        gt[i] = g
+        gt[j] = g
         small = g.reshape(size // 4, 4, size // 4, 4, 3).mean(axis=(1, 3)).astype(np.float32)
         frng = np.random.default_rng(seed * 100003 + i)
         small = small + frng.normal(0.0, 5.0 / 255.0, small.shape).astype(np.float32)
         up = np.clip(_bilinear_up_align_corners(small, size, size), 0.0, 1.0)
-        lq[i] = np.floor(up * 255.0 + 0.5).astype(np.uint8)
+        lq[j] = np.floor(up * 255.0 + 0.5).astype(np.uint8)
     return lq, gt
 
 

@@ -99,6 +99,57 @@ def test_halo_exchange_world2_gloo(tmp_path):
         assert b"OK" in out
 
 
+_WORKER8 = r"""
+import os, sys, torch, numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["PGT_REPO"])
+from pgtformer_amd import parallel
+from pgtformer_amd.driver import restore_clip
+from pgtformer_amd.synth import make_clip
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+F = 256                                        # BASELINE.json configs[2]: one 256-frame clip over 8 ranks
+s, e = parallel.frame_range(F, rank, world)
+assert e - s == 32
+mine, _ = make_clip(e - s, 16, seed=1234, start=s)        # every rank generates only its own frame range
+class StubRunner:
+    # stands in for driver.WindowRunner: "restores" output frame j as a fixed mix of its 3-frame window
+    dev = torch.device("cpu")
+    def run_clip(self, padded, out):
+        p = padded.to(torch.int32)
+        out.copy_(((p[:-2] + 2 * p[1:-1] + 3 * p[2:]) % 251).to(torch.uint8))
+        return out
+full = restore_clip(StubRunner(), torch.from_numpy(mine), rank, world, gather=True, n_total=F)
+if rank == 0:
+    clip, _ = make_clip(F, 16, seed=1234)
+    p = torch.from_numpy(np.concatenate([clip[:1], clip, clip[-1:]], 0)).to(torch.int32)   # replicate-padded clip ends
+    want = ((p[:-2] + 2 * p[1:-1] + 3 * p[2:]) % 251).to(torch.uint8)
+    assert full.shape == want.shape and torch.equal(full, want)
+else:
+    assert full is None
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_configs2_clip_sharding_world8_gloo(tmp_path):
+    """BASELINE.json configs[2] (bench.py --clip-frames 256 --gpus 8): a 256-frame clip sharded 32 frames per rank, each rank
+    generating only its own range, one all_gather of boundary frames, restored frames gathered to rank 0 in clip order - with
+    a stub in place of the model, against the single-process result on the whole clip."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8)
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PGT_REPO=REPO,
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode()
+        assert b"OK" in out
+
+
 def test_synth_clip_is_deterministic():
     from pgtformer_amd.synth import make_clip, window_from_clip
 
@@ -110,3 +161,5 @@ def test_synth_clip_is_deterministic():
     assert np.array_equal(w0[0], a[0]) and np.array_equal(w0[1], a[0]) and np.array_equal(w0[2], a[1])
     w2 = window_from_clip(a, 2)
     assert np.array_equal(w2[2], a[2]) and np.array_equal(w2[1], a[2])
+    c, gc = make_clip(2, 64, seed=7, start=1)          # a frame depends on the seed and its own index only
+    assert np.array_equal(c, a[1:3]) and np.array_equal(gc, ga[1:3])

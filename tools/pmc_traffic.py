@@ -3,10 +3,12 @@
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/fetch -o r -- python bench.py --steps 2 --warmup 1 --no-graph ...
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/write -o r -- python bench.py --steps 2 --warmup 1 --no-graph ...
-  python tools/pmc_traffic.py out/fetch/r_results.db out/write/r_results.db profiles/r2_igemm_traffic_pmc.json [precision B]
+  python tools/pmc_traffic.py out/fetch/r_results.db out/write/r_results.db profiles/r3_igemm_traffic_pmc.json [precision B]
 
-`precision` and `B` (windows per forward) of the profiled command are stored in the file: bench.py quotes the measurement
-as `roofline.traffic` only for the matching configuration.
+`precision`, `B` (windows per forward) of the profiled command and the sha256 of the library build it ran are stored in the
+file: bench.py quotes the measurement as `roofline.traffic` only for the matching configuration AND the same libpgt_hip.so.
+Besides the conv / linear family the file carries the WHOLE forward: HBM bytes of every kernel, per forward and per window
+(forwards counted from the trace: argmax_rows_kernel runs once per forward).
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 counts 128-byte requests as 64 B for wide (16 B/lane) coalesced reads, so the read side is doubled.
@@ -40,9 +42,22 @@ def main(fetch_db, write_db, out, precision=None, windows_per_forward=None):
            "hbm_bytes_per_launch": (2 * f_kib * 1024) / max(nf, 1) + w_kib * 1024 / max(nw, 1),
            "note": "read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE under-count for 16 B/lane streams); "
                    "Infinity-Cache hits are included in these L2 fabric counters"}
+    fa_kib, na = per_kernel(fetch_db, "FETCH_SIZE", ("%",))
+    wa_kib, _ = per_kernel(write_db, "WRITE_SIZE", ("%",))
+    _, fwd = per_kernel(fetch_db, "FETCH_SIZE", ("%argmax_rows_kernel%",))
+    fwd = max(fwd, 1)
+    res["whole_forward"] = {"forwards_in_trace": fwd, "kernel_launches_per_forward": na / fwd,
+                            "hbm_read_bytes_per_forward_corrected_x2": 2 * fa_kib * 1024 / fwd,
+                            "hbm_write_bytes_per_forward": wa_kib * 1024 / fwd,
+                            "hbm_bytes_per_forward": (2 * fa_kib + wa_kib) * 1024 / fwd}
     if precision is not None:
         res["precision"] = precision
         res["windows_per_forward"] = int(windows_per_forward)
+        res["whole_forward"]["hbm_gb_per_window"] = res["whole_forward"]["hbm_bytes_per_forward"] / int(windows_per_forward) / 1e9
+    import hashlib
+    import os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgtformer_amd", "lib", "libpgt_hip.so")
+    res["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
