@@ -150,6 +150,12 @@ def live_roofline(runner, frames, precision, nwin):
             f.write("shape(N,H,W,Cin,Cout,k,stride,ups) cfg(kernel,bm,bn) dtype launches total_us avg_us TFLOP/s GB/s\n")
             for (shape, cfg, dt), (cnt, us, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{shape} {cfg} {dt} {cnt} {us:.1f} {us / cnt:.1f} {fl / us / 1e6:.1f} {by / us / 1e3:.0f}\n")
+    if os.environ.get("PGT_DUMP_OPS"):      # every non-conv launch of the instrumented pass: kernel, ms, algorithmic GB/s
+        with open(os.environ["PGT_DUMP_OPS"], "w") as f:
+            f.write("kernel us MB GB/s\n")
+            for r in recs:
+                if not conv(r):
+                    f.write(f"{r['kernel']} {r['ms'] * 1e3:.1f} {r['bytes'] / 1e6:.1f} {r['bytes'] / (r['ms'] * 1e-3) / 1e9:.0f}\n")
     # HBM traffic of the igemm family from separate rocprofv3 --pmc passes (tools/pmc_traffic.py): only a measurement taken
     # with THIS library build (sha256 of libpgt_hip.so) in this configuration is quoted - a stale file is refused
     traffic, tsrc, wf_pmc = None, None, None
