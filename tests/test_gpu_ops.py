@@ -647,6 +647,21 @@ def test_epilogue_statistics_linear_and_subpixel_and_x3(dtype):
     check("gn_x3_shift", b_e, b_w, torch.float32, 5.0)
 
 
+def test_statistics_epilogue_only_on_kernels_1_and_4():
+    """Round 2 left a wrong-result variant (igemm5 with a statistics epilogue) reverted; it is gone: a conv pinned to kernel 5
+    or 6 leaves NO epilogue statistics (the following GroupNorm takes its separate pass), and the C-ABI rejects the request."""
+    from pgtformer_amd import hip
+    O = ops()
+    x = rnd((2, 32, 32, 64), 900, torch.bfloat16)
+    wt = rnd((64, 9 * 64), 901, torch.bfloat16, 0.04)
+    for k in (5, 6):
+        y = O.conv2d(g(x), g(wt), None, kh=3, kw=3, pad=(1, 1, 1, 1), kernel=k, gn=32)
+        assert getattr(y, "_pgt_gn", None) is None
+    st = O.GnStats(2, 1, 32 * 32, 64, 32, DEV)
+    with pytest.raises(hip.PgtError, match="statistics epilogue"):
+        O.conv2d(g(x), g(wt), None, kh=3, kw=3, pad=(1, 1, 1, 1), kernel=5, gn=(st, 0))
+
+
 def test_model_with_and_without_epilogue_statistics(monkeypatch):
     """Whole TDResnetBlock / decoder-style chain: epilogue statistics on vs off (PGT_EPILOGUE_GN=0) agree to the rounding of
     the statistics (bf16: the stored tensor vs its un-rounded fp32 values)."""

@@ -6,7 +6,7 @@ TAG=${1:-r3}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-PGT_DUMP_SHAPES=$O/${TAG}_conv_shapes_x3f16_b16.txt timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_x3f16_b16.json 2> $O/${TAG}_bench.err
+PGT_DUMP_SHAPES=$O/${TAG}_conv_shapes_x3f16_b16.txt timeout 400 python bench.py --steps 20 --warmup 3 > $O/${TAG}_bench_x3f16_b16.json 2> $O/${TAG}_bench.err
 timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --resident --precision bf16x3 > $O/${TAG}_bench_bf16x3_b16.json 2>> $O/${TAG}_bench.err
 timeout 200 python bench.py --steps 2 --warmup 1 --clip-frames 256 > $O/${TAG}_bench_configs2_n1.json 2>> $O/${TAG}_bench.err
 cd /tmp
