@@ -216,6 +216,21 @@ int pgt_x3_to_half(const void* src, int32_t lds, int32_t src_lo, void* dst, int3
 int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float* dst, int32_t ldd, int64_t rows,
                  int32_t cols, pgt_stream_t stream);
 
+/* ---- weight repack (once, at load) --------------------------------------------------------------
+ * The conv / linear kernels take their weights K-major; the reference stores nn.Conv2d weights as (Cout, Cin, KH, KW) and
+ * nn.Linear weights as (Cout, Cin) (= KH = KW = 1).  pgt_pack_conv_weight writes the operand `pgt_conv2d` expects for
+ * `dtype` from the reference tensor on the device: (Cout, KH*KW*Cin_pad) in fp32 / bf16 / half with the input channels
+ * zero-padded to Cin_pad (3 -> 8, 57 -> 64, the [enc | dec | fut] concats -> multiples of 64); PGT_BF16X3: the
+ * [w_hi | w_hi | w_lo]-per-64-channel-block form, or with x3_fold (Cout == 64) the folded (128, KH*KW*2*Cin_pad) form.
+ * out_scale (Cout floats or NULL) multiplies every output channel in fp32 before the rounding: the eval-BatchNorm fold
+ * of BiSeNet (archs/pgtformer_arch.py:40-68), whose factors and folded bias pgt_fold_batchnorm computes
+ * (scale = gamma / sqrt(var + eps), bias = (conv_bias - mean) * scale + beta).  pgt_packed_weight_bytes sizes `packed`. */
+size_t pgt_packed_weight_bytes(int32_t dtype, int32_t Cout, int32_t Cin_pad, int32_t KH, int32_t KW, int32_t x3_fold);
+int pgt_pack_conv_weight(int32_t dtype, const float* w_oihw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                         int32_t Cin_pad, const float* out_scale, int32_t x3_fold, void* packed, pgt_stream_t stream);
+int pgt_fold_batchnorm(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, const float* conv_bias, int32_t C, float* scale, float* bias, pgt_stream_t stream);
+
 /* ---- quantiser -------------------------------------------------------------------------------
  * codes[r] = first argmax_j logits[r, j]  (logits.argmax(-1), pgtformer_arch.py:663) */
 int pgt_argmax_rows(const float* logits, int32_t ld, int32_t rows, int32_t K, int32_t* codes,

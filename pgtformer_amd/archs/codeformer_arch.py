@@ -35,11 +35,11 @@ class TransformerSALayer(HipModule):
     def _pack(self, device, dtype):
         e = self.embed_dim
         w, b = self.self_attn.in_proj_weight.detach(), self.self_attn.in_proj_bias.detach()
-        self.w_qk = _pack_matrix(w[:2 * e].float(), 1, device, dtype)   # applied to LN(x)+pos
+        self.w_qk = _pack_matrix(w[:2 * e], device, dtype)   # applied to LN(x)+pos
         self.b_qk = _f32(b[:2 * e], device)
-        self.w_v = _pack_matrix(w[2 * e:].float(), 1, device, dtype)    # applied to LN(x)
+        self.w_v = _pack_matrix(w[2 * e:], device, dtype)    # applied to LN(x)
         self.b_v = _f32(b[2 * e:], device)
-        self.w_o = _pack_matrix(self.self_attn.out_proj.weight.detach().float(), 1, device, dtype)
+        self.w_o = _pack_matrix(self.self_attn.out_proj.weight, device, dtype)
         self.b_o = _f32(self.self_attn.out_proj.bias, device)
 
     def forward(self, tgt, B, L, query_pos=None):

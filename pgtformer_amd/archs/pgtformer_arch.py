@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules.rstt_layers import Conv2d, HipModule, LayerNorm, Linear, TDResnetBlock, _f32, _is_x3  # noqa: F401
+from ..modules.rstt_layers import Conv2d, HipModule, LayerNorm, Linear, TDResnetBlock, _f32, _is_x3, _pack_matrix  # noqa: F401
 from ..ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU
 from ..registry import ARCH_REGISTRY
 from .codeformer_arch import TransformerSALayer, adaptive_instance_normalization
@@ -272,10 +272,7 @@ class Fuse_sft_block(HipModule):
 
     def _pack(self, device, dtype):
         # scale.0 and shift.0 read the same tensor: one conv with the two filter banks stacked on Cout
-        def packed(conv):
-            w = conv.weight.detach().float()
-            return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
-        self.w_ss0 = torch.cat([packed(self.scale[0]), packed(self.shift[0])], 0).to(device=device, dtype=dtype).contiguous()
+        self.w_ss0 = _pack_matrix(torch.cat([self.scale[0].weight.detach(), self.shift[0].weight.detach()], 0), device, dtype)
         self.b_ss0 = _f32(torch.cat([self.scale[0].bias.detach(), self.shift[0].bias.detach()], 0), device)
         # bf16: tconvenc/tconvdec -> stack over T -> tfusion0 -> tfusion1 are all 1x1 and linear (reference :467-473), so
         # fut of output frame `to` is ONE linear map of the window's T [enc|dec] pixels: a (T x 1)-tap conv over the
@@ -293,7 +290,7 @@ class Fuse_sft_block(HipModule):
                 rows = w0[to * tcc:(to + 1) * tcc]                                           # (tcc, 2*t*tcc)
                 taps = [torch.cat([w1 @ rows[:, ti * tcc:(ti + 1) * tcc] @ we,
                                    w1 @ rows[:, (t + ti) * tcc:(t + ti + 1) * tcc] @ wd_], 1) for ti in range(t)]
-                self.w_mix.append(torch.stack(taps, 1).reshape(tcc, -1).contiguous().to(device=device, dtype=dtype))
+                self.w_mix.append(_pack_matrix(torch.stack(taps, 1).reshape(tcc, -1), device, dtype))     # K-major (tcc, T*2C)
                 self.b_mix.append(_f32(w1 @ (rows @ bcat + b0[to * tcc:(to + 1) * tcc]) + b1, device))
 
     def concat_width(self):

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _is_x3, prepare_tree)
+from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _is_x3, _pack_matrix, prepare_tree)
 from ..ops import ACT_SILU, X3
 from ..config import DEFAULT_PRECISION
 from ..registry import ARCH_REGISTRY
@@ -47,7 +47,7 @@ class Upsample(HipModule):
             for px in (0, 1):
                 w2 = torch.stack([torch.stack([sum(w[:, :, ky, kx] for ky in self._ROWS[py][a] for kx in self._ROWS[px][b])
                                                for b in (0, 1)], -1) for a in (0, 1)], -2)      # (Cout, Cin, 2, 2)
-                self.sub_w[(py, px)] = w2.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(device=device, dtype=dtype)
+                self.sub_w[(py, px)] = _pack_matrix(w2, device, dtype)
 
     def forward(self, x):
         if self.sub_w is None:

@@ -361,6 +361,64 @@ __global__ void zero2d_kernel(char* __restrict__ dst, long ldd, long rows, int c
 
 inline dim3 grid1d(long n, int blk = 256) { return dim3((unsigned)((n + blk - 1) / blk)); }
 
+// ---- weight repack (once per model, at load): reference (Cout, Cin, KH, KW) fp32 -> the conv kernels' B operand -------------
+// K-major rows (Cout, KH*KW*Cin_pad), k = (ky*KW + kx)*Cin_pad + ci, input channels zero-padded to Cin_pad, an optional
+// per-output-channel factor (eval-BatchNorm fold) applied in fp32 before the rounding to D.
+template <typename D>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int Cin_pad,
+                                                          const float* __restrict__ scale, D* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int taps = KH * KW;
+    if (i >= (long)Cout * taps * Cin_pad) return;
+    const int ci = (int)(i % Cin_pad);
+    const int tap = (int)((i / Cin_pad) % taps);
+    const int co = (int)(i / ((long)Cin_pad * taps));
+    float v = 0.f;
+    if (ci < Cin) v = __fmul_rn(w[((long)co * Cin + ci) * taps + tap], scale ? scale[co] : 1.f);
+    stf(out + i, v);
+}
+// split-bf16 forms.  Standard: (Cout, KH*KW*3*Cin_pad), per tap and 64-channel block [w_hi | w_hi | w_lo] (the kernels visit
+// the block's input planes as [x_hi | x_lo | x_hi]).  Folded (Cout == 64): (128, KH*KW*2*Cin_pad), rows 0..63 [w_hi | w_hi],
+// rows 64..127 [w_lo | 0] per tap and block (pgt_conv_desc::x3_fold).
+__global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int Cin_pad,
+                                                             const float* __restrict__ scale, bf16_t* __restrict__ out, int fold) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int taps = KH * KW;
+    if (i >= (long)Cout * taps * Cin_pad) return;
+    const int ci = (int)(i % Cin_pad);
+    const int tap = (int)((i / Cin_pad) % taps);
+    const int co = (int)(i / ((long)Cin_pad * taps));
+    float v = 0.f;
+    if (ci < Cin) v = __fmul_rn(w[((long)co * Cin + ci) * taps + tap], scale ? scale[co] : 1.f);
+    const uint16_t hi = f2bf(v);
+    const uint16_t lo = f2bf(v - bf2f(hi));
+    const int nblk = Cin_pad / 64, blk = ci / 64, c = ci % 64;
+    if (!fold) {
+        bf16_t* o = out + (long)co * taps * 3 * Cin_pad + ((long)tap * nblk + blk) * 192 + c;
+        o[0].v = hi;
+        o[64].v = hi;
+        o[128].v = lo;
+    } else {
+        const long rowlen = (long)taps * 2 * Cin_pad, off = ((long)tap * nblk + blk) * 128 + c;
+        bf16_t* top = out + (long)co * rowlen + off;
+        bf16_t* bot = out + (long)(64 + co) * rowlen + off;
+        top[0].v = hi;
+        top[64].v = hi;
+        bot[0].v = lo;
+        bot[64].v = 0;
+    }
+}
+// eval-mode BatchNorm2d folded into the preceding conv: s = gamma / sqrt(var + eps), bias' = (bias - mean) * s + beta
+// (separately rounded operations, as the reference's ATen ops round them)
+__global__ void fold_bn_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                               const float* bias, int C, float* scale, float* bias_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    const float s = __fdiv_rn(gamma[i], __fsqrt_rn(__fadd_rn(var[i], eps)));
+    scale[i] = s;
+    bias_out[i] = __fadd_rn(__fmul_rn(__fsub_rn(bias ? bias[i] : 0.f, mean[i]), s), beta[i]);
+}
+
 }  // namespace
 
 #define DT_DISPATCH(dtype, NAME, CALL_F32, CALL_BF16)              \
@@ -605,6 +663,41 @@ extern "C" int pgt_zero2d(void* dst, int64_t ldd_bytes, int64_t rows, int32_t ro
     if (rows == 0) return 0;
     hipLaunchKernelGGL(zero2d_kernel, grid1d((long)rows * (row_bytes / 16)), dim3(256), 0, (hipStream_t)stream, (char*)dst,
                        (long)ldd_bytes, (long)rows, row_bytes / 16);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t pgt_packed_weight_bytes(int32_t dtype, int32_t Cout, int32_t Cin_pad, int32_t KH, int32_t KW, int32_t x3_fold) {
+    const size_t k = (size_t)KH * KW * Cin_pad;
+    if (dtype == PGT_F32) return (size_t)Cout * k * 4;
+    if (dtype == PGT_BF16 || dtype == PGT_F16) return (size_t)Cout * k * 2;
+    if (dtype == PGT_BF16X3) return x3_fold ? (size_t)128 * 2 * k * 2 : (size_t)Cout * 3 * k * 2;
+    return 0;
+}
+
+extern "C" int pgt_pack_conv_weight(int32_t dtype, const float* w_oihw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                                    int32_t Cin_pad, const float* out_scale, int32_t x3_fold, void* packed, pgt_stream_t stream) {
+    PGT_CHECK(w_oihw && packed && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && Cin_pad >= Cin, "pack_conv_weight: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)Cout * KH * KW * Cin_pad;
+    const dim3 g = grid1d(total);
+    if (dtype == PGT_BF16X3) {
+        PGT_CHECK(Cin_pad % 64 == 0, "pack_conv_weight: split-bf16 weights come in 64-channel K blocks (Cin_pad=%d)", Cin_pad);
+        PGT_CHECK(!x3_fold || Cout == 64, "pack_conv_weight: the folded form is for 64 output channels (Cout=%d)", Cout);
+        hipLaunchKernelGGL(pack_weight_x3_kernel, g, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (bf16_t*)packed, x3_fold);
+        PGT_LAUNCH_CHECK();
+        return 0;
+    }
+    PGT_CHECK(!x3_fold, "pack_conv_weight: x3_fold goes with dtype PGT_BF16X3");
+    DT_DISPATCH_T(dtype, "pack_conv_weight",
+                  hipLaunchKernelGGL((pack_weight_kernel<T_>), g, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (T_*)packed));
+}
+
+extern "C" int pgt_fold_batchnorm(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                  float eps, const float* conv_bias, int32_t C, float* scale, float* bias, pgt_stream_t stream) {
+    PGT_CHECK(gamma && beta && running_mean && running_var && scale && bias && C > 0, "fold_batchnorm: bad argument");
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps,
+                       conv_bias, C, scale, bias);
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -53,6 +53,9 @@ SIGNATURES = {
     "pgt_x3_split": [vp, i32, vp, i32, i32, i64, i32, vp],
     "pgt_x3_merge": [vp, i32, i32, vp, i32, i64, i32, vp],
     "pgt_x3_to_half": [vp, i32, i32, vp, i32, i64, i32, vp],
+    "pgt_packed_weight_bytes": [i32, i32, i32, i32, i32, i32],
+    "pgt_pack_conv_weight": [i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp],
+    "pgt_fold_batchnorm": [vp, vp, vp, vp, f32, vp, i32, vp, vp, vp],
     "pgt_argmax_rows": [vp, i32, i32, i32, vp, vp],
     "pgt_rq_argmin": [vp, i32, vp, vp, i32, i32, vp, vp],
     "pgt_rq_nearest": [i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp],
@@ -76,7 +79,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz,
              "pgt_commit_loss_workspace_bytes": sz, "pgt_conv_gn_workspace_bytes": sz,
-             "pgt_conv2d_workspace_bytes": sz}
+             "pgt_conv2d_workspace_bytes": sz, "pgt_packed_weight_bytes": sz}
 
 
 class PgtError(RuntimeError):

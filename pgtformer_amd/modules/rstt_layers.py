@@ -50,12 +50,10 @@ def _is_x3f(dtype):
     return isinstance(dtype, str) and dtype == X3F
 
 
-def _pack_matrix(w2d, taps, device, dtype):
-    """fp32 (Cout, taps*Cin) K-major weight -> kernel operand: a cast, or for split-bf16 modules the
-    [w_hi | w_hi | w_lo]-per-tap form (ops.pack_x3_weight)."""
-    if _is_x3(dtype) or _is_x3f(dtype):
-        return ops.pack_x3_weight(w2d.reshape(w2d.shape[0], taps, -1)).to(device)
-    return w2d.contiguous().to(device=device, dtype=dtype)
+def _pack_matrix(w, device, dtype, cin_pad=None, scale=None, fold=False):
+    """reference weight - (Cout, Cin, KH, KW), or any K-major (Cout, K) matrix - -> kernel operand on `device`: the repack is
+    the library's (pgt_pack_conv_weight: K-major rows, channel padding, rounding to the compute type, the split-bf16 forms)"""
+    return ops.pack_conv_weight(w.detach().to(device=device, dtype=torch.float32), dtype, cin_pad=cin_pad, scale=scale, fold=fold)
 
 
 def _f32(t, device):
@@ -74,24 +72,20 @@ class Conv2d(nn.Conv2d, HipModule):
         self._bn_ref = ()  # (BatchNorm2d,) to fold; a tuple so it is not registered as a sub-module
 
     def _pack(self, device, dtype):
-        w = self.weight.detach().float()
-        b = self.bias.detach().float() if self.bias is not None else None
-        if self._bn_ref:
+        b = _f32(self.bias, device)
+        scale = None
+        if self._bn_ref:      # eval-mode BatchNorm2d folded into this conv (pgt_fold_batchnorm)
             bn = self._bn_ref[0]
-            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
-            w = w * s.view(-1, 1, 1, 1)
-            b0 = b if b is not None else torch.zeros_like(s)
-            b = (b0 - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
-        cout, cin, kh, kw = w.shape
-        if self.cin_pad is not None and self.cin_pad > cin:
-            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, self.cin_pad - cin))
-        self.pw = _pack_matrix(w.permute(0, 2, 3, 1).reshape(cout, -1), kh * kw, device, dtype)
-        self.pb = _f32(b, device)
+            scale, b = ops.fold_batchnorm(_f32(bn.weight, device), _f32(bn.bias, device), _f32(bn.running_mean, device),
+                                          _f32(bn.running_var, device), bn.eps, b)
+        cout, cin, kh, kw = self.weight.shape
+        cin_k = self._fold_cin = self.cin_pad if (self.cin_pad is not None and self.cin_pad > cin) else cin
+        self.pw = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale)
+        self.pb = b
         # split-bf16 layers with 64 output channels: the folded form fills the 128-column tile (pgt_conv_desc.x3_fold)
         self.pw_fold = None
-        cin_k = self._fold_cin = w.shape[1]
         if (_is_x3(dtype) or _is_x3f(dtype)) and cout == 64 and cin_k % 64 == 0 and USE_X3_FOLD:
-            self.pw_fold = ops.pack_x3_fold_weight(w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin_k)).to(device)
+            self.pw_fold = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale, fold=True)
 
     def run(self, x, **kw):
         fold = self.pw_fold is not None
@@ -112,7 +106,7 @@ class Conv2d(nn.Conv2d, HipModule):
 
 class Linear(nn.Linear, HipModule):
     def _pack(self, device, dtype):
-        self.pw = _pack_matrix(self.weight.detach().float(), 1, device, dtype)
+        self.pw = _pack_matrix(self.weight, device, dtype)
         self.pb = _f32(self.bias, device)
 
     def run(self, x, **kw):
@@ -205,7 +199,7 @@ class WindowAttention3D(HipModule):
 
     def _pack(self, device, dtype):
         # one fused (3C,C) projection [q | k | v]; dense per-head bias gathered once from the table
-        self.w_qkv = _pack_matrix(torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0).float(), 1, device, dtype)
+        self.w_qkv = _pack_matrix(torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0), device, dtype)
         if self.q.bias is not None:
             self.b_qkv = _f32(torch.cat([self.q.bias.detach(), self.kv.bias.detach()], 0), device)
         else:

@@ -82,6 +82,44 @@ def pack_x3_fold_weight(w3):
     return torch.cat([top, bot], 0).contiguous()
 
 
+def _dtype_code(dtype):
+    """model-side dtype tag -> (C-ABI dtype, torch storage dtype)"""
+    if isinstance(dtype, str):
+        assert dtype in (X3, X3F), dtype
+        return PGT_BF16X3, torch.bfloat16
+    return {torch.float32: PGT_F32, torch.bfloat16: PGT_BF16, torch.float16: hip.PGT_F16}[dtype], dtype
+
+
+def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
+    """Reference weight -> the conv / linear kernels' operand, on the device (pgt_pack_conv_weight).  w: fp32 device tensor
+    (Cout, Cin, KH, KW) (nn.Conv2d) or (Cout, Cin) (nn.Linear, or any K-major matrix); dtype: torch.float32 / bfloat16 /
+    float16, or X3 / X3F (split-bf16: [w_hi | w_hi | w_lo] per 64-channel block; fold=True: the 64-output-channel folded form);
+    cin_pad: zero-pad the input channels; scale: optional fp32 (Cout,) factor applied before rounding (BatchNorm fold)."""
+    assert w.dtype == torch.float32 and w.dim() in (2, 4)
+    w = w.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    cp = cin if cin_pad is None or cin_pad < cin else cin_pad
+    code, st = _dtype_code(dtype)
+    L = hip.lib()
+    nbytes = L.pgt_packed_weight_bytes(code, cout, cp, kh, kw, int(bool(fold)))
+    rows = 128 if fold else cout
+    out = torch.empty((rows, nbytes // (rows * torch.empty((), dtype=st).element_size())), device=w.device, dtype=st)
+    hip.check(L.pgt_pack_conv_weight(code, _p(w), cout, cin, kh, kw, cp, _p(scale), int(bool(fold)), _p(out), _stream()),
+              "pgt_pack_conv_weight")
+    return out
+
+
+def fold_batchnorm(gamma, beta, mean, var, eps, bias=None):
+    """eval-BatchNorm2d folded into the preceding conv: (scale, bias') fp32 (C,) on the device (pgt_fold_batchnorm)."""
+    c = gamma.numel()
+    scale = torch.empty((c,), dtype=torch.float32, device=gamma.device)
+    out = torch.empty((c,), dtype=torch.float32, device=gamma.device)
+    hip.check(hip.lib().pgt_fold_batchnorm(_p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(bias), c, _p(scale), _p(out), _stream()),
+              "pgt_fold_batchnorm")
+    return scale, out
+
+
 def to_x3(x, out=None):
     """fp32 (..., C) -> split-bf16 (..., 2C)."""
     assert x.dtype == torch.float32 and x.stride(-1) == 1

@@ -56,6 +56,33 @@ def _unpack_x3_weight(w, taps):
     return (w5[:, :, :, 0] + w5[:, :, :, 2]).reshape(cout, -1)
 
 
+def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
+    """torch restatement of pgt_pack_conv_weight (K-major rows, zero-padded input channels, optional per-channel factor)"""
+    w4 = w.float() if w.dim() == 4 else w.float()[:, :, None, None]
+    if scale is not None:
+        w4 = w4 * scale.float().view(-1, 1, 1, 1)
+    cout, cin, kh, kw = w4.shape
+    if cin_pad is not None and cin_pad > cin:
+        w4 = F.pad(w4, (0, 0, 0, 0, 0, cin_pad - cin))
+    k3 = w4.permute(0, 2, 3, 1).reshape(cout, kh * kw, -1)              # (Cout, taps, Cin_pad)
+    if isinstance(dtype, str):                                          # split-bf16
+        hi = k3.to(torch.bfloat16)
+        lo = (k3 - hi.float()).to(torch.bfloat16)
+        hi4, lo4 = hi.reshape(cout, kh * kw, -1, 1, 64), lo.reshape(cout, kh * kw, -1, 1, 64)
+        if fold:
+            top = torch.cat([hi4, hi4], 3).reshape(cout, -1)
+            bot = torch.cat([lo4, torch.zeros_like(lo4)], 3).reshape(cout, -1)
+            return torch.cat([top, bot], 0).contiguous()
+        return torch.cat([hi4, hi4, lo4], 3).reshape(cout, -1).contiguous()
+    return k3.reshape(cout, -1).to(dtype).contiguous()
+
+
+def fold_batchnorm(gamma, beta, mean, var, eps, bias=None):
+    s = gamma.float() / torch.sqrt(var.float() + eps)
+    b0 = bias.float() if bias is not None else torch.zeros_like(s)
+    return s, (b0 - mean.float()) * s + beta.float()
+
+
 def to_x3(x, out=None):
     return _store_x3(x.float(), out)
 
@@ -418,7 +445,7 @@ def frame_to_u8(x, out=None):
 ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "layernorm", "channel_stats",
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
-       "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
+       "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
        "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update"]
 
 

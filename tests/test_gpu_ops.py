@@ -647,6 +647,34 @@ def test_epilogue_statistics_linear_and_subpixel_and_x3(dtype):
     check("gn_x3_shift", b_e, b_w, torch.float32, 5.0)
 
 
+def test_weight_repack_behind_the_abi_matches_the_host_restatement():
+    """pgt_pack_conv_weight / pgt_fold_batchnorm (the repack a non-Python host needs after loading a reference checkpoint:
+    K-major rows, channel padding, BatchNorm fold, rounding, the split-bf16 forms) against the torch restatement: packed
+    operands bit for bit, the BatchNorm factors to one unit in the last place."""
+    O = ops()
+    w4 = rnd((72, 57, 3, 3), 950, torch.float32, 0.1)
+    sc = 1.0 + 0.2 * rnd((72,), 951)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        got = O.pack_conv_weight(g(w4), dt, cin_pad=64, scale=g(sc)).cpu()
+        want = E.pack_conv_weight(w4, dt, cin_pad=64, scale=sc)
+        assert got.dtype == want.dtype and torch.equal(got, want), dt
+    w2 = rnd((200, 136), 952, torch.float32, 0.1)                       # a Linear weight, no padding
+    assert torch.equal(O.pack_conv_weight(g(w2), torch.float16).cpu(), E.pack_conv_weight(w2, torch.float16))
+    wx = rnd((64, 128, 3, 3), 953, torch.float32, 0.05)
+    assert torch.equal(O.pack_conv_weight(g(wx), O.X3).cpu(), E.pack_conv_weight(wx, O.X3))
+    assert torch.equal(O.pack_conv_weight(g(wx), O.X3).cpu(), O.pack_x3_weight(wx.permute(0, 2, 3, 1).reshape(64, 9, 128)))
+    assert torch.equal(O.pack_conv_weight(g(wx), O.X3, fold=True).cpu(), O.pack_x3_fold_weight(wx.permute(0, 2, 3, 1).reshape(64, 9, 128)))
+    w57 = rnd((512, 57, 1, 1), 954, torch.float32, 0.1)                 # convpos: 57 -> 64 input channels, split-bf16
+    assert torch.equal(O.pack_conv_weight(g(w57), O.X3, cin_pad=64).cpu(), E.pack_conv_weight(w57, O.X3, cin_pad=64))
+    gam, bet, mu, var, b0 = 1 + 0.1 * rnd((72,), 955), 0.1 * rnd((72,), 956), 0.1 * rnd((72,), 957), rnd((72,), 958).abs() + 0.5, rnd((72,), 959)
+    s_g, b_g = O.fold_batchnorm(g(gam), g(bet), g(mu), g(var), 1e-5, g(b0))
+    s_w, b_w = E.fold_batchnorm(gam, bet, mu, var, 1e-5, b0)
+    ulp = lambda a, b: float(((a.cpu() - b).abs() / b.abs().clamp_min(1e-30)).max())   # noqa: E731  (device sqrt / divide: <= 1 ulp)
+    assert ulp(s_g, s_w) <= 2.4e-7 and float((b_g.cpu() - b_w).abs().max()) <= 5e-7, (ulp(s_g, s_w), float((b_g.cpu() - b_w).abs().max()))
+    s_g, b_g = O.fold_batchnorm(g(gam), g(bet), g(mu), g(var), 1e-5, None)
+    assert float((b_g.cpu() - E.fold_batchnorm(gam, bet, mu, var, 1e-5, None)[1]).abs().max()) <= 5e-7
+
+
 def test_statistics_epilogue_only_on_kernels_1_and_4():
     """Round 2 left a wrong-result variant (igemm5 with a statistics epilogue) reverted; it is gone: a conv pinned to kernel 5
     or 6 leaves NO epilogue statistics (the following GroupNorm takes its separate pass), and the C-ABI rejects the request."""

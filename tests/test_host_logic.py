@@ -19,7 +19,16 @@ def cpu_model(cfg, full_sd):
     m = PGTFormer(**cfg)
     missing = m.load_state_dict(full_sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
-    m.prepare("cpu", "fp32")
+    # the weight repack is a library call (pgt_pack_conv_weight): prepared here under its CPU emulation
+    import pgtformer_amd.ops as real
+    saved = {n: getattr(real, n) for n in ("pack_conv_weight", "fold_batchnorm")}
+    for n in saved:
+        setattr(real, n, getattr(emu_ops, n))
+    try:
+        m.prepare("cpu", "fp32")
+    finally:
+        for n, f in saved.items():
+            setattr(real, n, f)
     return m
 
 
@@ -92,11 +101,12 @@ def test_stage1_host_logic_matches_reference(cpu_model, golden_window, monkeypat
     assert np.abs(out[1, :, 192:320, 192:320].numpy() - g["stage1_out_mid_crop"]).max() < 5e-3
 
 
-def test_subpixel_upsample_matches_resize_then_conv():
+def test_subpixel_upsample_matches_resize_then_conv(monkeypatch):
     """Upsample in the bf16 modes runs four 2x2 sub-pixel convolutions with merged taps instead of nearest-x2 + conv3x3
     (reference: tdcrqvae3_arch.py:34-52): same result (checked in fp32 through the CPU emulation of the ops)."""
     import torch
     from pgtformer_amd.archs.tdcrqvae3_arch import Upsample
+    emu_ops.install(monkeypatch)
     torch.manual_seed(3)
     up = Upsample(16, True)
     x = torch.randn(2, 5, 7, 16)
