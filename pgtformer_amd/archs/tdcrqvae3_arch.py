@@ -504,6 +504,7 @@ class HubMixin:
         def init(self, *a, **k):
             if "_hub_config" not in self.__dict__:
                 bound = inspect.signature(orig).bind(self, *a, **k)
+                bound.apply_defaults()      # the reference's mixin stores defaulted constructor arguments too
                 cfg = {}
                 for name, val in list(bound.arguments.items())[1:]:
                     if inspect.signature(orig).parameters[name].kind is inspect.Parameter.VAR_KEYWORD:
@@ -557,7 +558,7 @@ class HubMixin:
 @ARCH_REGISTRY.register()
 class TDCRQVAE3(HubMixin, HipModule):
     """Stage-I temporal RQ-VAE (reference: :711-872). `prepare(device, precision)` must be called after
-    weights are loaded; precision in {"fp32", "bf16", "mixed"} ("mixed": encoder side fp32, decoder bf16)."""
+    weights are loaded (precision modes: see `prepare`)."""
 
     def __init__(self, *, embed_dim=64, n_embed=512, decay=0.99, loss_type="mse", latent_loss_weight=0.25,
                  bottleneck_type="rq", ddconfig=None, checkpointing=False, tf=3, **kwargs):
