@@ -37,7 +37,7 @@ template <> struct ElemIO<bf16_t> {
 struct half_t { _Float16 v; };
 typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ float sat_half(float f) { return __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f); }
+__device__ __forceinline__ float sat_half(float f) { return __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }   // one v_med3_f32
 __device__ __forceinline__ uint32_t f2h2(float lo, float hi) {   // {lo, hi} packed, round to nearest even, saturating
     const halfx2 v = {(_Float16)sat_half(lo), (_Float16)sat_half(hi)};
     return __builtin_bit_cast(uint32_t, v);

@@ -29,6 +29,9 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
     static_assert(SROWS * (BN / 8) % 512 == 0, "chunks per thread");
     float* stage = reinterpret_cast<float*>(smem);
     static_assert(!X3 || sizeof(T) == 2, "16-bit storage");
+    // half launches: the SFT operands are not prefetched - the second 32-register prefetch array pushed these
+    // instantiations over 256 VGPRs (scratch reloads inside the store loop: the K = 256 linears ran 25 % behind bf16)
+    constexpr bool kLateSft = !X3 && sizeof(T) == 2 && !__is_same(T, bf16_t);
     const T* res = reinterpret_cast<const T*>(p.res);
     const T* dec = reinterpret_cast<const T*>(p.dec);
     const T* shf = reinterpret_cast<const T*>(p.shift);
@@ -62,8 +65,10 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
                         pre1[c] = *reinterpret_cast<const uint4*>(res + (long)m * p.ldr + p.rlo + n);
                     }
                 } else if (p.epi == 1) {
-                    pre0[c] = *reinterpret_cast<const uint4*>(dec + (long)m * p.ld_dec + n);
-                    pre1[c] = *reinterpret_cast<const uint4*>(shf + (long)m * p.ld_shift + n);
+                    if constexpr (!kLateSft) {
+                        pre0[c] = *reinterpret_cast<const uint4*>(dec + (long)m * p.ld_dec + n);
+                        pre1[c] = *reinterpret_cast<const uint4*>(shf + (long)m * p.ld_shift + n);
+                    }
                 } else if (res) {
                     pre0[c] = *reinterpret_cast<const uint4*>(res + (long)m * p.ldr + n);
                 }
@@ -165,8 +170,13 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
                 }
             } else if (p.epi == 1) {
                 float d[8], sh[8];
-                Vec16<T>::unpack(pre0[c], d);
-                Vec16<T>::unpack(pre1[c], sh);
+                if constexpr (kLateSft) {   // (4 launches per forward: fetched where they are used, no second prefetch array)
+                    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(dec + (long)m * p.ld_dec + n), d);
+                    Vec16<T>::unpack(*reinterpret_cast<const uint4*>(shf + (long)m * p.ld_shift + n), sh);
+                } else {
+                    Vec16<T>::unpack(pre0[c], d);
+                    Vec16<T>::unpack(pre1[c], sh);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = d[e] + p.sft_w * (d[e] * v[e] + sh[e]);
             } else {

@@ -647,6 +647,29 @@ def test_epilogue_statistics_linear_and_subpixel_and_x3(dtype):
     check("gn_x3_shift", b_e, b_w, torch.float32, 5.0)
 
 
+def test_half_stores_saturate_instead_of_overflowing():
+    """PGT_F16: every fp32 -> half store clamps to +-65504 (a value out of half range must not become inf and then NaN
+    downstream); in-range values are rounded to nearest even as torch rounds them."""
+    O = ops()
+    x = torch.full((1, 8, 8, 64), 200.0, dtype=torch.float16)
+    w = torch.full((64, 64), 100.0, dtype=torch.float16)                      # 64 * 200 * 100 = 1.28e6 > 65504
+    y = O.conv2d(g(x), g(w), None).float().cpu()
+    assert torch.isfinite(y).all() and float(y.min()) == 65504.0
+    y = O.conv2d(g(x), g(-w), None).float().cpu()
+    assert float(y.max()) == -65504.0
+    big = torch.tensor([[1e6, -1e6, 70000.0, 65504.0, 65519.9, 1.00048828125, 3.1415927]], dtype=torch.float32).repeat(4, 1)
+    got = O.cast(g(F_pad8(big)), torch.float16).float().cpu()[:, :7]
+    want = big.clamp(-65504.0, 65504.0).to(torch.float16).float()
+    assert torch.equal(got, want), (got[0], want[0])
+    sc, sh = g(torch.full((1, 64), 1000.0)), g(torch.zeros(1, 64))
+    z = O.affine_act(g(x), sc, sh).float().cpu()                               # 200 * 1000 = 2e5
+    assert torch.isfinite(z).all() and float(z.max()) == 65504.0
+
+
+def F_pad8(t):
+    return torch.nn.functional.pad(t, (0, 8 - t.shape[1] % 8 if t.shape[1] % 8 else 0)).contiguous()
+
+
 def test_weight_repack_behind_the_abi_matches_the_host_restatement():
     """pgt_pack_conv_weight / pgt_fold_batchnorm (the repack a non-Python host needs after loading a reference checkpoint:
     K-major rows, channel padding, BatchNorm fold, rounding, the split-bf16 forms) against the torch restatement: packed
