@@ -216,6 +216,13 @@ int pgt_x3_to_half(const void* src, int32_t lds, int32_t src_lo, void* dst, int3
 int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float* dst, int32_t ldd, int64_t rows,
                  int32_t cols, pgt_stream_t stream);
 
+/* One categorical draw per row of a (rows, K) probability matrix by inverse CDF: codes[r] = first j with
+ * prob[r,0] + .. + prob[r,j] > u[r] * sum_j prob[r,j], u[r] uniform in [0, 1) supplied by the caller (the stochastic branch of
+ * RQBottleneck.get_soft_codes: torch.multinomial(soft_code, 1), archs/tdcrqvae3_arch.py:443-446 - the same distribution,
+ * the caller's random stream). */
+int pgt_sample_rows(const float* prob, int32_t ld, int32_t rows, int32_t K, const float* u, int32_t* codes,
+                    pgt_stream_t stream);
+
 /* ---- weight repack (once, at load) --------------------------------------------------------------
  * The conv / linear kernels take their weights K-major; the reference stores nn.Conv2d weights as (Cout, Cin, KH, KW) and
  * nn.Linear weights as (Cout, Cin) (= KH = KW = 1).  pgt_pack_conv_weight writes the operand `pgt_conv2d` expects for

@@ -249,10 +249,11 @@ class RQBottleneck(HipModule):
         quants = ops.straight_through(x2, agg)
         return quants.reshape(b, h, w, d), loss, torch.stack(codes, -1).reshape(b, h, w, depth)
 
-    def get_soft_codes(self, x, temp=1.0, stochastic=False):
-        """soft codes softmax(-dist / temp) (B,h,w,d,K) fp32 and hard codes (B,h,w,d) (reference :429-457)."""
-        if stochastic:
-            raise NotImplementedError("stochastic code sampling (torch.multinomial) is a training / sampling-side feature")
+    def get_soft_codes(self, x, temp=1.0, stochastic=False, generator=None):
+        """soft codes softmax(-dist / temp) (B,h,w,d,K) fp32 and hard codes (B,h,w,d) (reference :429-457).  stochastic: the
+        codes are drawn from the soft codes (the reference's torch.multinomial(soft_code, 1), :443-446) - one categorical
+        draw per token by inverse CDF with uniforms from `generator` (a device torch.Generator, or None: the default one);
+        same distribution, this build's random stream.  The residual carries the DRAWN code's embedding, as the reference's."""
         b, h, w, d = x.shape
         depth = self.code_shape[-1]
         rows = b * h * w
@@ -262,6 +263,9 @@ class RQBottleneck(HipModule):
             book = self.codebooks[i]
             dot, xn = book.distances_dot(resid)
             soft, c = ops.rq_soft_codes(dot, xn, book.enorm, temp)
+            if stochastic:
+                u = torch.rand((rows,), device=soft.device, dtype=torch.float32, generator=generator)
+                c = ops.sample_rows(soft, u)
             if i + 1 < depth:
                 scratch = torch.empty_like(resid)
                 ops.embed_rows(book.book, c, x.dtype, out=scratch, resid=resid)
@@ -660,8 +664,8 @@ class TDCRQVAE3(HubMixin, HipModule):
         return self.get_codes(xs.reshape(b * t, c, h, w))
 
     @torch.no_grad()
-    def get_soft_codes(self, xs, temp=1.0, stochastic=False):
-        soft, code = self.quantizer.get_soft_codes(self.encode(xs), temp=temp, stochastic=stochastic)
+    def get_soft_codes(self, xs, temp=1.0, stochastic=False, generator=None):
+        soft, code = self.quantizer.get_soft_codes(self.encode(xs), temp=temp, stochastic=stochastic, generator=generator)
         return soft, code.long()
 
     @torch.no_grad()

@@ -352,6 +352,43 @@ __global__ __launch_bounds__(256) void rq_soft_codes_kernel(const float* __restr
     if (lane == 0) codes[row] = bi;
 }
 
+// One categorical draw per row by inverse CDF (what torch.multinomial(prob, 1) samples, reference
+// archs/tdcrqvae3_arch.py:443-446): codes[r] = the first j with prob[r, 0] + ... + prob[r, j] > u[r] * sum(prob[r, :]).
+// One wavefront per row; lane l owns the contiguous slice [l*per, (l+1)*per): slice sums, an exclusive scan over the lanes
+// (fixed order), then the owning lane walks its slice.  Deterministic for a given u.
+__global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restrict__ prob, int ld, int rows, int K,
+                                                          const float* __restrict__ u, int* __restrict__ codes) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = prob + (long)row * ld;
+    const int per = (K + 63) / 64;
+    const int j0 = lane * per, j1 = min(K, j0 + per);
+    float mine = 0.f;
+    for (int j = j0; j < j1; ++j) mine += pr[j];
+    float incl = mine;                                     // inclusive scan over lanes (Hillis-Steele, fixed order)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const float total = __shfl(incl, 63, 64);
+    const float target = u[row] * total;
+    const float excl = incl - mine;
+    // the owning lane: the first one whose inclusive sum exceeds the target (the last non-empty lane if rounding leaves none)
+    const unsigned long long hit = __ballot(incl > target && j0 < K);
+    const int owner = hit ? __ffsll((long long)hit) - 1 : min(63, (K - 1) / per);
+    if (lane == owner) {
+        float c = excl;
+        int pick = j1 - 1;
+        for (int j = j0; j < j1; ++j) {
+            c += pr[j];
+            if (c > target) { pick = j; break; }
+        }
+        codes[row] = pick;
+    }
+}
+
 // zero a (rows, row_bytes) byte matrix with row stride ldd bytes (16-byte granules): pad channels of concat buffers
 __global__ void zero2d_kernel(char* __restrict__ dst, long ldd, long rows, int chunks) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -653,6 +690,14 @@ extern "C" int pgt_rq_soft_codes(const float* dot, int32_t ld, const float* xnor
     PGT_CHECK(dot && xnorm && enorm && soft && codes && K > 0 && temp > 0.f, "rq_soft_codes: bad argument");
     hipLaunchKernelGGL(rq_soft_codes_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dot, ld, xnorm, enorm,
                        rows, K, 1.0f / temp, soft, codes);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_sample_rows(const float* prob, int32_t ld, int32_t rows, int32_t K, const float* u, int32_t* codes,
+                               pgt_stream_t stream) {
+    PGT_CHECK(prob && u && codes && K > 0 && ld >= K, "sample_rows: bad argument");
+    hipLaunchKernelGGL(sample_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, prob, ld, rows, K, u, codes);
     PGT_LAUNCH_CHECK();
     return 0;
 }

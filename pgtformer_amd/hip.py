@@ -53,6 +53,7 @@ SIGNATURES = {
     "pgt_x3_split": [vp, i32, vp, i32, i32, i64, i32, vp],
     "pgt_x3_merge": [vp, i32, i32, vp, i32, i64, i32, vp],
     "pgt_x3_to_half": [vp, i32, i32, vp, i32, i64, i32, vp],
+    "pgt_sample_rows": [vp, i32, i32, i32, vp, vp, vp],
     "pgt_packed_weight_bytes": [i32, i32, i32, i32, i32, i32],
     "pgt_pack_conv_weight": [i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp],
     "pgt_fold_batchnorm": [vp, vp, vp, vp, f32, vp, i32, vp, vp, vp],

@@ -662,6 +662,15 @@ def rq_soft_codes(dot, xnorm, enorm, temp=1.0):
     return soft, codes
 
 
+def sample_rows(prob, u):
+    """one categorical draw per row of prob (rows, K) fp32 by inverse CDF with the caller's uniforms u (rows,) in [0, 1)"""
+    rows, k = prob.shape
+    assert prob.dtype == torch.float32 and u.dtype == torch.float32 and u.numel() == rows and u.is_contiguous()
+    codes = torch.empty((rows,), dtype=torch.int32, device=prob.device)
+    hip.check(hip.lib().pgt_sample_rows(_p(prob), _ld_rows(prob), rows, k, _p(u), _p(codes), _stream()), "pgt_sample_rows")
+    return codes
+
+
 def commit_loss(x, q, out=None, scale=1.0):
     """out[0] (+)= scale * mean((x - q)^2) over two (rows, C) matrices; out: fp32 device scalar (1,) (None: new, overwritten)."""
     rows, c = x.shape

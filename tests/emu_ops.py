@@ -335,6 +335,12 @@ def rq_soft_codes(dot, xnorm, enorm, temp=1.0):
     return F.softmax(-dist / temp, dim=-1), dist.argmin(-1).to(torch.int32)
 
 
+def sample_rows(prob, u):
+    c = prob.float().cumsum(-1)
+    t = (u.float() * c[:, -1]).unsqueeze(1)
+    return (c > t).float().argmax(-1).to(torch.int32)
+
+
 def commit_loss(x, q, out=None, scale=1.0):
     v = scale * (x.float() - q.float()).pow(2.0).mean().reshape(1)
     return v if out is None else out + v
@@ -445,7 +451,7 @@ def frame_to_u8(x, out=None):
 ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "layernorm", "channel_stats",
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
-       "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
+       "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "sample_rows", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
        "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update"]
 
 

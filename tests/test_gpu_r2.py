@@ -169,8 +169,45 @@ def test_stage1_api_matches_reference_golden(gold, cfg, full_sd, golden_window):
     assert rec["forward_loss_vs_full_golden"] <= 1e-4 * max(1e-6, float(full["stage1_loss"][0]))
     assert rec["z_q_err"] <= 1e-4 and rec["soft_err"] <= 1e-4 and rec["soft_max_err"] <= 1e-4
     assert rec["decode_code_err"] <= 2e-3 and rec["forward_out_err"] <= 2e-3
-    with pytest.raises(NotImplementedError):
-        TDCRQVAE3.get_soft_codes(m, xd, stochastic=True)
+    # stochastic soft codes (reference: torch.multinomial(soft_code, 1), :443-446): same soft codes, codes drawn from them -
+    # reproducible for a seeded generator, and at temp -> 0 the draw collapses onto the nearest code
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(7)
+    soft_s, code_a = TDCRQVAE3.get_soft_codes(m, xd, temp=0.5, stochastic=True, generator=gen)
+    gen.manual_seed(7)
+    _, code_b = TDCRQVAE3.get_soft_codes(m, xd, temp=0.5, stochastic=True, generator=gen)
+    assert torch.equal(soft_s, soft) and torch.equal(code_a, code_b) and code_a.shape == scode.shape
+    p_drawn = soft_s.reshape(-1, 1024).gather(1, code_a.reshape(-1, 1)).reshape(-1)
+    assert float(p_drawn.min()) > 0.0
+    _, code_cold = TDCRQVAE3.get_soft_codes(m, xd, temp=1e-4, stochastic=True, generator=gen)
+    assert np.array_equal(code_cold.cpu().numpy().astype(np.int16), ref_codes)
+
+
+def test_sample_rows_is_an_inverse_cdf_draw():
+    """pgt_sample_rows: the drawn index brackets u * total in the cumulative sums, ties and zero-probability entries are
+    never drawn, and the empirical frequencies follow the probabilities."""
+    from tests import emu_ops as E
+    from pgtformer_amd import ops as O
+
+    g_ = torch.Generator().manual_seed(3)
+    prob = torch.rand((4096, 1024), generator=g_) ** 8
+    prob[:, 100:200] = 0.0
+    prob = prob / prob.sum(-1, keepdim=True)
+    u = torch.rand((4096,), generator=g_)
+    got = O.sample_rows(prob.to(DEV), u.to(DEV)).cpu().long()
+    c = prob.double().cumsum(-1)
+    t = u.double() * c[:, -1]
+    lo = torch.where(got > 0, c.gather(1, (got - 1).clamp_min(0).unsqueeze(1)).squeeze(1), torch.zeros_like(t))
+    hi = c.gather(1, got.unsqueeze(1)).squeeze(1)
+    assert bool(((lo <= t + 1e-6) & (hi >= t - 1e-6)).all())
+    assert not bool(((got >= 100) & (got < 200)).any())
+    assert float((got == E.sample_rows(prob, u).long()).float().mean()) > 0.995       # differs only by fp32 summation order
+    one = torch.tensor([0.5, 0.25, 0.125, 0.125] + [0.0] * 60).repeat(20000, 1)
+    d = O.sample_rows(one.to(DEV), torch.rand((20000,), generator=g_).to(DEV)).cpu()
+    f = torch.bincount(d.long(), minlength=64).float() / 20000
+    assert float((f[:4] - one[0, :4]).abs().max()) < 0.012 and float(f[4:].sum()) == 0.0
+    edge = O.sample_rows(one[:2].to(DEV), torch.tensor([0.0, 0.99999994]).to(DEV)).cpu().tolist()
+    assert edge == [0, 3]
 
 
 def test_stage1_bf16x3_codes_match_reference(gold, cfg, full_sd, golden_window):
