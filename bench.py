@@ -215,7 +215,7 @@ def _physical_cores():
         return os.cpu_count()
 
 
-def cpu_baseline(cfg, sd, window_u8, budget_s=30.0, threads=0):
+def cpu_baseline(cfg, sd, window_u8, budget_s=40.0, threads=0):
     """The oracle (a port of the reference's fp32 eager CPU path) timed on this host as SURVEY 8(d) prescribes: threads =
     physical cores, 2 warm-up windows, then the median of up to 5 timed windows - bounded by `budget_s` of CPU work
     (slow hosts get fewer timed windows; the count is reported)."""

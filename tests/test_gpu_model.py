@@ -271,6 +271,37 @@ def test_psnr_contract_at_the_operating_point(tail_models, tag):
             assert rec["psnr_build_vs_ref_unclamped_db"] >= 50.0, rec
 
 
+def test_psnr_contract_on_the_benchmarked_path(tail_models):
+    """The path bench.py times - unique uint8 frames in, overlap-aware windows (per-frame work once per frame), middle-only
+    decoder tail, several windows per forward - at the operating point: the clip's windows w1 and w2 in ONE forward, each
+    restored middle frame against the reference's (fp32 rows of r3_golden.npz): |dPSNR vs GT| <= 1e-3 dB, unclamped
+    PSNR(build, reference) >= 70 dB, and the driver's uint8 frames within +-1 of the reference's."""
+    from pgtformer_amd.driver import WindowRunner
+    from pgtformer_amd.synth import make_clip
+
+    g = np.load(os.path.join(GOLD, "r3_golden.npz"))
+    lq_u8, gt = make_clip(4, 512, seed=1234)
+    m = tail_models["x3f16"]
+    frames = torch.from_numpy(lq_u8).to(DEV)
+    out, _, _ = m.forward_nhwc(frames, w=1.0, win=m.window_index(2, 3, DEV), middle_only=True)     # (2,512,512,3) fp32
+    assert out.shape == (2, 512, 512, 3) and out.dtype == torch.float32
+    out = out.cpu()
+    runner = WindowRunner(m, 1.0, use_graph=True, batch=2, lanes=2)
+    padded = torch.cat([frames[:1], frames, frames[-1:]], 0)             # replicate-padded clip: outputs 0..3, windows 1, 2 inside
+    u8 = runner.run_clip(padded, torch.empty_like(frames)).cpu()
+    for j, tag in ((0, "w1"), (1, "w2")):
+        rows = out[j].permute(2, 0, 1)[:, ::8, :].double()
+        ref = torch.from_numpy(g[f"{tag}.out_mid_rows"]).double()
+        gt_rows = torch.from_numpy(gt[j + 1]).permute(2, 0, 1)[:, ::8, :].double()
+        rec = {"dpsnr_db": psnr(rows, gt_rows) - psnr(ref, gt_rows), "psnr_build_vs_ref_unclamped_db": psnr(rows, ref)}
+        ref_u8 = (ref.float().clamp(0, 1) * 255).to(torch.uint8).permute(1, 2, 0)
+        du = (u8[j + 1][::8].int() - ref_u8.int()).abs()
+        rec.update(u8_max_diff=int(du.max()), u8_equal_fraction=float((du == 0).float().mean()))
+        _LOG[f"operating_point_benchmarked_path/{tag}/x3f16"] = rec
+        assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_build_vs_ref_unclamped_db"] >= 70.0, rec
+        assert rec["u8_max_diff"] <= 1 and rec["u8_equal_fraction"] >= 0.97, rec
+
+
 def test_whole_model_pure_bf16_report(models, golden_window):
     """Pure bf16 (opt-in speed mode) is reported, not a parity mode: with random-init weights ~2 % of the codes flip."""
     g = np.load(os.path.join(GOLD, "full_golden.npz"))
