@@ -71,9 +71,10 @@ def parse():
 
 
 def _lib_sha16():
-    import hashlib
-    from pgtformer_amd import hip
-    return hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()[:16]
+    """identity of the kernel build: sha256 over the HIP sources and headers libpgt_hip.so is compiled from (stable across
+    rebuilds of the same sources, unlike the bytes of the .so)"""
+    from tools.pmc_traffic import source_sha16
+    return source_sha16()
 
 
 def live_roofline(runner, frames, precision, nwin):

@@ -5,8 +5,8 @@
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/write -o r -- python bench.py --steps 2 --warmup 1 --no-graph ...
   python tools/pmc_traffic.py out/fetch/r_results.db out/write/r_results.db profiles/r3_igemm_traffic_pmc.json [precision B]
 
-`precision`, `B` (windows per forward) of the profiled command and the sha256 of the library build it ran are stored in the
-file: bench.py quotes the measurement as `roofline.traffic` only for the matching configuration AND the same libpgt_hip.so.
+`precision`, `B` (windows per forward) of the profiled command and a sha256 over the kernel sources it ran are stored in the
+file: bench.py quotes the measurement as `roofline.traffic` only for the matching configuration AND the same kernel sources.
 Besides the conv / linear family the file carries the WHOLE forward: HBM bytes of every kernel, per forward and per window
 (forwards counted from the trace: argmax_rows_kernel runs once per forward).
 
@@ -19,6 +19,20 @@ import sys
 
 
 FAMILY = ("%igemm%_kernel%", "%conv3x3_c64_kernel%")   # the conv / linear kernels of csrc/igemm*.hip
+
+
+def source_sha16():
+    """sha256 (first 16 hex digits) over the sources libpgt_hip.so is built from: csrc/*.{hip,cpp,h} and include/*.h"""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for d in (os.path.join(root, "pgtformer_amd", "csrc"), os.path.join(root, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".cpp", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(db, counter, likes):
@@ -54,10 +68,7 @@ def main(fetch_db, write_db, out, precision=None, windows_per_forward=None):
         res["precision"] = precision
         res["windows_per_forward"] = int(windows_per_forward)
         res["whole_forward"]["hbm_gb_per_window"] = res["whole_forward"]["hbm_bytes_per_forward"] / int(windows_per_forward) / 1e9
-    import hashlib
-    import os
-    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgtformer_amd", "lib", "libpgt_hip.so")
-    res["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    res["lib_sha16"] = source_sha16()      # of the kernel sources this measurement ran (bench.py refuses another build's file)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
