@@ -506,6 +506,13 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         PGT_CHECK(!residual || p.res_f32 || (d->ldr >= p.rlo + d->Cout && p.rlo % 8 == 0), "pgt_conv2d: bf16x3 residual planes");
         PGT_CHECK(!residual || !p.res_f32 || d->ldr % 4 == 0, "pgt_conv2d: fp32 residual rows must be 16-byte aligned");
         PGT_CHECK(p.vec_epi && (long)d->Cout * p.K * 2 < (1L << 31), "pgt_conv2d: bf16x3 needs Cout %% 8 == 0, 16-byte aligned rows and weights < 2 GiB");
+        // the 64-input-channel 3x3 layers of the full-resolution levels: weights in registers, no operand streaming (kernel 6)
+        auto p2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+        const bool v6x = d->Cin == 64 && d->Cout <= 64 && d->Cout % 16 == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
+                         d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H && d->Wo == d->W && p2(d->W) && p2(d->H) && d->W >= 32 &&
+                         d->H * d->W >= 64 && !d->x3_fold && d->epi == 0 && d->gn_groups == 0 && d->orow_mul == 0 && d->ldx % 8 == 0;
+        PGT_CHECK(d->kernel != 6 || v6x, "pgt_conv2d: kernel=6 with bf16x3 needs a 3x3 stride-1 same-size conv, Cin == 64, Cout %% 16 == 0 (<= 64), power-of-two maps, split output");
+        if (v6x && (d->kernel == 0 || d->kernel == 6) && d->force_bn == 0) return pgt_igemm6x3_launch(&p, st);
         const int rc = pgt_igemm4_launch(&p, d->x3_fold ? 128 : (d->force_bn ? d->force_bn : (d->Cout <= 128 ? 128 : 256)), st);
         PGT_CHECK(rc != 1, "pgt_conv2d: bf16x3 has no %d-column tile (128, 256)", d->force_bn);
         return rc;

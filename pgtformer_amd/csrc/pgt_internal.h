@@ -25,3 +25,5 @@ int pgt_igemm4_launch(const void* conv_p, int bn, hipStream_t st);
 int pgt_igemm5_launch(const void* conv_p, hipStream_t st);
 // igemm6.hip: 3x3, Cin == 64, Cout <= 64: weights in registers, persistent workgroups, one halo image per filter row
 int pgt_igemm6_launch(const void* conv_p, hipStream_t st);
+// igemm6x3.hip: the same layers on split-bf16 operands (Cout % 16 == 0): hi / lo weights in registers, MFMA 16x16x32, three products
+int pgt_igemm6x3_launch(const void* conv_p, hipStream_t st);

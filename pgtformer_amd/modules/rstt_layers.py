@@ -20,6 +20,7 @@ from .. import ops
 from ..ops import ACT_GELU, ACT_NONE, ACT_SILU, X3, X3F
 
 USE_X3_FOLD = os.environ.get("PGT_X3_FOLD", "1") != "0"   # A/B switch of the folded 64-channel split-bf16 convs
+USE_X3_C64 = os.environ.get("PGT_X3_C64", "1") != "0"     # A/B switch of the register-weight split-bf16 3x3 kernel (igemm6x3.hip)
 
 
 class HipModule(nn.Module):
@@ -89,6 +90,10 @@ class Conv2d(nn.Conv2d, HipModule):
 
     def run(self, x, **kw):
         fold = self.pw_fold is not None
+        if (fold and USE_X3_C64 and (_is_x3(self.dt) or _is_x3f(self.dt)) and self._fold_cin == 64 and self.kernel_size == (3, 3) and self.stride == (1, 1)
+                and self.pad4 == (1, 1, 1, 1) and x.shape[2] >= 32 and not (x.shape[1] & (x.shape[1] - 1)) and not (x.shape[2] & (x.shape[2] - 1))):
+            fold = False      # the register-weight kernel of these layers takes the standard split matrix (igemm6x3.hip)
+            kw = {k: v for k, v in kw.items() if k != "gn"}     # (no epilogue statistics on these layers: ops.gn_ok)
         if fold and kw.get("gn") is not None:
             if self._fold_cin == 64 and self.kernel_size[0] == 3:
                 kw = {k: v for k, v in kw.items() if k != "gn"}     # these layers leave no epilogue statistics (ops.gn_ok)
