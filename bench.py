@@ -133,6 +133,8 @@ def live_roofline(runner, frames, precision, nwin):
                "only the GroupNorms whose statistics do not come out of the producing conv's epilogue"),
         family("fp32 <-> split-bf16 / half conversions", lambda r: r["kernel"] == "x3_convert", "hbm"),
         family("gathers / copies / pad zeroing", lambda r: r["kernel"] == "copy_gather", "hbm"),
+        family("weight-rounding compensation (sampled channel means + per-frame bias)", lambda r: r["kernel"] == "mean_field", "hbm",
+               "small launches: 4096 sampled pixels per frame, a (K x Cout) matrix-vector product per frame"),
     ]
     kernels = [k for k in kernels if k]
     ig = [r for r in recs if conv(r)]

@@ -101,6 +101,10 @@ typedef struct pgt_conv_desc {
                                  * (the standard form leaves half of the tile idle for three segments).                  */
     int32_t dec_lo, shift_lo;   /* PGT_BF16X3 with PGT_EPI_SFT: element offsets of the lo planes of sft_dec / sft_shift
                                  * (0 = Cout): out = dec + sft_w * (dec * act(conv) + shift) on split operands       */
+    int32_t bias_rows;          /* 0: `bias` holds Cout values.  > 0: `bias` is a (N*Ho*Wo / bias_rows, Cout) fp32 matrix, one
+                                 * vector per bias_rows consecutive output pixels - a bias per frame (bias_rows = Ho*Wo; for
+                                 * token rows: tokens per frame), the form pgt_mean_field_bias produces.  A multiple of 512
+                                 * that divides N*Ho*Wo; single-plane dtypes; kernels 0, 1, 4, 5, 6.                       */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -148,6 +152,19 @@ int pgt_layernorm(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32
 /* per-(n,c) mean and UNBIASED variance over HW pixels (calc_mean_std, codeformer_arch.py:15-29) */
 int pgt_channel_stats(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C,
                       float* mean, float* var_unbiased, pgt_stream_t stream);
+/* ---- mean-field compensation of the weight rounding of a 16-bit layer (no reference counterpart: the reference's layers are
+ * fp32, modules/rstt_layers.py:875-904, archs/pgtformer_arch.py:460-484; this keeps a half / bf16 layer's output unbiased).
+ * y = W x + b with W rounded to W16 leaves (W - W16) x; the part of it that is constant over a frame, (W - W16) mean(x), is
+ * put back as a per-frame bias (pgt_conv_desc::bias_rows):  out[r][o] = bias[o] + sum_k defect_t[k][o] * mean[r][k],
+ * defect_t[k][o] = sum over filter taps of (W - W16)[o][k][tap] (fp32, K x Cout).
+ * pgt_sampled_channel_mean: mean[n][c] of x (N, HW, C; pixel stride ldx) over a fixed sample of min(HW, 1024) pixels of each
+ * frame: 16 consecutive pixels from each of up to 64 equal cells (K <= 3840 in pgt_mean_field_bias); pgt_sampled_pixel(HW, i) = the i-th sampled pixel index
+ * (-1 past the end) so that a host can reproduce the sample. */
+int pgt_sampled_channel_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C, float* mean,
+                             pgt_stream_t stream);
+int pgt_sampled_pixel(int32_t HW, int32_t i);
+int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* bias, int32_t R, int32_t K, int32_t Cout,
+                        float* out, pgt_stream_t stream);
 /* AdaIN coefficients: scale = sqrt(var_s+eps)/sqrt(var_c+eps), shift = mean_s - mean_c*scale
  * (adaptive_instance_normalization, codeformer_arch.py:32-46); n = N*C entries */
 int pgt_adain_affine(const float* mean_c, const float* var_c, const float* mean_s, const float* var_s,

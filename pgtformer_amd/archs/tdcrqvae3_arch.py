@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _is_x3, _pack_matrix, prepare_tree)
+from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _defect_t, _is_x3, _pack_matrix,
+                                    _wants_wcomp, prepare_tree)
 from ..ops import ACT_SILU, X3
 from ..config import DEFAULT_PRECISION
 from ..registry import ARCH_REGISTRY
@@ -42,12 +43,13 @@ class Upsample(HipModule):
         if dtype == torch.float32:
             return
         w = self.conv.weight.detach().float()                       # (Cout, Cin, 3, 3)
-        self.sub_w = {}
+        self.sub_w, self.sub_def = {}, {}
         for py in (0, 1):
             for px in (0, 1):
                 w2 = torch.stack([torch.stack([sum(w[:, :, ky, kx] for ky in self._ROWS[py][a] for kx in self._ROWS[px][b])
                                                for b in (0, 1)], -1) for a in (0, 1)], -2)      # (Cout, Cin, 2, 2)
                 self.sub_w[(py, px)] = _pack_matrix(w2, device, dtype)
+                self.sub_def[(py, px)] = _defect_t(w2, self.sub_w[(py, px)]) if _wants_wcomp(dtype) else None
 
     def forward(self, x):
         if self.sub_w is None:
@@ -57,8 +59,10 @@ class Upsample(HipModule):
         out = torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=x.dtype)
         # a TDResnetBlock's GroupNorm follows: the four launches share one statistics workspace (4 sub-ranges)
         st = ops.GnStats(n, 4, h * w, cout, 32, x.device) if (ops.USE_EPILOGUE_GN and ops.gn_ok(n, h * w, cout)) else None
+        mean = ops.sampled_channel_mean(x) if (self.sub_def[(0, 0)] is not None and (h * w) % 512 == 0) else None
         for i, ((py, px), w2) in enumerate(self.sub_w.items()):
-            ops.conv2d(x, w2, self.conv.pb, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, out_parity=(py, px),
+            b = self.conv.pb if mean is None else ops.mean_field_bias(mean, self.sub_def[(py, px)], self.conv.pb)
+            ops.conv2d(x, w2, b, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, out_parity=(py, px),
                        gn=None if st is None else (st, i))
         return out if st is None else st.bind(out, cout)
 

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
                 for (int j = 0; j < NI; ++j) {
                     const int cl = wn * (BN / 2) + j * 32 + (lane & 31);
                     const int n = n0 + cl;
-                    const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+                    const float bv = (p.bias && n < p.Cout) ? bias_of(p, m0)[n] : 0.f;
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
         if (n >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float bv = p.bias ? bias_of(p, m0)[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(ConvP p, const flo
         for (int e = 0; e < 8; ++e) v[e] += t[e];
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + (p.bias ? p.bias[n + e] : 0.f), p.act);
+    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + (p.bias ? bias_of(p, m)[n + e] : 0.f), p.act);
     if (p.epi == 1) {
         float d[8], sh[8];
         load8<T>(reinterpret_cast<const T*>(p.dec) + (long)m * p.ld_dec + n, d);
@@ -476,6 +476,10 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.dlo = d->dec_lo ? d->dec_lo : d->Cout;
     p.slo = d->shift_lo ? d->shift_lo : d->Cout;
     p.nw = (x3 && d->x3_fold) ? 128 : d->Cout;
+    p.bias_rows = d->bias_rows;
+    PGT_CHECK(d->bias_rows == 0 || (bias && d->bias_rows > 0 && d->bias_rows % 512 == 0 && p.M % d->bias_rows == 0 && !x3 &&
+                                    d->kernel != 2 && d->kernel != 3),
+              "pgt_conv2d: bias_rows=%d (a bias vector per frame) needs a bias, a multiple of 512 rows that divides M=%d, a single-plane dtype and kernel 0, 1, 4, 5 or 6", d->bias_rows, p.M);
     PGT_CHECK(!d->x3_fold || (x3 && d->Cout == 64 && d->gn_groups == 0), "pgt_conv2d: x3_fold is the 64-output-channel form of dtype PGT_BF16X3 (no statistics epilogue)");
     p.res_f32 = (x3 && d->res_f32) ? 1 : 0;
     PGT_CHECK(!d->res_f32 || (x3 && d->out_f32), "pgt_conv2d: res_f32 goes with dtype PGT_BF16X3 and out_f32");

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
                 wreg[t][ks] = v;
             }
     }
-    const float bv = (p.bias && wc * 32 + (lane & 31) < p.Cout) ? p.bias[wc * 32 + (lane & 31)] : 0.f;
+    const bool has_bias = p.bias && wc * 32 + (lane & 31) < p.Cout;
 
     const int S = p.W < 128 ? p.W : 128;
     const int s_shift = p.W < 128 ? p.wo_shift : 7;
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvP p, int ntiles
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * 128;
+        const float bv = has_bias ? bias_of(p, m0)[wc * 32 + (lane & 31)] : 0.f;   // (per frame with bias_rows)
         __syncthreads();   // the previous tile's epilogue has left the LDS
         // ---- the three images: piece q = wave + 4 i (i < 5) of image ky = rows 8q + (lane >> 3), chunk lane & 7
 #pragma unroll 1

@@ -48,6 +48,7 @@ struct ConvP {
     int res_f32;                // x3 with fp32 output: the residual is fp32 too (ldr counts floats)
     int f16;                    // 16-bit operands are IEEE half (PGT_F16) instead of bf16
     int dlo, slo;               // x3 with the SFT epilogue: element offsets of the lo planes of dec / shift
+    int bias_rows;              // > 0: bias is a (M / bias_rows, Cout) matrix - one vector per bias_rows consecutive output pixels (a frame)
     int nw;                     // rows of the weight matrix = GEMM columns (Cout; 128 for the folded 64-channel x3 form, x3 == 2)
     // GroupNorm statistics of the OUTPUT from the epilogue (gn_part != nullptr): every workgroup tile writes the sum and
     // sum of squares of its outputs per channel group to gn_part[((img * gn_maxblk + k) * gn_G + g) * 2 + {0, 1}], k = the
@@ -57,6 +58,12 @@ struct ConvP {
     float* gn_hdr;
     int gn_cpg, gn_G, gn_maxblk, gn_hw;
 };
+
+// bias vector of output pixel m: shared, or the one of m's frame (pgt_conv_desc::bias_rows; a workgroup tile never straddles
+// two frames: bias_rows is a multiple of 512 rows)
+__device__ __forceinline__ const float* bias_of(const ConvP& p, int m) {
+    return p.bias_rows ? p.bias + (long)(m / p.bias_rows) * p.Cout : p.bias;
+}
 
 // Cross-thread part of the epilogue statistics.  Every thread holds s[0..7] / s[8..15] = sum / sum of squares of the 8
 // channels of ITS chunk column over the tile rows it finished; threads whose (tid % NCOL) agree share a column.

@@ -39,7 +39,7 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wc * 64 + j * 32 + (lane & 31);
-        bv[j] = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
+        bv[j] = (p.bias && n < p.Cout) ? bias_of(p, m0)[n] : 0.f;
     }
     float gs[16];   // GN: per-thread sum / sum of squares of the 8 channels of this thread's chunk column
 #pragma unroll

@@ -448,6 +448,105 @@ __global__ __launch_bounds__(kStatSlots * 64) void channel_stats_kernel(const T*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Mean-field compensation of the weight rounding of 16-bit convs / linears.  A layer y = W x + b run
+// with W rounded to half / bf16 leaves the error (W - W16) x; its part that is the same at every pixel of a frame,
+// (W - W16) mean(x), is a per-frame bias and is put back: bias_n = b + D mean_n, D[o][k] = sum over the filter taps of
+// (W - W16)[o][k][tap].  mean_n is taken over a fixed sample of <= 1024 pixels of the frame (an estimate good to 1-2 % of a
+// term that is itself 2^-12 of the output): kSampleRun consecutive pixels from each of up to kSampleCells equal cells.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSampleRun = 16, kSampleCells = 64;
+__host__ __device__ inline void mean_sample_geometry(int HW, int* run, int* cells, int* cell) {
+    *run = HW < kSampleRun ? HW : kSampleRun;
+    int r = HW / *run;
+    *cells = r < kSampleCells ? r : kSampleCells;
+    *cell = HW / *cells;
+}
+// i-th sampled pixel: pixel i % run of the run of cell i / run, which starts at a hashed offset inside the cell (so that the
+// runs do not line up in columns of the image)
+__host__ __device__ inline int mean_sample_pixel(int i, int cell, int run) {
+    const int j = i / run;
+    return j * cell + (int)(((unsigned)j * 40503u) % (unsigned)(cell - run + 1)) + i % run;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sampled_mean_kernel(const T* __restrict__ x, int ldx, int HW, int C, float* __restrict__ mean) {
+    __shared__ float sm[32][64 + 1];
+    const int cc = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + cc * 8;
+    const int n = blockIdx.y;
+    int run, cells, cell;
+    mean_sample_geometry(HW, &run, &cells, &cell);
+    const int S = cells * run;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        const T* base = x + (long)n * HW * ldx + c0;
+#pragma unroll 4
+        for (int i = pl; i < S; i += 32) {
+            float v[8];
+            RowIO<T, 8, sizeof(T) == 2>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[pl][cc * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tot += sm[k][threadIdx.x];
+        if (c < C) mean[(long)n * C + c] = tot / (float)S;
+    }
+}
+
+// out[r][o] = bias[o] + sum_k defect_t[k][o] * mean[r][k]: a workgroup = OL outputs x kMfbFrames frames, K cut in 256 / OL
+// slices that are summed in slice order - one fixed order whatever the grid
+constexpr int kMfbFrames = 4;
+template <int OL>
+__global__ __launch_bounds__(256) void mean_field_bias_kernel(const float* __restrict__ mean, const float* __restrict__ defect_t,
+                                                             const float* __restrict__ bias, int R, int K, int Cout, float* __restrict__ out) {
+    constexpr int KS = 256 / OL;
+    extern __shared__ float smk[];                     // [kMfbFrames][K] means, then [KS][kMfbFrames][OL] partial sums
+    const int ol = threadIdx.x % OL, ks = threadIdx.x / OL;
+    const int o = blockIdx.x * OL + ol, r0 = blockIdx.y * kMfbFrames;
+    for (int i = threadIdx.x; i < kMfbFrames * K; i += 256) {
+        const int r = r0 + i / K;
+        smk[i] = r < R ? mean[(long)r * K + i % K] : 0.f;
+    }
+    __syncthreads();
+    float acc[kMfbFrames];
+#pragma unroll
+    for (int f = 0; f < kMfbFrames; ++f) acc[f] = 0.f;
+    const int kq = (K + KS - 1) / KS, k0 = ks * kq, k1 = k0 + kq < K ? k0 + kq : K;
+    if (o < Cout) {
+#pragma unroll 16
+        for (int k = k0; k < k1; ++k) {
+            const float d = defect_t[(long)k * Cout + o];
+#pragma unroll
+            for (int f = 0; f < kMfbFrames; ++f) acc[f] += d * smk[f * K + k];
+        }
+    }
+    __syncthreads();
+    float* red = smk;
+#pragma unroll
+    for (int f = 0; f < kMfbFrames; ++f) red[(ks * kMfbFrames + f) * OL + ol] = acc[f];
+    __syncthreads();
+    if (ks == 0 && o < Cout) {
+        const float b = bias ? bias[o] : 0.f;
+#pragma unroll
+        for (int f = 0; f < kMfbFrames; ++f) {
+            if (r0 + f >= R) break;
+            float t = 0.f;
+            for (int q = 0; q < KS; ++q) t += red[(q * kMfbFrames + f) * OL + ol];
+            out[(long)(r0 + f) * Cout + o] = b + t;
+        }
+    }
+}
+
 __global__ void adain_affine_kernel(const float* mc, const float* vc, const float* ms, const float* vs, float eps,
                                     float* scale, float* shift, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -629,6 +728,48 @@ extern "C" int pgt_channel_stats(int32_t dtype, const void* x, int32_t ldx, int3
         hipLaunchKernelGGL((channel_stats_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, C, mean, var_unbiased);
     else
         PGT_CHECK(false, "channel_stats: bad dtype %d", dtype);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_sampled_channel_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C, float* mean,
+                                        pgt_stream_t stream) {
+    PGT_CHECK(x && mean && N >= 1 && HW >= 1, "sampled_channel_mean: null argument");
+    PGT_CHECK(C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "sampled_channel_mean: C=%d and ldx=%d must be multiples of 8, x 16-byte aligned", C, ldx);
+    const dim3 grid((C + 63) / 64, N), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PGT_F32)
+        hipLaunchKernelGGL((sampled_mean_kernel<float>), grid, blk, 0, st, (const float*)x, ldx, HW, C, mean);
+    else if (dtype == PGT_BF16)
+        hipLaunchKernelGGL((sampled_mean_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, C, mean);
+    else if (dtype == PGT_F16)
+        hipLaunchKernelGGL((sampled_mean_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, C, mean);
+    else
+        PGT_CHECK(false, "sampled_channel_mean: bad dtype %d", dtype);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_sampled_pixel(int32_t HW, int32_t i) {
+    int run, cells, cell;
+    if (HW < 1 || i < 0) return -1;
+    mean_sample_geometry(HW, &run, &cells, &cell);
+    if (i >= cells * run) return -1;
+    return mean_sample_pixel(i, cell, run);
+}
+
+extern "C" int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* bias, int32_t R, int32_t K, int32_t Cout,
+                                   float* out, pgt_stream_t stream) {
+    PGT_CHECK(mean && defect_t && out && R >= 1 && K >= 1 && Cout >= 1, "mean_field_bias: null argument");
+    PGT_CHECK(K <= 3840, "mean_field_bias: K=%d > 3840", K);
+    size_t lds = (size_t)kMfbFrames * K * sizeof(float);
+    if (lds < 256 * kMfbFrames * sizeof(float)) lds = 256 * kMfbFrames * sizeof(float);
+    const int fb = (R + kMfbFrames - 1) / kMfbFrames;
+    hipStream_t st = (hipStream_t)stream;
+    // narrow layers give their threads to the K axis instead (the 32-channel temporal mix has K = T * 2C up to 3072)
+    if (Cout > 32) hipLaunchKernelGGL(mean_field_bias_kernel<64>, dim3((Cout + 63) / 64, fb), dim3(256), lds, st, mean, defect_t, bias, R, K, Cout, out);
+    else if (Cout > 8) hipLaunchKernelGGL(mean_field_bias_kernel<32>, dim3((Cout + 31) / 32, fb), dim3(256), lds, st, mean, defect_t, bias, R, K, Cout, out);
+    else hipLaunchKernelGGL(mean_field_bias_kernel<8>, dim3((Cout + 7) / 8, fb), dim3(256), lds, st, mean, defect_t, bias, R, K, Cout, out);
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                                    "ld_dec", "ld_shift")] + [("sft_w", f32)] + \
                [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue", "kernel", "splitk", "stages",
                                    "orow_mul", "orow_xmul", "orow_off", "x_lo", "y_lo", "r_lo", "gn_groups", "gn_sub",
-                                   "gn_nsub", "gn_img0", "gn_nimg", "res_f32", "x3_fold", "dec_lo", "shift_lo")]
+                                   "gn_nsub", "gn_img0", "gn_nimg", "res_f32", "x3_fold", "dec_lo", "shift_lo", "bias_rows")]
 
 
 # name -> argtypes (restype is int32 unless listed in _RESTYPES); must cover every symbol of pgt_hip.h
@@ -42,6 +42,9 @@ SIGNATURES = {
     "pgt_layernorm": [i32, vp, i32, i32, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, vp],
     "pgt_channel_stats": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
     "pgt_adain_affine": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
+    "pgt_sampled_channel_mean": [i32, vp, i32, i32, i32, i32, vp, vp],
+    "pgt_sampled_pixel": [i32, i32],
+    "pgt_mean_field_bias": [vp, vp, vp, i32, i32, i32, vp, vp],
     "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pgt_window_attention3d": [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pgt_mha": [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp],

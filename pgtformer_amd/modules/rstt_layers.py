@@ -23,6 +23,10 @@ USE_X3_FOLD = os.environ.get("PGT_X3_FOLD", "1") != "0"   # A/B switch of the fo
 USE_X3_C64 = os.environ.get("PGT_X3_C64", "1") != "0"     # A/B switch of the register-weight split-bf16 3x3 kernel (igemm6x3.hip)
 
 
+USE_WCOMP = os.environ.get("PGT_WCOMP", "1") != "0"       # A/B switch of the mean-field weight-rounding compensation
+USE_WCOMP_LINEAR = os.environ.get("PGT_WCOMP_LINEAR", "1") != "0"   # ... of the token-row linears (window-attention blocks)
+
+
 class HipModule(nn.Module):
     """Base: `prepare(device, dtype)` repacks this module's weights for the kernels (recursively)."""
 
@@ -57,6 +61,46 @@ def _pack_matrix(w, device, dtype, cin_pad=None, scale=None, fold=False):
     return ops.pack_conv_weight(w.detach().to(device=device, dtype=torch.float32), dtype, cin_pad=cin_pad, scale=scale, fold=fold)
 
 
+def _wants_wcomp(dtype):
+    """single-plane 16-bit operands (half / bf16 layers): their weight rounding is compensated to first order"""
+    return USE_WCOMP and dtype in (torch.float16, torch.bfloat16)
+
+
+def _defect_t(w, pw, scale=None, sum_taps=True):
+    """Rounding defect of a packed 16-bit weight, as the (K, Cout) fp32 operand of ops.mean_field_bias:
+    D[k][o] = sum over the filter taps of (w * scale - packed)[o][k][tap] (sum_taps=False: one row per (tap, k), for a conv
+    whose taps read different frames).  w: the fp32 reference weight (Cout, Cin[, KH, KW]); pw = _pack_matrix(w, ...) of it.
+    DESIGN.md section 2.2: y = W x + b run with W16 leaves (W - W16) x, whose frame-constant part (W - W16) mean(x) is
+    put back as a per-frame bias."""
+    w32 = w.detach().to(device=pw.device, dtype=torch.float32)
+    cout, cin = w32.shape[0], w32.shape[1]
+    if scale is not None:
+        w32 = w32 * scale.view(-1, *([1] * (w32.dim() - 1)))
+    taps = w32.shape[2] * w32.shape[3] if w32.dim() == 4 else 1
+    cp = pw.shape[1] // taps
+    assert pw.shape == (cout, taps * cp) and cp >= cin, (pw.shape, w32.shape)
+    d = torch.zeros((cout, taps, cp), dtype=torch.float64, device=pw.device)
+    d[:, :, :cin] = w32.reshape(cout, cin, taps).permute(0, 2, 1).double() - pw.view(cout, taps, cp)[:, :, :cin].double()
+    d = d.sum(1) if sum_taps else d.reshape(cout, taps * cp)
+    return d.float().t().contiguous()
+
+
+def _frame_bias(x, pdef, pb, frames=None):
+    """per-frame bias of a compensated layer: x (N,H,W,C) image batch, or (rows, C) tokens of `frames` frames; None when the
+    layer is not compensated or its frames are not whole 512-row tiles (pgt_conv_desc::bias_rows)"""
+    if pdef is None:
+        return pb
+    if x.dim() == 2:
+        if not USE_WCOMP_LINEAR:
+            return pb
+        if not frames or x.shape[0] % frames or (x.shape[0] // frames) % 512:
+            return pb
+        x = x.as_strided((frames, x.shape[0] // frames, x.shape[1]), (x.stride(0) * (x.shape[0] // frames), x.stride(0), 1))
+    elif (x.shape[1] * x.shape[2]) % 512:
+        return pb
+    return ops.mean_field_bias(ops.sampled_channel_mean(x), pdef, pb)
+
+
 def _f32(t, device):
     return None if t is None else t.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -83,6 +127,7 @@ class Conv2d(nn.Conv2d, HipModule):
         cin_k = self._fold_cin = self.cin_pad if (self.cin_pad is not None and self.cin_pad > cin) else cin
         self.pw = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale)
         self.pb = b
+        self.pdef = _defect_t(self.weight, self.pw, scale=scale) if _wants_wcomp(dtype) else None
         # split-bf16 layers with 64 output channels: the folded form fills the 128-column tile (pgt_conv_desc.x3_fold)
         self.pw_fold = None
         if (_is_x3(dtype) or _is_x3f(dtype)) and cout == 64 and cin_k % 64 == 0 and USE_X3_FOLD:
@@ -105,7 +150,10 @@ class Conv2d(nn.Conv2d, HipModule):
         if _is_x3f(self.dt):     # fp32 in / fp32 out, split-bf16 MFMA arithmetic in between
             return ops.conv2d(ops.to_x3(x), w, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
                               stride=self.stride[0], pad=self.pad4, x3=True, out_f32=True, **kw)
-        return ops.conv2d(x, w, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
+        b = self.pb
+        if self.pdef is not None and self.stride == (1, 1) and not kw.get("ups"):     # (same-size layers: frames of H*W output pixels)
+            b = _frame_bias(x, self.pdef, self.pb)
+        return ops.conv2d(x, w, b, kh=self.kernel_size[0], kw=self.kernel_size[1],
                           stride=self.stride[0], pad=self.pad4, x3=_is_x3(self.dt), **kw)
 
 
@@ -113,9 +161,11 @@ class Linear(nn.Linear, HipModule):
     def _pack(self, device, dtype):
         self.pw = _pack_matrix(self.weight, device, dtype)
         self.pb = _f32(self.bias, device)
+        self.pdef = _defect_t(self.weight, self.pw) if _wants_wcomp(dtype) else None
 
-    def run(self, x, **kw):
-        return ops.linear(x, self.pw, self.pb, x3=_is_x3(self.dt), **kw)
+    def run(self, x, frames=None, **kw):
+        """frames: the rows of x are the tokens of that many frames (equal counts): enables the per-frame compensation"""
+        return ops.linear(x, self.pw, _frame_bias(x, self.pdef, self.pb, frames), x3=_is_x3(self.dt), **kw)
 
 
 class GroupNorm(nn.GroupNorm, HipModule):
@@ -204,7 +254,9 @@ class WindowAttention3D(HipModule):
 
     def _pack(self, device, dtype):
         # one fused (3C,C) projection [q | k | v]; dense per-head bias gathered once from the table
-        self.w_qkv = _pack_matrix(torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0), device, dtype)
+        wcat = torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0)
+        self.w_qkv = _pack_matrix(wcat, device, dtype)
+        self.d_qkv = _defect_t(wcat, self.w_qkv) if _wants_wcomp(dtype) else None
         if self.q.bias is not None:
             self.b_qkv = _f32(torch.cat([self.q.bias.detach(), self.kv.bias.detach()], 0), device)
         else:
@@ -234,11 +286,12 @@ class VSTSREncoderTransformerBlock(HipModule):
         win, shift = get_window_size((H, W), self.window_size, self.shift_size)
         x3 = _is_x3(self.dt)
         ln = self.norm1.run(xt)
-        qkv = ops.linear(ln, self.attn.w_qkv, self.attn.b_qkv, x3=x3)
+        nf = B * self.num_frames                      # frames of H*W tokens (rows in (b, d, y, x) order)
+        qkv = ops.linear(ln, self.attn.w_qkv, _frame_bias(ln, self.attn.d_qkv, self.attn.b_qkv, nf), x3=x3)
         ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift, x3=x3)
-        x1 = self.attn.proj.run(ao, res=xt)
-        m = self.mlp.fc1.run(self.norm2.run(x1), act=ACT_GELU)
-        return self.mlp.fc2.run(m, res=x1, out=out, gn=None if gn_images is None else (32, gn_images))
+        x1 = self.attn.proj.run(ao, frames=nf, res=xt)
+        m = self.mlp.fc1.run(self.norm2.run(x1), frames=nf, act=ACT_GELU)
+        return self.mlp.fc2.run(m, frames=nf, res=x1, out=out, gn=None if gn_images is None else (32, gn_images))
 
 
 class EncoderLayer(HipModule):

@@ -364,7 +364,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                 st = GnStats(n, 1, ho0 * wo0, cout, gn, x.device)
         for i in range(0, n, per):
             sl = slice(i, min(n, i + per))
-            conv2d(x[sl], w, bias, kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, act=act,
+            conv2d(x[sl], w, bias if bias is None or bias.dim() == 1 else bias[sl], kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, act=act,
                    res=None if res is None else res[sl], post_relu=post_relu,
                    sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
                    tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3,
@@ -396,6 +396,9 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.splitk = int(splitk)
     d.stages = int(stages)
     d.x3_fold = int(bool(x3_fold))
+    if bias is not None and bias.dim() == 2:      # one bias vector per frame (mean_field_bias): (frames, Cout) fp32
+        assert bias.shape[1] == cout and bias.is_contiguous() and (n * ho * wo) % bias.shape[0] == 0 and bias.shape[0] % n == 0, (bias.shape, n, cout)
+        d.bias_rows = (n * ho * wo) // bias.shape[0]
     if out_rows is not None:
         d.orow_mul, d.orow_xmul, d.orow_off = out_rows
     st = None        # epilogue GroupNorm statistics
@@ -561,6 +564,42 @@ def channel_stats(x, want_var=True):
     hip.check(hip.lib().pgt_channel_stats(_dt(x), _p(x), _ld_img(x), n, h * w, c, _p(mean), _p(var), _stream()),
               "pgt_channel_stats")
     return mean, var
+
+
+def sampled_channel_mean(x):
+    """fp32 (N, C): mean of x (N,H,W,C) - or (N, HW, C) - per frame and channel over the library's fixed pixel sample (<= 1024
+    pixels of a frame: pgt_sampled_channel_mean)."""
+    if x.dim() == 3:
+        x = x.unsqueeze(1)
+    n, h, w, c = x.shape
+    mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    with _Prof("mean_field", 0, float(n * min(h * w, 1024) * c * x.element_size())):
+        hip.check(hip.lib().pgt_sampled_channel_mean(_dt(x), _p(x), _ld_img(x), n, h * w, c, _p(mean), _stream()), "pgt_sampled_channel_mean")
+    return mean
+
+
+def mean_field_bias(mean, defect_t, bias=None):
+    """(R, Cout) fp32 per-frame bias = bias + mean (R, K) @ defect_t (K, Cout): the frame-constant part of the error a layer makes
+    with its weights rounded to 16 bits, put back (pgt_mean_field_bias; conv2d / linear take the result as `bias`)."""
+    r, k = mean.shape
+    assert defect_t.shape[0] == k and defect_t.is_contiguous() and mean.is_contiguous() and mean.dtype == defect_t.dtype == torch.float32
+    cout = defect_t.shape[1]
+    out = torch.empty((r, cout), dtype=torch.float32, device=mean.device)
+    with _Prof("mean_field", 2.0 * r * k * cout, float(defect_t.numel() * 4)):
+        hip.check(hip.lib().pgt_mean_field_bias(_p(mean), _p(defect_t), _p(bias), r, k, cout, _p(out), _stream()), "pgt_mean_field_bias")
+    return out
+
+
+def sampled_pixels(hw):
+    """pixel indices of the library's sample of an hw-pixel frame (host-side mirror for tests / emulation)"""
+    L = hip.lib()
+    out, i = [], 0
+    while True:
+        p = L.pgt_sampled_pixel(hw, i)
+        if p < 0:
+            return out
+        out.append(p)
+        i += 1
 
 
 def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):

@@ -135,7 +135,10 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
     xi = F.pad(xi, (pad[2], pad[3], pad[0], pad[1]))
     wt = w.float().reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
-    y = F.conv2d(xi, wt, bias.float() if bias is not None else None, stride=stride).permute(0, 2, 3, 1)
+    y = F.conv2d(xi, wt, bias.float() if (bias is not None and bias.dim() == 1) else None, stride=stride).permute(0, 2, 3, 1)
+    if bias is not None and bias.dim() == 2:       # one bias vector per frame: bias_rows = N*Ho*Wo / frames consecutive output pixels
+        fr = bias.shape[0]
+        y = (y.reshape(fr, -1, cout) + bias.float()[:, None, :]).reshape(y.shape)
     y = _act(y, act)
     if sft is not None:
         dec, shift, sw = sft
@@ -165,7 +168,10 @@ def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, 
     if x3:
         x, w = _merge(x), _unpack_x3_weight(w, 1)
         res = None if res is None else _merge(res)
-    y = _act(F.linear(x.float(), w.float(), bias.float() if bias is not None else None), act)
+    y = F.linear(x.float(), w.float(), bias.float() if (bias is not None and bias.dim() == 1) else None)
+    if bias is not None and bias.dim() == 2:
+        y = (y.reshape(bias.shape[0], -1, y.shape[-1]) + bias.float()[:, None, :]).reshape(y.shape)
+    y = _act(y, act)
     if res is not None:
         y = y + res.float()
     if x3 and not out_f32:
@@ -215,6 +221,28 @@ def channel_stats(x, want_var=True):
     n, h, w, c = x.shape
     xf = x.float().reshape(n, h * w, c)
     return xf.mean(1).contiguous(), (xf.var(1, unbiased=True).contiguous() if want_var else None)
+
+
+_SAMPLES = {}
+
+
+def sampled_pixels(hw):
+    """the library's pixel sample of an hw-pixel frame (pgt_sampled_pixel is host code: callable without a GPU)"""
+    if hw not in _SAMPLES:
+        from pgtformer_amd import ops as real_ops
+        _SAMPLES[hw] = torch.tensor(real_ops.sampled_pixels(hw), dtype=torch.long)
+    return _SAMPLES[hw]
+
+
+def sampled_channel_mean(x):
+    if x.dim() == 4:
+        x = x.reshape(x.shape[0], x.shape[1] * x.shape[2], x.shape[3])
+    return x[:, sampled_pixels(x.shape[1]), :].float().mean(1)
+
+
+def mean_field_bias(mean, defect_t, bias=None):
+    y = mean.float() @ defect_t.float()
+    return y if bias is None else y + bias.float()
 
 
 def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):
@@ -452,7 +480,7 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "sample_rows", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
-       "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update"]
+       "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update", "sampled_channel_mean", "mean_field_bias"]
 
 
 def install(monkeypatch):

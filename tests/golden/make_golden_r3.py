@@ -228,5 +228,44 @@ def main():
         print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
 
 
+MORE_WINDOWS = ((2077, 1), (1077, 4), (3077, 3))     # (clip seed, window): other clips, picked where an uncompensated half
+#                                                        decoder is furthest from the reference (tools/gpu/psnr_sweep.py)
+
+
+def more_windows():
+    """`--more`: the REFERENCE on windows of other synthetic clips at the same operating point (weights: the committed
+    r3_tail.npz through r3_scheme, nothing is re-trained) -> r3_golden_more.npz: fp32 rows of the middle frame + codes."""
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    from archs.pgtformer_arch import PGTFormer                       # reference
+
+    from pgtformer_amd.config import default_config
+    from pgtformer_amd.manifest import pgtformer_manifest
+    from pgtformer_amd.synth import make_clip, window_from_clip
+    from pgtformer_amd.weightgen import generate_state_dict
+    from r3_scheme import fitted_tail_state_dict
+
+    torch.manual_seed(0)
+    torch.use_deterministic_algorithms(True)
+    cfg = default_config()
+    model = PGTFormer(**cfg)
+    model.eval()
+    model.load_state_dict(fitted_tail_state_dict(generate_state_dict(pgtformer_manifest(cfg), cfg, seed=0)), strict=True)
+    full = {}
+    for seed, i in MORE_WINDOWS:
+        lq_u8, gt = make_clip(i + 2, 512, seed=seed)
+        x = torch.from_numpy(window_from_clip(lq_u8, i).astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+        g = torch.from_numpy(gt[i]).permute(2, 0, 1)
+        with torch.no_grad():
+            out, logits, _ = model(x.clone(), w=1.0)
+        tag = f"c{seed}w{i}"
+        print(f"{tag}: middle frame range [{out[1].min().item():.3f}, {out[1].max().item():.3f}], PSNR(ref, GT) {psnr(out[1], g):.3f} dB")
+        full[f"{tag}.out_mid_rows"] = out[1, :, ::8, :].numpy()
+        full[f"{tag}.codes"] = logits.argmax(-1).numpy().astype(np.int16)
+        full[f"{tag}.psnr_ref_vs_gt_db"] = np.array([psnr(out[1], g)])
+    np.savez_compressed(os.path.join(HERE, "r3_golden_more.npz"), **full)
+    print("r3_golden_more.npz", os.path.getsize(os.path.join(HERE, "r3_golden_more.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    more_windows() if "--more" in sys.argv else main()

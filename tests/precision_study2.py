@@ -1,0 +1,130 @@
+"""TEST INFRASTRUCTURE (a study, not a test): per-level decoder precision policies at the fitted-tail operating point, on
+several windows.  The encoder side of the oracle runs once per window (exact, cached under /tmp); the decoder is re-run
+with the conv / linear ACTIVATION operands, WEIGHT operands and STORED activations rounded by a policy chosen per layer
+group (512x512 level, 256->512 up-sampling, 256x256 level + fusion, the rest).
+
+    python tests/precision_study2.py [seed:window ...]      (default 1234:1 1077:4 2077:1)
+"""
+import os, sys, time
+import numpy as np, torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pgt_oracle as O
+from pgtformer_amd.config import default_config
+from pgtformer_amd.manifest import pgtformer_manifest
+from pgtformer_amd.synth import make_clip, window_from_clip
+from pgtformer_amd.weightgen import generate_state_dict
+from tests.golden.r3_scheme import fitted_tail_state_dict
+
+cfg = default_config()
+sd = fitted_tail_state_dict(generate_state_dict(pgtformer_manifest(cfg), cfg, seed=0))
+
+
+def q_f16(t): return t.to(torch.float16).float()
+def q_bf16(t): return t.to(torch.bfloat16).float()
+def q_x3(t):
+    hi = t.to(torch.bfloat16).float()
+    return hi + (t - hi).to(torch.bfloat16).float()
+def q_h2(t):       # two half planes: 22 significand bits
+    hi = t.to(torch.float16).float()
+    return hi + (t - hi).to(torch.float16).float()
+def q_id(t): return t
+Q = {"f16": q_f16, "bf16": q_bf16, "x3": q_x3, "h2": q_h2, "f32": q_id}
+
+
+def group_of(p):
+    if p.startswith("decoder.up.0.") or p.startswith("decoder.norm_out") or p.startswith("decoder.conv_out"):
+        return "L512"
+    if p.startswith("decoder.up.1.upsample"):
+        return "U256"
+    if p.startswith("decoder.up.1.") or p.startswith("fuse_convs_dict.256"):
+        return "L256"
+    return "rest"
+
+
+def run_decoder(cache, policy):
+    """policy: group -> (activation operand, weight operand, storage) format names"""
+    oc, ol, og, oln = O._conv, O._lin, O._gn, O._ln
+    def pol(p): return [Q[n] for n in policy[group_of(p)]]
+    def conv(sd_, p, xx, stride=1, padding=0):
+        a, w, s = pol(p)
+        return s(F.conv2d(a(xx), w(sd_[p + ".weight"]), sd_.get(p + ".bias"), stride=stride, padding=padding))
+    def lin(sd_, p, xx):
+        a, w, s = pol(p)
+        return s(F.linear(a(xx), w(sd_[p + ".weight"]), sd_.get(p + ".bias")))
+    def gn(sd_, p, xx, eps=1e-6): return pol(p)[2](og(sd_, p, xx, eps))
+    def ln(sd_, p, xx, eps=1e-5): return pol(p)[2](oln(sd_, p, xx, eps))
+    O._conv, O._lin, O._gn, O._ln = conv, lin, gn, ln
+    try:
+        def fuse(fs, hcur):
+            if fs in cache["connect"]:
+                return O.fuse_sft(sd, f"fuse_convs_dict.{fs}", cache["enc_feats"][fs], hcur, 1.0)
+            return hcur
+        return O.decoder_forward(sd, cache["dd"], cache["zq"], cache["t"], fuse)
+    finally:
+        O._conv, O._lin, O._gn, O._ln = oc, ol, og, oln
+
+
+def encoder_side(seed, i):
+    path = f"/tmp/pgt_study_{seed}_{i}.pt"
+    if os.path.exists(path):
+        return torch.load(path)
+    from pgtformer_amd.config import PGTFORMER_DEFAULTS
+    lq_u8, gt = make_clip(i + 2, 512, seed=seed)
+    win = window_from_clip(lq_u8, i)
+    x = torch.from_numpy(win.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    full = dict(PGTFORMER_DEFAULTS); full.update(cfg)
+    # run the oracle once with the decoder replaced by a recorder
+    rec = {}
+    odec = O.decoder_forward
+    def grab(sd_, dd, zq, t, fuse):
+        rec.update(dd=dd, zq=zq, t=t)
+        return odec(sd_, dd, zq, t, fuse)
+    ofuse = O.fuse_sft
+    feats = {}
+    def fuse_rec(sd_, p, enc, dec, w, tcc=32):
+        feats[p.split(".")[-1]] = enc
+        return ofuse(sd_, p, enc, dec, w, tcc)
+    O.decoder_forward, O.fuse_sft = grab, fuse_rec
+    try:
+        ref = O.pgtformer_forward(sd, cfg, x, w=1.0)[0]
+    finally:
+        O.decoder_forward, O.fuse_sft = odec, ofuse
+    cache = dict(rec, enc_feats=feats, connect=list(feats), ref=ref, gt=torch.from_numpy(gt[i]).permute(2, 0, 1).contiguous())
+    torch.save(cache, path)
+    return cache
+
+
+def psnr(a, b): return float(-10 * torch.log10(((a.double() - b.double()) ** 2).mean()))
+
+H = ("f16", "f16", "f16")
+POLICIES = {
+    "half everywhere": dict(L512=H, U256=H, L256=H, rest=H),
+    "L512 weights h2": dict(L512=("f16", "h2", "f16"), U256=H, L256=H, rest=H),
+    "L512 weights h2 + x3 storage": dict(L512=("f16", "h2", "x3"), U256=H, L256=H, rest=H),
+    "L512 x3": dict(L512=("x3", "x3", "x3"), U256=H, L256=H, rest=H),
+    "L512+U256 x3": dict(L512=("x3", "x3", "x3"), U256=("x3", "x3", "x3"), L256=H, rest=H),
+    "L512+U256+L256 weights h2": dict(L512=("f16", "h2", "f16"), U256=("f16", "h2", "f16"), L256=("f16", "h2", "f16"), rest=H),
+    "all weights h2": {g: ("f16", "h2", "f16") for g in ("L512", "U256", "L256", "rest")},
+    "L512+U256+L256 x3": dict(L512=("x3",) * 3, U256=("x3",) * 3, L256=("x3",) * 3, rest=H),
+    "all x3": {g: ("x3",) * 3 for g in ("L512", "U256", "L256", "rest")},
+}
+
+if __name__ == "__main__":
+    wins = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(1234, 1), (1077, 4), (2077, 1)]
+    only = os.environ.get("PGT_STUDY_ONLY")
+    torch.set_num_threads(8)
+    for seed, i in wins:
+        t0 = time.time()
+        c = encoder_side(seed, i)
+        ref, gt = c["ref"][1], c["gt"]
+        print(f"== clip {seed} window {i}: PSNR(ref, GT) mid = {psnr(ref, gt):.3f} dB ({time.time() - t0:.0f} s)", flush=True)
+        for name, pol in POLICIES.items():
+            if only and only not in name:
+                continue
+            t0 = time.time()
+            out = run_decoder(c, pol)[1]
+            e, r = (out - ref).double(), (ref - gt).double()
+            rho = float((e * r).sum() / (e.norm() * r.norm()))
+            print(f"  {name:36s} PSNR(build, ref) {psnr(out, ref):6.2f} dB   dPSNR {psnr(out, gt) - psnr(ref, gt):+.2e} dB   "
+                  f"corr(e, r) {rho:+.4f}   ({time.time() - t0:.0f} s)", flush=True)

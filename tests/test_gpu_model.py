@@ -302,6 +302,32 @@ def test_psnr_contract_on_the_benchmarked_path(tail_models):
         assert rec["u8_max_diff"] <= 1 and rec["u8_equal_fraction"] >= 0.97, rec
 
 
+@pytest.mark.parametrize("tag", ["c2077w1", "c1077w4", "c3077w3"])
+def test_psnr_contract_on_windows_of_other_clips(tail_models, tag):
+    """The contract beyond the clip the tail was fitted on: windows of three other synthetic clips (reference rows in
+    r3_golden_more.npz, `make_golden_r3.py --more`), chosen where a half decoder WITHOUT the weight-rounding compensation is
+    furthest from the reference (profiles/r3_psnr_sweep.md: +1.1e-3, -1.3e-3, +1.0e-3 dB).  Through the benchmarked path
+    (uint8 frames, overlap-aware window, middle-only tail): |dPSNR vs GT| <= 1e-3 dB, every code equal to the reference's,
+    unclamped PSNR(build, reference) >= 70 dB."""
+    from pgtformer_amd.synth import make_clip
+
+    g = np.load(os.path.join(GOLD, "r3_golden_more.npz"))
+    seed, i = int(tag[1:5]), int(tag[6:])
+    lq_u8, gt = make_clip(i + 2, 512, seed=seed)
+    m = tail_models["x3f16"]
+    frames = torch.from_numpy(lq_u8[i - 1:i + 2]).to(DEV)
+    out, _, _ = m.forward_nhwc(frames, w=1.0, win=m.window_index(1, 3, DEV), middle_only=True)        # (1,512,512,3) fp32
+    rows = out[0].float().cpu().permute(2, 0, 1)[:, ::8, :].double()
+    ref = torch.from_numpy(g[f"{tag}.out_mid_rows"]).double()
+    gt_rows = torch.from_numpy(gt[i]).permute(2, 0, 1)[:, ::8, :].double()
+    codes = m.last_codes.cpu().numpy().astype(np.int16)
+    rec = {"psnr_ref_vs_gt_db": psnr(ref, gt_rows), "dpsnr_db": psnr(rows, gt_rows) - psnr(ref, gt_rows),
+           "psnr_build_vs_ref_unclamped_db": psnr(rows, ref), "code_agreement": float((codes == g[f"{tag}.codes"]).mean())}
+    _LOG[f"operating_point_other_clips/{tag}/x3f16"] = rec
+    assert rec["psnr_ref_vs_gt_db"] >= 25.0 and rec["code_agreement"] == 1.0, rec
+    assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_build_vs_ref_unclamped_db"] >= 70.0, rec
+
+
 def test_whole_model_pure_bf16_report(models, golden_window):
     """Pure bf16 (opt-in speed mode) is reported, not a parity mode: with random-init weights ~2 % of the codes flip."""
     g = np.load(os.path.join(GOLD, "full_golden.npz"))

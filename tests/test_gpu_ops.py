@@ -732,3 +732,97 @@ def test_model_with_and_without_epilogue_statistics(monkeypatch):
         monkeypatch.setattr(O, "USE_EPILOGUE_GN", True)
         assert getattr(off, "_pgt_gn", None) is None
         check(f"block_gn_on_vs_off_{dtype}", on, off, dtype, 0.5)
+
+
+# ------------------------------------------------------------------------------------------------
+# mean-field compensation of the weight rounding: sampled channel means, the per-frame bias they give,
+# and the per-frame bias epilogue of every conv / linear kernel
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sampled_channel_mean_and_mean_field_bias(dtype):
+    O = ops()
+    for (n, h, w, c, cw) in [(3, 32, 32, 64, 64), (2, 128, 128, 256, 320), (2, 512, 512, 64, 64), (5, 4, 8, 72, 72), (1, 64, 64, 576, 576)]:
+        buf = rnd((n, h, w, cw), 11 + c, dtype) + 0.25
+        x = buf[..., :c]                                     # a channel slice of a wider buffer when cw > c
+        want = E.sampled_channel_mean(x)
+        got = O.sampled_channel_mean(g(buf)[..., :c])
+        idx = E.sampled_pixels(h * w)
+        assert len(idx) == min(h * w, 1024) and len(set(idx.tolist())) == len(idx) and int(idx.max()) < h * w
+        check(f"sampled_mean_{n}x{h}x{w}x{c}", got, want, torch.float32, tol_scale=0.05)
+        if h * w >= 4096:       # the sample stands for the frame: its mean is close to the full mean
+            full = x.float().mean(dim=(1, 2))
+            assert (want - full).abs().max() < 0.2
+    mean = rnd((7, 200), 5) * 0.3
+    dt = rnd((200, 96), 6) * 1e-3
+    b = rnd((96,), 7)
+    check("mean_field_bias", O.mean_field_bias(g(mean), g(dt), g(b)), mean @ dt + b, torch.float32, tol_scale=0.05)
+    check("mean_field_bias_nobias", O.mean_field_bias(g(mean), g(dt)), mean @ dt, torch.float32, tol_scale=0.05)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["c64_3x3", "c256_3x3", "cout32", "splitk_32x32", "tokens", "kernel5", "sft"])
+def test_conv2d_bias_per_frame(dtype, case):
+    """pgt_conv_desc::bias_rows: one bias vector per frame, through every kernel the static selection uses (register-weight
+    64-channel kernel, phased LDS-DMA kernel, register-staged tiles, split-K, token rows of a linear, SFT epilogue)."""
+    O = ops()
+    kw = {}
+    if case == "c64_3x3":
+        n, h, w, cin, cout, k = 3, 32, 64, 64, 64, 3
+    elif case == "c256_3x3":
+        n, h, w, cin, cout, k = 4, 32, 32, 256, 256, 3
+    elif case == "cout32":
+        n, h, w, cin, cout, k = 2, 32, 32, 96, 32, 3
+    elif case == "splitk_32x32":
+        n, h, w, cin, cout, k = 1, 32, 32, 1024, 128, 3
+    elif case == "kernel5":
+        n, h, w, cin, cout, k = 2, 32, 32, 128, 256, 3
+        kw = {"kernel": 5} if dtype == torch.bfloat16 else {}
+    elif case == "sft":
+        n, h, w, cin, cout, k = 2, 32, 32, 128, 128, 3
+    else:
+        n, h, w, cin, cout, k = 1, 1, 6 * 1024, 256, 768, 1
+    x = rnd((n, h, w, cin), 21, dtype)
+    wt = rnd((cout, k * k * cin), 22, dtype, 0.05)
+    frames = 6 if case == "tokens" else n
+    bias = rnd((frames, cout), 23)
+    pad = (1, 1, 1, 1) if k == 3 else (0, 0, 0, 0)
+    if case == "sft":
+        dec, sh = rnd((n, h, w, cout), 24, dtype), rnd((n, h, w, cout), 25, dtype)
+        want = E.conv2d(x, wt, bias, kh=k, kw=k, pad=pad, sft=(dec, sh, 0.7))
+        got = O.conv2d(g(x), g(wt), g(bias), kh=k, kw=k, pad=pad, sft=(g(dec), g(sh), 0.7))
+    else:
+        res = rnd((n, h, w, cout), 24, dtype)
+        want = E.conv2d(x, wt, bias, kh=k, kw=k, pad=pad, act=E.ACT_SILU, res=res)
+        got = O.conv2d(g(x), g(wt), g(bias), kh=k, kw=k, pad=pad, act=E.ACT_SILU, res=g(res), **kw)
+    check(f"conv_bias_per_frame_{case}", got, want, dtype, tol_scale=2.0)
+    # and it is not the shared-bias result (the frames' vectors differ)
+    other = O.conv2d(g(x), g(wt), g(bias[0].contiguous()), kh=k, kw=k, pad=pad)
+    assert frames == 1 or not torch.equal(other[-1], got[-1])
+    if case == "c64_3x3":       # frames that are not whole 512-row tiles are refused, not mis-indexed
+        with pytest.raises(Exception):
+            O.conv2d(g(x[:, :8, :16]), g(wt), g(bias), kh=k, kw=k, pad=pad)
+
+
+def test_compensated_half_conv_is_closer_to_fp32():
+    """What the compensation is for: a half conv on inputs with a channel mean (post-SiLU activations) - the frame-mean
+    of its error against the fp32 conv drops by an order of magnitude with the per-frame bias of _frame_bias."""
+    from pgtformer_amd.modules.rstt_layers import Conv2d, prepare_tree
+    torch.manual_seed(3)
+    conv = Conv2d(128, 128, 3, padding=1)
+    x32 = torch.nn.functional.silu(rnd((2, 64, 64, 128), 31))
+    want = E.conv2d(x32, E.pack_conv_weight(conv.weight.detach(), torch.float32), conv.bias.detach(), kh=3, kw=3, pad=(1, 1, 1, 1))
+    xh = g(x32.to(torch.float16))
+    want_h = E.conv2d(xh.cpu().float(), E.pack_conv_weight(conv.weight.detach(), torch.float32), conv.bias.detach(), kh=3, kw=3, pad=(1, 1, 1, 1))
+    errs = {}
+    import pgtformer_amd.modules.rstt_layers as R
+    for on in (False, True):
+        old = R.USE_WCOMP
+        R.USE_WCOMP = on
+        try:
+            prepare_tree(conv, torch.device(DEV), torch.float16)
+            y = conv.run(xh).float().cpu()
+        finally:
+            R.USE_WCOMP = old
+        e = (y - want_h)[:, 4:-4, 4:-4]                       # away from the zero-padded border
+        errs[on] = float(e.mean(dim=(1, 2)).abs().mean())       # per-(frame, channel) mean error = the bias part
+    _LOG.append({"name": "compensated_half_conv_bias_error", "off": errs[False], "on": errs[True]})
+    assert errs[True] < 0.25 * errs[False], errs

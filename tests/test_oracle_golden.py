@@ -126,3 +126,22 @@ def test_oracle_at_the_fitted_tail_operating_point(cfg, full_sd):
         assert float(g[f"{tag}.psnr_ref_vs_gt_db"][0]) >= 25.0
         lo, hi = g[f"{tag}.out_stats"][:, 2].min(), g[f"{tag}.out_stats"][:, 3].max()
         assert lo > -0.5 and hi < 1.5
+
+
+@pytest.mark.slow
+def test_oracle_on_a_window_of_another_clip(cfg, full_sd):
+    """tests/golden/r3_golden_more.npz (`make_golden_r3.py --more`: the reference on windows of other synthetic clips at the
+    fitted-tail operating point - the windows the GPU contract test uses beyond the golden clip): the oracle reproduces the
+    reference's middle frame and codes on one of them bit for bit."""
+    from oracle import pgt_oracle as O
+    from pgtformer_amd.synth import make_clip, window_from_clip
+    from tests.golden.r3_scheme import fitted_tail_state_dict
+
+    g = np.load(os.path.join(GOLD, "r3_golden_more.npz"))
+    assert sorted({k.split(".")[0] for k in g.files}) == ["c1077w4", "c2077w1", "c3077w3"]
+    assert all(float(g[f"{t}.psnr_ref_vs_gt_db"][0]) >= 25.0 for t in ("c1077w4", "c2077w1", "c3077w3"))
+    lq_u8, _ = make_clip(3, 512, seed=2077)
+    x = torch.from_numpy(window_from_clip(lq_u8, 1).astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    out, logits, _ = O.pgtformer_forward(fitted_tail_state_dict(full_sd), cfg, x, w=1.0)
+    assert np.array_equal(out[1, :, ::8, :].numpy(), g["c2077w1.out_mid_rows"])
+    assert np.array_equal(logits.argmax(-1).numpy().astype(np.int16), g["c2077w1.codes"])
