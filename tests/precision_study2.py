@@ -3,7 +3,15 @@ several windows.  The encoder side of the oracle runs once per window (exact, ca
 with the conv / linear ACTIVATION operands, WEIGHT operands and STORED activations rounded by a policy chosen per layer
 group (512x512 level, 256->512 up-sampling, 256x256 level + fusion, the rest).
 
-    python tests/precision_study2.py [seed:window ...]      (default 1234:1 1077:4 2077:1)
+    python tests/precision_study2.py [levels|groups|compensation|planes] [seed:window ...]   (default windows 1234:1 1077:4 2077:1)
+
+  levels        per-level policies (which levels need more than half precision)
+  groups        22-bit weights in one decoder level at a time / in all but one: whose weight rounding carries the systematic error
+  compensation  half everywhere + the mean-field compensation of the weight rounding (what the product does: per-frame bias
+                (W - W16) mean(x) from the library's pixel sample), for the residual-block / fusion convs only and for every layer
+  planes        the code-prediction branch on two bf16 planes (the product's split-bf16) against two half planes: logit error
+                and flipped codes against the exact oracle
+Results: profiles/r3_psnr_sweep.md.
 """
 import os, sys, time
 import numpy as np, torch
@@ -110,8 +118,123 @@ POLICIES = {
     "all x3": {g: ("x3",) * 3 for g in ("L512", "U256", "L256", "rest")},
 }
 
+def run_groups(c):
+    """22-bit ("h2") weights in one group of decoder layers at a time, and everywhere but one group"""
+    global group_of
+    G = ["up.0", "up.1", "up.2", "up.3", "up.4", "mid"]
+
+    def by_level(p):
+        if p.startswith("decoder.norm_out") or p.startswith("decoder.conv_out"):
+            return "up.0"
+        for k in range(6):
+            if p.startswith(f"decoder.up.{k}."):
+                return f"up.{k}"
+        if p.startswith("fuse_convs_dict."):
+            return {"256": "up.1", "128": "up.2", "64": "up.3", "32": "up.4"}[p.split(".")[1]]
+        return "mid"
+    old, group_of = group_of, by_level
+    W2 = ("f16", "h2", "f16")
+    pols = {"half everywhere": {g: H for g in G}, "all weights h2": {g: W2 for g in G}}
+    pols.update({f"only {g} weights h2": {k: (W2 if k == g else H) for k in G} for g in G})
+    pols.update({f"all but {g} weights h2": {k: (H if k == g else W2) for k in G} for g in G})
+    try:
+        for name, pol in pols.items():
+            report(name, run_decoder(c, pol)[1], c)
+    finally:
+        group_of = old
+
+
+def run_compensation(c):
+    """half operands / storage everywhere; `which` layers get the per-frame bias (W - W16) mean(x), mean over the library's
+    pixel sample of the frame (pgt_sampled_pixel)"""
+    from tests.emu_ops import sampled_pixels
+    oc, ol, og, oln = O._conv, O._lin, O._gn, O._ln
+    for which in ("none", "convs of residual / fusion blocks", "every conv and linear"):
+        def sel(p):
+            blk = p.split(".")[-1] in ("conv1", "conv2", "conv_out") and p.startswith("decoder") or p.startswith("fuse")
+            return which != "none" and (blk or which.startswith("every"))
+        def conv(sd_, p, xx, stride=1, padding=0):
+            W = sd_[p + ".weight"]; Wq = q_f16(W)
+            y = F.conv2d(q_f16(xx), Wq, sd_.get(p + ".bias"), stride=stride, padding=padding)
+            if sel(p):
+                n, cch, hh, ww = xx.shape
+                m = xx.reshape(n, cch, hh * ww)[:, :, sampled_pixels(hh * ww)].mean(2)               # (N, Cin)
+                y = y + (m @ (W - Wq).sum(dim=(2, 3)).t()).view(n, -1, 1, 1)
+            return q_f16(y)
+        def lin(sd_, p, xx):
+            W = sd_[p + ".weight"]; Wq = q_f16(W)
+            y = F.linear(q_f16(xx), Wq, sd_.get(p + ".bias"))
+            if sel(p):
+                y = y + (W - Wq) @ xx.reshape(-1, xx.shape[-1]).mean(0)
+            return q_f16(y)
+        O._conv, O._lin = conv, lin
+        O._gn = lambda sd_, p, xx, eps=1e-6: q_f16(og(sd_, p, xx, eps))
+        O._ln = lambda sd_, p, xx, eps=1e-5: q_f16(oln(sd_, p, xx, eps))
+        try:
+            def fuse(fs, hcur):
+                return O.fuse_sft(sd, f"fuse_convs_dict.{fs}", c["enc_feats"][fs], hcur, 1.0) if fs in c["connect"] else hcur
+            out = O.decoder_forward(sd, c["dd"], c["zq"], c["t"], fuse)[1]
+        finally:
+            O._conv, O._lin, O._gn, O._ln = oc, ol, og, oln
+        report(f"compensated: {which}", out, c)
+
+
+def run_planes(seed, i):
+    """code-prediction branch with operands and stored activations on two bf16 planes / two half planes"""
+    lq_u8, _ = make_clip(i + 2, 512, seed=seed)
+    x = torch.from_numpy(window_from_clip(lq_u8, i).astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    oc, ol, og, oln = O._conv, O._lin, O._gn, O._ln
+
+    def run(q):
+        mx = [0.0]
+        def conv(sd_, p, xx, stride=1, padding=0):
+            y = F.conv2d(q(xx), q(sd_[p + ".weight"]), sd_.get(p + ".bias"), stride=stride, padding=padding)
+            mx[0] = max(mx[0], float(xx.abs().max()), float(y.abs().max()))
+            return q(y)
+        def lin(sd_, p, xx):
+            y = F.linear(q(xx), q(sd_[p + ".weight"]), sd_.get(p + ".bias"))
+            mx[0] = max(mx[0], float(xx.abs().max()), float(y.abs().max()))
+            return q(y)
+        O._conv, O._lin = conv, lin
+        O._gn = lambda sd_, p, xx, eps=1e-6: q(og(sd_, p, xx, eps))
+        O._ln = lambda sd_, p, xx, eps=1e-5: q(oln(sd_, p, xx, eps))
+        try:
+            return O.pgtformer_forward(sd, cfg, x, w=1.0, code_only=True)[0], mx[0]
+        finally:
+            O._conv, O._lin, O._gn, O._ln = oc, ol, og, oln
+    ref, mx = run(q_id)
+    top2 = ref.topk(2, -1).values
+    gap = top2[..., 0] - top2[..., 1]
+    print(f"== clip {seed} window {i}: max |activation| {mx:.1f}, smallest top-2 logit gap {float(gap.min()):.2e}, gaps < 1e-4: {int((gap < 1e-4).sum())}", flush=True)
+    for name, q in (("two bf16 planes (16 bits)", q_x3), ("two half planes (22 bits)", q_h2)):
+        lg = run(q)[0]
+        print(f"  {name:28s} logits: max err {float((lg - ref).abs().max()):.2e}  rms {float((lg - ref).pow(2).mean().sqrt()):.2e}   "
+              f"flipped codes {int((lg.argmax(-1) != ref.argmax(-1)).sum())}/{ref.argmax(-1).numel()}", flush=True)
+
+
+def report(name, out, c):
+    ref, gt = c["ref"][1], c["gt"]
+    e, r = (out - ref).double(), (ref - gt).double()
+    rho = float((e * r).sum() / (e.norm() * r.norm()))
+    print(f"  {name:40s} PSNR(build, ref) {psnr(out, ref):6.2f} dB   dPSNR {psnr(out, gt) - psnr(ref, gt):+.2e} dB   corr(e, r) {rho:+.4f}", flush=True)
+
+
 if __name__ == "__main__":
+    mode = sys.argv[1] if len(sys.argv) > 1 and ":" not in sys.argv[1] else "levels"
+    sys.argv = [a for a in sys.argv if a != mode]
     wins = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(1234, 1), (1077, 4), (2077, 1)]
+    if mode == "planes":
+        torch.set_num_threads(8)
+        for seed, i in wins:
+            run_planes(seed, i)
+        sys.exit(0)
+    if mode in ("groups", "compensation"):
+        torch.set_num_threads(8)
+        for seed, i in wins:
+            c = encoder_side(seed, i)
+            print(f"== clip {seed} window {i}: PSNR(ref, GT) mid = {psnr(c['ref'][1], c['gt']):.3f} dB", flush=True)
+            (run_groups if mode == "groups" else run_compensation)(c)
+        sys.exit(0)
     only = os.environ.get("PGT_STUDY_ONLY")
     torch.set_num_threads(8)
     for seed, i in wins:
