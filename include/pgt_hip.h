@@ -27,18 +27,20 @@ extern "C" {
 
 typedef void* pgt_stream_t; /* hipStream_t */
 
-/* PGT_BF16X3: split-bf16 storage, value = hi + lo (hi = bf16(v), lo = bf16(v - hi)): a tensor of C logical channels
- * keeps two bf16 planes per pixel / token row, hi at channel offset 0 and lo at an explicit `*_lo` element offset (C for
- * a dense tensor, the parent's width for a channel slice); row strides count bf16 elements (>= 2C).  Products are
- * formed as hi*hi + lo*hi + hi*lo on the bf16 MFMA with fp32 accumulation (16 significand bits instead of 8): the
- * code-prediction branch runs in this type so that the arg-max codes reproduce the fp32 reference
- * (archs/pgtformer_arch.py:638-664) at bf16-MFMA speed. */
+/* PGT_F16X3: split storage on two IEEE-half planes, value = hi + lo (hi = half(v), lo = half(v - hi); conversions saturate at
+ * +-65504): a tensor of C logical channels keeps two half planes per pixel / token row, hi at channel offset 0 and lo at an
+ * explicit `*_lo` element offset (C for a dense tensor, the parent's width for a channel slice); row strides count 16-bit
+ * elements (>= 2C).  Products are formed as hi*hi + lo*hi + hi*lo on the f16 MFMA with fp32 accumulation (22 significand
+ * bits instead of 11; below 2^-3 the lo plane is subnormal and the resolution is absolute, 6e-8): the code-prediction branch
+ * runs in this type so that the arg-max codes reproduce the fp32 reference (archs/pgtformer_arch.py:638-664) at
+ * 16-bit-MFMA speed.  (Rounds 2-3a used two bf16 planes, 16 bits: its logit error of 6e-5 flipped one code in 16 000 at
+ * near-ties; the half planes bring it to 1.5e-5) */
 /* PGT_F16: IEEE half storage and operands (v_mfma_f32_32x32x16_f16, fp32 accumulate; fp32 -> half stores saturate at
  * +-65504): the decoder-side type of the default precision mode - 11 significand bits on the same MFMA rate as bf16's 8,
  * which is what holds |PSNR(build, GT) - PSNR(reference, GT)| under 1e-3 dB (reference decoder: fp32,
  * archs/pgtformer_arch.py:684-712).  Accepted by conv2d / linear, the norms, channel statistics, window attention,
  * embed_rows, copy2d, frame_to_u8, nhwc_to_nchw. */
-enum { PGT_F32 = 0, PGT_BF16 = 1, PGT_BF16X3 = 2, PGT_F16 = 3 };
+enum { PGT_F32 = 0, PGT_BF16 = 1, PGT_F16X3 = 2, PGT_F16 = 3 };
 enum { PGT_ACT_NONE = 0, PGT_ACT_RELU = 1, PGT_ACT_GELU = 2, PGT_ACT_SILU = 3, PGT_ACT_LEAKY02 = 4, PGT_ACT_SIGMOID = 5 };
 enum { PGT_EPI_PLAIN = 0, PGT_EPI_SFT = 1 };
 
@@ -79,7 +81,7 @@ typedef struct pgt_conv_desc {
      * that replace nearest-x2 up-sampling + conv3x3 (archs/tdcrqvae3_arch.py:34-52).  Plain epilogue only (no
      * residual / SFT operands); kernels 1 and 4 (and 0 = auto).                                                  */
     int32_t orow_mul, orow_xmul, orow_off;
-    /* dtype == PGT_BF16X3: element offsets of the lo planes of x, y and the residual inside a pixel row (0 = Cin / Cout /
+    /* dtype == PGT_F16X3: element offsets of the lo planes of x, y and the residual inside a pixel row (0 = Cin / Cout /
      * Cout, i.e. dense [hi | lo] tensors).  w then has 3*KH*KW*Cin columns: per filter tap and per 64-channel
      * block [w_hi | w_hi | w_lo] (64 each), matching the K order [x_hi | x_lo | x_hi] of that block.  y is split as well unless out_f32.  Kernel 4 only (bf16 MFMA,
      * Cin % 64 == 0); no SFT epilogue.                                                                              */
@@ -92,14 +94,14 @@ typedef struct pgt_conv_desc {
      * Needs Cout % 8 == 0, Ho*Wo a multiple of the kernel's tile rows (<= 512), kernels 0, 1, 4, no split-K.            */
     int32_t gn_groups, gn_sub, gn_nsub;
     int32_t gn_img0, gn_nimg;   /* this call covers images gn_img0 .. gn_img0+N-1 of a gn_nimg-image tensor (0, 0 = all N) */
-    int32_t res_f32;            /* PGT_BF16X3 with out_f32: the residual is fp32 as well (ldr in floats) - split-bf16
+    int32_t res_f32;            /* PGT_F16X3 with out_f32: the residual is fp32 as well (ldr in floats) - split-bf16
                                  * ARITHMETIC on tensors that are stored in fp32 (BiSeNet's BasicBlocks)              */
-    int32_t x3_fold;            /* PGT_BF16X3, Cout == 64: the weight matrix has 128 rows and TWO K segments per tap and
+    int32_t x3_fold;            /* PGT_F16X3, Cout == 64: the weight matrix has 128 rows and TWO K segments per tap and
                                  * 64-channel block (K = KH*KW*2*Cin, the input visited as [x_hi | x_lo]): rows 0..63 hold
                                  * [w_hi | w_hi], rows 64..127 [w_lo | 0]; y[n] = acc[n] + acc[n + 64] before activation /
                                  * residual.  A 64-channel layer then fills the 128-column tile with 2/3 of the K steps
                                  * (the standard form leaves half of the tile idle for three segments).                  */
-    int32_t dec_lo, shift_lo;   /* PGT_BF16X3 with PGT_EPI_SFT: element offsets of the lo planes of sft_dec / sft_shift
+    int32_t dec_lo, shift_lo;   /* PGT_F16X3 with PGT_EPI_SFT: element offsets of the lo planes of sft_dec / sft_shift
                                  * (0 = Cout): out = dec + sft_w * (dec * act(conv) + shift) on split operands       */
     int32_t bias_rows;          /* 0: `bias` holds Cout values.  > 0: `bias` is a (N*Ho*Wo / bias_rows, Cout) fp32 matrix, one
                                  * vector per bias_rows consecutive output pixels - a bias per frame (bias_rows = Ho*Wo; for
@@ -202,7 +204,7 @@ int pgt_mha(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ld
             int32_t ldv, void* out, int32_t ldo, int32_t B, int32_t L, int32_t heads, int32_t hd,
             float scale, pgt_stream_t stream);
 
-/* ---- split-bf16 (PGT_BF16X3) forms of the normalisation / attention entry points ------------------------------
+/* ---- split-bf16 (PGT_F16X3) forms of the normalisation / attention entry points ------------------------------
  * Same arithmetic as the functions above on tensors stored as [hi | lo] bf16 planes; every tensor argument carries the
  * element offset of its lo plane (`*_lo`) next to its row stride.  Statistics, softmax and accumulation are fp32;
  * every MFMA product is hi*hi + lo*hi + hi*lo.  Used by the code-prediction branch (encoder levels with temporal
@@ -244,7 +246,7 @@ int pgt_sample_rows(const float* prob, int32_t ld, int32_t rows, int32_t K, cons
  * The conv / linear kernels take their weights K-major; the reference stores nn.Conv2d weights as (Cout, Cin, KH, KW) and
  * nn.Linear weights as (Cout, Cin) (= KH = KW = 1).  pgt_pack_conv_weight writes the operand `pgt_conv2d` expects for
  * `dtype` from the reference tensor on the device: (Cout, KH*KW*Cin_pad) in fp32 / bf16 / half with the input channels
- * zero-padded to Cin_pad (3 -> 8, 57 -> 64, the [enc | dec | fut] concats -> multiples of 64); PGT_BF16X3: the
+ * zero-padded to Cin_pad (3 -> 8, 57 -> 64, the [enc | dec | fut] concats -> multiples of 64); PGT_F16X3: the
  * [w_hi | w_hi | w_lo]-per-64-channel-block form, or with x3_fold (Cout == 64) the folded (128, KH*KW*2*Cin_pad) form.
  * out_scale (Cout floats or NULL) multiplies every output channel in fp32 before the rounding: the eval-BatchNorm fold
  * of BiSeNet (archs/pgtformer_arch.py:40-68), whose factors and folded bias pgt_fold_batchnorm computes

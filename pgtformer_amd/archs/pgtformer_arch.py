@@ -503,7 +503,7 @@ class PGTFormer(TDCRQVAE3):
                 feat_out[self.fuse_encoder_indices[f_size]] = cats[f_size][..., :blk.in_ch]
         want = {self.fuse_encoder_indices[f] for f in self.connect_list}
         z, feats = self.encoder(raw, return_multi_res_feats=True, feat_out=feat_out, win=win, want_feats=want,
-                                feat_dtype=self.dec_dt if self.dec_dt == torch.float16 else None)
+                                feat_dtype=self.dec_dt if self.dec_dt in (torch.float16, torch.bfloat16) else None)
         enc_feat = {}
         for f_size in self.connect_list:
             f = feats[self.fuse_encoder_indices[f_size]]

@@ -344,7 +344,7 @@ class Encoder(HipModule):
     @staticmethod
     def _convert(h, cur, want):
         if _is_x3(want) and not _is_x3(cur):
-            assert cur == torch.float32, "split-bf16 levels follow fp32 levels"
+            assert cur == torch.float32, "split levels follow fp32 levels"
             return ops.to_x3(h)
         assert _is_x3(cur) == _is_x3(want) and (_is_x3(cur) or cur == want), (cur, want)
         return h
@@ -361,8 +361,8 @@ class Encoder(HipModule):
         attn_resolutions starting at 128), so it runs once per frame and is gathered to window order (B*T frames) where
         the first EncoderLayer starts.  want_feats: levels whose feature maps the caller needs (None: all); the others
         are returned as None (a per-frame 512x512 map would otherwise be gathered for nothing).
-        Feature maps of split-bf16 levels are returned as their hi planes (bf16 views), or - feat_dtype=torch.float16, the
-        IEEE-half decoder - as half tensors rounded once from hi + lo (11 significand bits instead of the hi plane's 8)."""
+        Feature maps of split levels are returned as their hi planes (half views: the value rounded to IEEE half), cast to
+        feat_dtype / the dtype of the destination where that differs (the bf16 decoder of "bf16x3")."""
         feats = []
         cur = self.conv_in.dt
         # (the level-0 block starts with a GroupNorm: statistics from conv_in's epilogue unless a dtype conversion intervenes)
@@ -391,18 +391,15 @@ class Encoder(HipModule):
             if not wanted:
                 feats.append(None)
             else:
-                if not _is_x3(cur):
-                    f = h
-                elif feat_dtype == torch.float16:
-                    f = ops.x3_to_half(h)                                        # hi + lo -> half, on the unique frames
-                else:
-                    f = h[..., :h.shape[-1] // 2]                                # hi plane of a split map
+                # a split map is handed over as its hi plane: the value rounded to IEEE half (a strided view, no pass)
+                f = h if not _is_x3(cur) else h[..., :h.shape[-1] // 2]
+                want_dt = dst.dtype if dst is not None else (feat_dtype if (feat_dtype is not None and _is_x3(cur)) else f.dtype)
                 if per_frame:     # per-frame level: cast on the unique frames, then gather to window order
-                    if dst is not None and f.dtype != dst.dtype:
-                        f = ops.cast(f, dst.dtype)
-                    f = ops.gather_frames(f, win, out=dst)
+                    f = ops.gather_frames(ops.cast(f, want_dt), win, out=dst)
                 elif dst is not None and f.data_ptr() != dst.data_ptr():
                     f = ops.copy_into(f, dst)
+                elif f.dtype != want_dt:
+                    f = ops.cast(f, want_dt)
                 feats.append(f)
             if i_level != self.num_resolutions - 1:
                 h = lvl.downsample(h)

@@ -24,17 +24,36 @@ constexpr int BKV = 64;
 constexpr int KSTR = 144;   // K tile row stride in bytes (128 + 16 pad): conflict-free ds_read_b128
 constexpr int VSTR = 136;   // V^T row stride in bytes (64 keys * 2 + 8): conflict-free ds_read_b64
 
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f2bf2(lo, hi); }   // v_cvt_pk_bf16_f32
+// 16-bit operand type of a launch: bf16 (plain bf16 rows), or the half planes of split rows (X3; common.h x3p_t)
+template <bool H> struct P16 {
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {      // {lo, hi} packed
+        if constexpr (H) return f2h2(lo, hi);
+        else return f2bf2(lo, hi);                                               // v_cvt_pk_bf16_f32
+    }
+    static __device__ __forceinline__ float lo_of(uint32_t w) {
+        if constexpr (H) return (float)__builtin_bit_cast(halfx2, w).x;
+        else return __uint_as_float(w << 16);
+    }
+    static __device__ __forceinline__ float hi_of(uint32_t w) {
+        if constexpr (H) return (float)__builtin_bit_cast(halfx2, w).y;
+        else return __uint_as_float(w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, const f32x16& c) {
+        if constexpr (H) return mma16<half_t>(a, b, c);
+        else return mma16<bf16_t>(a, b, c);
+    }
+};
 // raw v_exp_f32 (2^x): arguments here are <= 8 and results feed a bf16 operand, no range fix-up needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// X3: q, k, v and out are split-bf16 rows, lo planes qlo / klo / vlo / olo elements after the hi planes; S^T and O^T
+// X3: q, k, v and out are split rows (two half planes), lo planes qlo / klo / vlo / olo elements after the hi planes; S^T and O^T
 // take three MFMAs per product (hi*hi + lo*hi + hi*lo), P is split in registers after the exp.
 template <bool X3, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k,
                                                        int ldk, const uint16_t* __restrict__ v, int ldv,
                                                        uint16_t* __restrict__ out, int ldo, int L, float c /* scale*log2(e) */,
                                                        int qlo, int klo, int vlo, int olo) {
+    using E = P16<X3>;                                      // split rows live on half planes
     constexpr int NP = X3 ? 2 : 1;
     constexpr int PLANE = BKV * KSTR + HD * VSTR;
     constexpr int STAGE = NP * PLANE;                       // one K / V^T tile (hi [+ lo] planes)
@@ -151,13 +170,10 @@ __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __res
                 const uint4 a = *reinterpret_cast<const uint4*>(k_rd + kb * 32 * KSTR + st * 32);
                 if constexpr (X3) {   // small terms first
                     const uint4 al = *reinterpret_cast<const uint4*>(k_rd + PLANE + kb * 32 * KSTR + st * 32);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al),
-                                                                    __builtin_bit_cast(bf16x8, qf[st]), s[kb], 0, 0, 0);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                    __builtin_bit_cast(bf16x8, qfl[st]), s[kb], 0, 0, 0);
+                    s[kb] = E::mma(al, qf[st], s[kb]);
+                    s[kb] = E::mma(a, qfl[st], s[kb]);
                 }
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                __builtin_bit_cast(bf16x8, qf[st]), s[kb], 0, 0, 0);
+                s[kb] = E::mma(a, qf[st], s[kb]);
             }
         }
         if (k0 + BKV > L) {
@@ -198,17 +214,19 @@ __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __res
                 p[e] = fast_exp2(__builtin_fmaf(s[kb][e], c, -m));
                 lsum += p[e];
             }
-            pf[kb][0] = make_uint4(pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7]));
-            pf[kb][1] = make_uint4(pack2(p[8], p[9]), pack2(p[10], p[11]), pack2(p[12], p[13]), pack2(p[14], p[15]));
+            pf[kb][0] = make_uint4(E::pack2(p[0], p[1]), E::pack2(p[2], p[3]), E::pack2(p[4], p[5]), E::pack2(p[6], p[7]));
+            pf[kb][1] = make_uint4(E::pack2(p[8], p[9]), E::pack2(p[10], p[11]), E::pack2(p[12], p[13]), E::pack2(p[14], p[15]));
             if constexpr (X3) {
+                x3_opaque(pf[kb][0]);      // the lo plane is taken against the packed hi bits (common.h)
+                x3_opaque(pf[kb][1]);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const uint32_t w4[4] = {pf[kb][s2].x, pf[kb][s2].y, pf[kb][s2].z, pf[kb][s2].w};
                     uint32_t r4[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        r4[j] = pack2(p[s2 * 8 + 2 * j] - __uint_as_float(w4[j] << 16),
-                                      p[s2 * 8 + 2 * j + 1] - __uint_as_float(w4[j] & 0xffff0000u));
+                        r4[j] = E::pack2(p[s2 * 8 + 2 * j] - E::lo_of(w4[j]),
+                                      p[s2 * 8 + 2 * j + 1] - E::hi_of(w4[j]));
                     pfl[kb][s2] = make_uint4(r4[0], r4[1], r4[2], r4[3]);
                 }
             }
@@ -229,13 +247,10 @@ __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __res
                         const uint2 llo = *reinterpret_cast<const uint2*>(pa + PLANE);
                         const uint2 lhi = *reinterpret_cast<const uint2*>(pa + PLANE + 16);
                         const uint4 al = make_uint4(llo.x, llo.y, lhi.x, lhi.y);
-                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al),
-                                                                       __builtin_bit_cast(bf16x8, pf[kb][s2]), o[d], 0, 0, 0);
-                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                       __builtin_bit_cast(bf16x8, pfl[kb][s2]), o[d], 0, 0, 0);
+                        o[d] = E::mma(al, pf[kb][s2], o[d]);
+                        o[d] = E::mma(a, pfl[kb][s2], o[d]);
                     }
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                   __builtin_bit_cast(bf16x8, pf[kb][s2]), o[d], 0, 0, 0);
+                    o[d] = E::mma(a, pf[kb][s2], o[d]);
                 }
         // the other stage was last read in tile t-1, which every wave left through the barrier below
         if (more) sstore((t + 1) & 1);
@@ -253,13 +268,14 @@ __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __res
                 const float v0 = o[d][4 * g4 + 0] * inv, v1 = o[d][4 * g4 + 1] * inv;
                 const float v2 = o[d][4 * g4 + 2] * inv, v3 = o[d][4 * g4 + 3] * inv;
                 uint2 w;
-                w.x = pack2(v0, v1);
-                w.y = pack2(v2, v3);
+                w.x = E::pack2(v0, v1);
+                w.y = E::pack2(v2, v3);
+                if constexpr (X3) { x3_opaque(w.x); x3_opaque(w.y); }
                 *reinterpret_cast<uint2*>(orow + dd) = w;
                 if constexpr (X3) {
                     uint2 wl;
-                    wl.x = pack2(v0 - __uint_as_float(w.x << 16), v1 - __uint_as_float(w.x & 0xffff0000u));
-                    wl.y = pack2(v2 - __uint_as_float(w.y << 16), v3 - __uint_as_float(w.y & 0xffff0000u));
+                    wl.x = E::pack2(v0 - E::lo_of(w.x), v1 - E::hi_of(w.x));
+                    wl.y = E::pack2(v2 - E::lo_of(w.y), v3 - E::hi_of(w.y));
                     *reinterpret_cast<uint2*>(orow + olo + dd) = wl;
                 }
             }

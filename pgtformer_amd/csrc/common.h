@@ -96,23 +96,46 @@ template <> __device__ __forceinline__ f32x16 mma16<half_t>(const uint4& a, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
 }
 
-// Split-bf16 ("bf16x3") storage: value = hi + lo with hi = bf16(v), lo = bf16(v - hi) - 16 significand bits in two bf16
-// planes.  A product of two split numbers is taken as hi*hi + lo*hi + hi*lo on the bf16 MFMA (the lo*lo term is below
-// 2^-16 relative), accumulated in fp32: ~2^-17 relative error per product against 2^-9 for plain bf16.
+// Split ("x3") storage: value = hi + lo on two 16-bit planes, hi = rn16(v), lo = rn16(v - hi).  A product of two split
+// numbers is taken as hi*hi + lo*hi + hi*lo on the 16-bit MFMA (the lo*lo term is below the planes' resolution), accumulated
+// in fp32.  The plane type is IEEE half (x3p_t): 22 significand bits at the same three MFMAs per product that two bf16 planes
+// (16 bits, rounds 2-3a) take - the logit error of the code-prediction branch drops 5x, to the level of fp32 summation-order
+// noise (profiles/r3_psnr_sweep.md section 3).  Range: hi saturates at +-65504 (no inf); below 2^-3 the lo plane is subnormal
+// and the resolution is absolute (6e-8) instead of relative - the f16 MFMA keeps subnormal operands (measured).
+using x3p_t = half_t;
+// The lo plane must be taken against the hi bits that are STORED: the compiler is free to form "the half of f" twice in
+// two ways (v_cvt_pk_f16_f32 of the fp32 value for the packed store, v_fma_mixlo_f16 fused with the producing multiply for
+// the subtraction) which round differently at near-ties - seen in the window-attention epilogue, hi + lo off by one half
+// ulp on 2 of 73 728 outputs.  x3_opaque() hides the packed register from that folding (no instruction is emitted).
+__device__ __forceinline__ void x3_opaque(uint32_t& w) { asm volatile("" : "+v"(w)); }
+__device__ __forceinline__ void x3_opaque(uint4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
 __device__ __forceinline__ void split8(const float* f, uint4& hi, uint4& lo) {
-    hi = Vec16<bf16_t>::pack(f);
+    hi = Vec16<x3p_t>::pack(f);
+    x3_opaque(hi);
     float h[8], r[8];
-    Vec16<bf16_t>::unpack(hi, h);
+    Vec16<x3p_t>::unpack(hi, h);
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = f[e] - h[e];
-    lo = Vec16<bf16_t>::pack(r);
+    lo = Vec16<x3p_t>::pack(r);
 }
 __device__ __forceinline__ void merge8(const uint4& hi, const uint4& lo, float* f) {
     float l[8];
-    Vec16<bf16_t>::unpack(hi, f);
-    Vec16<bf16_t>::unpack(lo, l);
+    Vec16<x3p_t>::unpack(hi, f);
+    Vec16<x3p_t>::unpack(lo, l);
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] += l[e];
+}
+// two values -> one dword of each plane ({a, b} packed)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = f2h2(a, b);
+    x3_opaque(hi);
+    const halfx2 h = __builtin_bit_cast(halfx2, hi);
+    lo = f2h2(a - (float)h.x, b - (float)h.y);
+}
+__device__ __forceinline__ float x3_hi_of(float f) {      // value of the hi plane of f (opaque: see x3_opaque)
+    uint32_t w = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)sat_half(f));
+    x3_opaque(w);
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)w);
 }
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_LEAKY02 = 4, ACT_SIGMOID = 5 };

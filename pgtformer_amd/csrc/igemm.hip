@@ -407,7 +407,7 @@ template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm,
 
 // number of K slices pgt_conv2d_ws would use for this layer (1 = single pass)
 static int planned_splitk(const pgt_conv_desc* d) {
-    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_BF16X3 || d->gn_groups > 0) return 1;
+    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_F16X3 || d->gn_groups > 0) return 1;
     const long M = (long)d->N * d->Ho * d->Wo;
     const int K = d->KH * d->KW * d->Cin;
     const int bk = d->dtype == PGT_F32 ? 32 : 64;
@@ -428,8 +428,8 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
                              const void* residual, const void* sft_dec, const void* sft_shift, void* y,
                              void* workspace, size_t workspace_bytes, pgt_stream_t stream) {
     PGT_CHECK(d && x && w && y, "pgt_conv2d: null argument");
-    PGT_CHECK(d->dtype == PGT_F32 || d->dtype == PGT_BF16 || d->dtype == PGT_BF16X3 || d->dtype == PGT_F16, "pgt_conv2d: bad dtype %d", d->dtype);
-    const bool x3 = d->dtype == PGT_BF16X3;
+    PGT_CHECK(d->dtype == PGT_F32 || d->dtype == PGT_BF16 || d->dtype == PGT_F16X3 || d->dtype == PGT_F16, "pgt_conv2d: bad dtype %d", d->dtype);
+    const bool x3 = d->dtype == PGT_F16X3;
     const bool f16 = d->dtype == PGT_F16;
     const int es = d->dtype == PGT_F32 ? 4 : 2;
     const int ch = 16 / es;
@@ -480,9 +480,9 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     PGT_CHECK(d->bias_rows == 0 || (bias && d->bias_rows > 0 && d->bias_rows % 512 == 0 && p.M % d->bias_rows == 0 && !x3 &&
                                     d->kernel != 2 && d->kernel != 3),
               "pgt_conv2d: bias_rows=%d (a bias vector per frame) needs a bias, a multiple of 512 rows that divides M=%d, a single-plane dtype and kernel 0, 1, 4, 5 or 6", d->bias_rows, p.M);
-    PGT_CHECK(!d->x3_fold || (x3 && d->Cout == 64 && d->gn_groups == 0), "pgt_conv2d: x3_fold is the 64-output-channel form of dtype PGT_BF16X3 (no statistics epilogue)");
+    PGT_CHECK(!d->x3_fold || (x3 && d->Cout == 64 && d->gn_groups == 0), "pgt_conv2d: x3_fold is the 64-output-channel form of dtype PGT_F16X3 (no statistics epilogue)");
     p.res_f32 = (x3 && d->res_f32) ? 1 : 0;
-    PGT_CHECK(!d->res_f32 || (x3 && d->out_f32), "pgt_conv2d: res_f32 goes with dtype PGT_BF16X3 and out_f32");
+    PGT_CHECK(!d->res_f32 || (x3 && d->out_f32), "pgt_conv2d: res_f32 goes with dtype PGT_F16X3 and out_f32");
     p.xlo = d->x_lo ? d->x_lo : d->Cin;
     p.ylo = d->y_lo ? d->y_lo : d->Cout;
     p.rlo = d->r_lo ? d->r_lo : d->Cout;

@@ -360,15 +360,15 @@ template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T
 // tiles; bn = 128: 512x128 tiles.  Returns 1 if the tile is not built.
 int pgt_igemm4_launch(const void* pv, int bn, hipStream_t st) {
     const ConvP& p = *reinterpret_cast<const ConvP*>(pv);
-    if (p.x3) {   // split-bf16 operands (no up-sampled inputs on that path)
+    if (p.x3) {   // split operands on two half planes (no up-sampled inputs on that path)
         if (p.ups) return 1;
         if (p.gn_part) {
-            if (bn == 256) return launch4<2, 4, false, true, true>(p, st);
-            if (bn == 128) return launch4<4, 2, false, true, true>(p, st);
+            if (bn == 256) return launch4<2, 4, false, true, true, x3p_t>(p, st);
+            if (bn == 128) return launch4<4, 2, false, true, true, x3p_t>(p, st);
             return 1;
         }
-        if (bn == 256) return launch4<2, 4, false, true>(p, st);
-        if (bn == 128) return launch4<4, 2, false, true>(p, st);
+        if (bn == 256) return launch4<2, 4, false, true, false, x3p_t>(p, st);
+        if (bn == 128) return launch4<4, 2, false, true, false, x3p_t>(p, st);
         return 1;
     }
     if (p.f16) {   // IEEE half operands (PGT_F16): the same schedule on v_mfma_f32_32x32x16_f16

@@ -1,4 +1,4 @@
-// 3x3 convolution, 64 input channels, <= 64 output channels on SPLIT-bf16 operands (PGT_BF16X3): the full-resolution
+// 3x3 convolution, 64 input channels, <= 64 output channels on SPLIT-bf16 operands (PGT_F16X3): the full-resolution
 // levels of the encoder (64 -> 64 at 512x512, the code-prediction branch).  On the 256- / 128-wide tiles of igemm4.hip a
 // 64-channel layer idles half of the tile or, in the folded form, spends a fourth product on a zero quadrant; either way
 // the operands stream through LDS once per filter tap.
@@ -15,7 +15,7 @@
 //     (bias, activation, split residual, split8 -> hi / lo planes).  54 KiB of LDS and <= 256 VGPRs per 4-wave workgroup:
 //     two workgroups share a CU, one computes while the other waits for its DMA or stores its tile.
 //
-// Preconditions (caller): PGT_BF16X3 with split or fp32 output (then an fp32 residual), KH = KW = 3, stride 1, pad 1, Cin == 64, Cout in {16, 32, 48, 64},
+// Preconditions (caller): PGT_F16X3 with split or fp32 output (then an fp32 residual), KH = KW = 3, stride 1, pad 1, Cin == 64, Cout in {16, 32, 48, 64},
 // Ho == H, Wo == W, W and H powers of two, W >= 32, H*W >= 64, input < 2 GiB, plain epilogue (no SFT, no statistics).
 #include "common.h"
 #include "pgt_internal.h"
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvP p, int nti
         const int r = mt * 16 + col;
         e0[mt] = (r >> s_shift) * S2 + (r & (S - 1));
     }
-    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.res);
+    const x3p_t* res = reinterpret_cast<const x3p_t*>(p.res);
     float* stage = reinterpret_cast<float*>(smem);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -132,13 +132,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvP p, int nti
                     // consecutive MFMAs never share an accumulator
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[mt]), __builtin_bit_cast(bf16x8, whi[t][ks]), acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(halfx8, al[mt]), __builtin_bit_cast(halfx8, whi[t][ks]), acc[mt], 0, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt]), __builtin_bit_cast(bf16x8, wlo[t][ks]), acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(halfx8, ah[mt]), __builtin_bit_cast(halfx8, wlo[t][ks]), acc[mt], 0, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt]), __builtin_bit_cast(bf16x8, whi[t][ks]), acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(halfx8, ah[mt]), __builtin_bit_cast(halfx8, whi[t][ks]), acc[mt], 0, 0, 0);
                 }
             }
         __syncthreads();   // every wave is done with the images
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvP p, int nti
                 if (p.res_f32) {      // split arithmetic on fp32-stored tensors (BiSeNet's BasicBlocks)
                     load8<float>(reinterpret_cast<const float*>(p.res) + (long)m * p.ldr + c8, r);
                 } else {
-                    const bf16_t* rp = res + (long)m * p.ldr + c8;
+                    const x3p_t* rp = res + (long)m * p.ldr + c8;
                     merge8(*reinterpret_cast<const uint4*>(rp), *reinterpret_cast<const uint4*>(rp + p.rlo), r);
                 }
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvP p, int nti
             }
             uint4 hi, lo;
             split8(v, hi, lo);
-            bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + (long)m * p.ldy + c8;
+            x3p_t* yp = reinterpret_cast<x3p_t*>(p.y) + (long)m * p.ldy + c8;
             *reinterpret_cast<uint4*>(yp) = hi;
             *reinterpret_cast<uint4*>(yp + p.ylo) = lo;
         }

@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(const char* __restri
     *reinterpret_cast<uint4*>(dst + ((long)f * rows + r) * dst_row_stride + (long)c * 16) = v;
 }
 
-// fp32 (rows, cols) -> split-bf16 planes (hi at dst, lo at dst + dlo), 8 columns per thread
-__global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int lds, bf16_t* __restrict__ dst, int ldd,
+// fp32 (rows, cols) -> split planes (hi at dst, lo at dst + dlo), 8 columns per thread
+__global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ src, int lds, x3p_t* __restrict__ dst, int ldd,
                                                        int dlo, long rows, int cols8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols8) return;
@@ -275,9 +275,9 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__
     *reinterpret_cast<uint4*>(dst + r * ldd + c) = hi;
     *reinterpret_cast<uint4*>(dst + r * ldd + dlo + c) = lo;
 }
-// split-bf16 planes -> fp32 or IEEE half (hi + lo carries 16 significand bits: half keeps 11 of them, the bf16 hi plane alone 8)
+// split planes -> fp32, or IEEE half (the value rounded to half: the hi plane, up to ties)
 template <typename D>
-__global__ __launch_bounds__(256) void x3_merge_kernel(const bf16_t* __restrict__ src, int lds, int slo, D* __restrict__ dst,
+__global__ __launch_bounds__(256) void x3_merge_kernel(const x3p_t* __restrict__ src, int lds, int slo, D* __restrict__ dst,
                                                        int ldd, long rows, int cols8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols8) return;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 // the block's input planes as [x_hi | x_lo | x_hi]).  Folded (Cout == 64): (128, KH*KW*2*Cin_pad), rows 0..63 [w_hi | w_hi],
 // rows 64..127 [w_lo | 0] per tap and block (pgt_conv_desc::x3_fold).
 __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int Cin_pad,
-                                                             const float* __restrict__ scale, bf16_t* __restrict__ out, int fold) {
+                                                             const float* __restrict__ scale, x3p_t* __restrict__ out, int fold) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int taps = KH * KW;
     if (i >= (long)Cout * taps * Cin_pad) return;
@@ -427,22 +427,23 @@ __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* __rest
     const int co = (int)(i / ((long)Cin_pad * taps));
     float v = 0.f;
     if (ci < Cin) v = __fmul_rn(w[((long)co * Cin + ci) * taps + tap], scale ? scale[co] : 1.f);
-    const uint16_t hi = f2bf(v);
-    const uint16_t lo = f2bf(v - bf2f(hi));
+    const float hf = x3_hi_of(v);
+    const _Float16 hi = (_Float16)hf;
+    const _Float16 lo = (_Float16)sat_half(v - hf);
     const int nblk = Cin_pad / 64, blk = ci / 64, c = ci % 64;
     if (!fold) {
-        bf16_t* o = out + (long)co * taps * 3 * Cin_pad + ((long)tap * nblk + blk) * 192 + c;
+        x3p_t* o = out + (long)co * taps * 3 * Cin_pad + ((long)tap * nblk + blk) * 192 + c;
         o[0].v = hi;
         o[64].v = hi;
         o[128].v = lo;
     } else {
         const long rowlen = (long)taps * 2 * Cin_pad, off = ((long)tap * nblk + blk) * 128 + c;
-        bf16_t* top = out + (long)co * rowlen + off;
-        bf16_t* bot = out + (long)(64 + co) * rowlen + off;
+        x3p_t* top = out + (long)co * rowlen + off;
+        x3p_t* bot = out + (long)(64 + co) * rowlen + off;
         top[0].v = hi;
         top[64].v = hi;
         bot[0].v = lo;
-        bot[64].v = 0;
+        bot[64].v = (_Float16)0.f;
     }
 }
 // eval-mode BatchNorm2d folded into the preceding conv: s = gamma / sqrt(var + eps), bias' = (bias - mean) * s + beta
@@ -572,6 +573,8 @@ extern "C" int pgt_copy2d(int32_t src_dtype, const void* src, int32_t lds, int32
         hipLaunchKernelGGL((copy2d_kernel<half_t, half_t>), g, b, 0, st, (const half_t*)src, lds, (half_t*)dst, ldd, (long)rows, cols);
     else if (src_dtype == PGT_BF16 && dst_dtype == PGT_F16)
         hipLaunchKernelGGL((copy2d_kernel<bf16_t, half_t>), g, b, 0, st, (const bf16_t*)src, lds, (half_t*)dst, ldd, (long)rows, cols);
+    else if (src_dtype == PGT_F16 && dst_dtype == PGT_BF16)
+        hipLaunchKernelGGL((copy2d_kernel<half_t, bf16_t>), g, b, 0, st, (const half_t*)src, lds, (bf16_t*)dst, ldd, (long)rows, cols);
     else
         PGT_CHECK(false, "copy2d: bad dtypes %d -> %d", src_dtype, dst_dtype);
     PGT_LAUNCH_CHECK();
@@ -629,7 +632,7 @@ extern "C" int pgt_x3_split(const float* src, int32_t lds, void* dst, int32_t ld
     PGT_CHECK(src && dst && cols % 8 == 0 && lds % 4 == 0 && ldd % 8 == 0 && dst_lo % 8 == 0 && dst_lo >= cols &&
               ldd >= dst_lo + cols && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "x3_split: bad argument / alignment");
     hipLaunchKernelGGL(x3_split_kernel, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream, src, lds,
-                       (bf16_t*)dst, ldd, dst_lo, (long)rows, cols / 8);
+                       (x3p_t*)dst, ldd, dst_lo, (long)rows, cols / 8);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -639,7 +642,7 @@ extern "C" int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float*
     PGT_CHECK(src && dst && cols % 8 == 0 && lds % 8 == 0 && ldd % 4 == 0 && src_lo % 8 == 0 && lds >= src_lo + cols &&
               ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "x3_merge: bad argument / alignment");
     hipLaunchKernelGGL(x3_merge_kernel<float>, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)src, lds, src_lo, dst, ldd, (long)rows, cols / 8);
+                       (const x3p_t*)src, lds, src_lo, dst, ldd, (long)rows, cols / 8);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -649,7 +652,7 @@ extern "C" int pgt_x3_to_half(const void* src, int32_t lds, int32_t src_lo, void
     PGT_CHECK(src && dst && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && src_lo % 8 == 0 && lds >= src_lo + cols &&
               ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "x3_to_half: bad argument / alignment");
     hipLaunchKernelGGL(x3_merge_kernel<half_t>, grid1d((long)rows * (cols / 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)src, lds, src_lo, (half_t*)dst, ldd, (long)rows, cols / 8);
+                       (const x3p_t*)src, lds, src_lo, (half_t*)dst, ldd, (long)rows, cols / 8);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -716,7 +719,7 @@ extern "C" size_t pgt_packed_weight_bytes(int32_t dtype, int32_t Cout, int32_t C
     const size_t k = (size_t)KH * KW * Cin_pad;
     if (dtype == PGT_F32) return (size_t)Cout * k * 4;
     if (dtype == PGT_BF16 || dtype == PGT_F16) return (size_t)Cout * k * 2;
-    if (dtype == PGT_BF16X3) return x3_fold ? (size_t)128 * 2 * k * 2 : (size_t)Cout * 3 * k * 2;
+    if (dtype == PGT_F16X3) return x3_fold ? (size_t)128 * 2 * k * 2 : (size_t)Cout * 3 * k * 2;
     return 0;
 }
 
@@ -726,14 +729,14 @@ extern "C" int pgt_pack_conv_weight(int32_t dtype, const float* w_oihw, int32_t 
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)Cout * KH * KW * Cin_pad;
     const dim3 g = grid1d(total);
-    if (dtype == PGT_BF16X3) {
+    if (dtype == PGT_F16X3) {
         PGT_CHECK(Cin_pad % 64 == 0, "pack_conv_weight: split-bf16 weights come in 64-channel K blocks (Cin_pad=%d)", Cin_pad);
         PGT_CHECK(!x3_fold || Cout == 64, "pack_conv_weight: the folded form is for 64 output channels (Cout=%d)", Cout);
-        hipLaunchKernelGGL(pack_weight_x3_kernel, g, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (bf16_t*)packed, x3_fold);
+        hipLaunchKernelGGL(pack_weight_x3_kernel, g, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (x3p_t*)packed, x3_fold);
         PGT_LAUNCH_CHECK();
         return 0;
     }
-    PGT_CHECK(!x3_fold, "pack_conv_weight: x3_fold goes with dtype PGT_BF16X3");
+    PGT_CHECK(!x3_fold, "pack_conv_weight: x3_fold goes with dtype PGT_F16X3");
     DT_DISPATCH_T(dtype, "pack_conv_weight",
                   hipLaunchKernelGGL((pack_weight_kernel<T_>), g, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (T_*)packed));
 }

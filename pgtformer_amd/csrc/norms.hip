@@ -11,7 +11,7 @@ constexpr int kT = 256;
 // GroupNorm statistics, stage 1: per (image, pixel-chunk) partial sum / sum-of-squares per group.
 // Thread -> (pixel slot, 16-byte channel chunk); the chunk is fixed per thread, pixels strided.
 // ---------------------------------------------------------------------------------------------
-// X3: x is a split-bf16 tensor (T = bf16_t): the value of a channel is hi + lo, the lo plane sits xlo elements
+// X3: x is a split tensor (T = x3p_t planes): the value of a channel is hi + lo, the lo plane sits xlo elements
 // after the hi plane in every pixel row.
 template <typename T, int NQ, bool X3 = false>
 __global__ __launch_bounds__(kT) void gn_partial_kernel(const T* __restrict__ x, int ldx, int HW, int C, int groups,
@@ -321,7 +321,7 @@ template <int EPL> struct RowIO<float, EPL, true> {    // EPL in {4, 8, 16}
     }
 };
 
-// X3 (T = bf16_t): x, y, pos and y2 are split-bf16 rows, the lo plane xlo / ylo / plo / y2lo elements after the hi plane.
+// X3 (T = x3p_t): x, y, pos and y2 are split rows, the lo plane xlo / ylo / plo / y2lo elements after the hi plane.
 // RPW rows per wavefront: all of their loads are issued before the first reduction (one 8- or 16-byte load per lane in
 // flight ran the C = 256 half layers at 3.5 TB/s; the per-row arithmetic and reduction order are unchanged).
 template <typename T, int EPL, bool VEC, bool X3 = false, int RPW = 1>
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kT) void layernorm_kernel(const T* __restrict__ x, 
         if constexpr (X3) {
             float hf[EPL], lf[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) { hf[e] = bf2f(f2bf(f[e])); lf[e] = f[e] - hf[e]; }
+            for (int e = 0; e < EPL; ++e) { hf[e] = x3_hi_of(f[e]); lf[e] = f[e] - hf[e]; }
             IO::st(dst, hf);
             IO::st(dst + lo_off, lf);
         } else {
@@ -650,7 +650,7 @@ extern "C" int pgt_groupnorm_affine_x3(const void* x, int32_t ldx, int32_t x_lo,
                                        float* shift, void* workspace, size_t workspace_bytes, pgt_stream_t stream) {
     PGT_CHECK(x && gamma && beta && scale && shift && workspace, "groupnorm_x3: null argument");
     PGT_CHECK(((uintptr_t)x & 15) == 0 && x_lo % 8 == 0 && x_lo >= C && ldx >= x_lo + C, "groupnorm_x3: bad planes (ldx=%d x_lo=%d C=%d)", ldx, x_lo, C);
-    return gn_affine_impl<bf16_t, true>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream, x_lo);
+    return gn_affine_impl<x3p_t, true>(x, ldx, N, HW, C, groups, eps, gamma, beta, scale, shift, workspace, workspace_bytes, (hipStream_t)stream, x_lo);
 }
 
 extern "C" int pgt_affine_act_x3(const void* x, int32_t ldx, int32_t x_lo, void* y, int32_t ldy, int32_t y_lo, int32_t N,
@@ -659,7 +659,7 @@ extern "C" int pgt_affine_act_x3(const void* x, int32_t ldx, int32_t x_lo, void*
     PGT_CHECK(x && y && scale && shift, "affine_act_x3: null argument");
     PGT_CHECK((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && x_lo % 8 == 0 && y_lo % 8 == 0 && ldx >= x_lo + C && ldy >= y_lo + C &&
               x_lo >= C && y_lo >= C, "affine_act_x3: bad planes");
-    return affine_act_impl<bf16_t, true>(x, ldx, y, ldy, N, HW, C, scale, shift, act, (hipStream_t)stream, x_lo, y_lo);
+    return affine_act_impl<x3p_t, true>(x, ldx, y, ldy, N, HW, C, scale, shift, act, (hipStream_t)stream, x_lo, y_lo);
 }
 
 template <typename T, bool X3 = false>
@@ -700,7 +700,7 @@ extern "C" int pgt_layernorm_x3(const void* x, int32_t ldx, int32_t x_lo, int32_
     PGT_CHECK(!y2 || pos, "layernorm_x3: y2 requested without pos");
     PGT_CHECK(x_lo >= C && y_lo >= C && ldx >= x_lo + C && ldy >= y_lo + C, "layernorm_x3: bad planes");
     PGT_CHECK(!y2 || (pos_lo >= C && y2_lo >= C && ldpos >= pos_lo + C && ldy2 >= y2_lo + C), "layernorm_x3: bad pos / y2 planes");
-    return layernorm_impl<bf16_t, true>(x, ldx, rows, C, gamma, beta, eps, y, ldy, pos, ldpos, y2, ldy2, (hipStream_t)stream,
+    return layernorm_impl<x3p_t, true>(x, ldx, rows, C, gamma, beta, eps, y, ldy, pos, ldpos, y2, ldy2, (hipStream_t)stream,
                                         x_lo, y_lo, pos_lo, y2_lo);
 }
 

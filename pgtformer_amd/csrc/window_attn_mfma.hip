@@ -32,6 +32,14 @@ template <bool F16> struct El {
             return f2bf2(lo, hi);
         }
     }
+    static __device__ __forceinline__ float lo_of(uint32_t w) {      // the two values of a packed dword
+        if constexpr (F16) return (float)__builtin_bit_cast(half2v, w).x;
+        else return __uint_as_float(w << 16);
+    }
+    static __device__ __forceinline__ float hi_of(uint32_t w) {
+        if constexpr (F16) return (float)__builtin_bit_cast(half2v, w).y;
+        else return __uint_as_float(w & 0xffff0000u);
+    }
     static __device__ __forceinline__ f32x4 mma32(const uint4& a, const uint4& b, f32x4 c) {   // 16x16x32
         if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, a), __builtin_bit_cast(half8v, b), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -42,7 +50,7 @@ template <bool F16> struct El {
     }
 };
 
-// X3: qkv and out are split-bf16 rows (hi plane at the usual columns, lo plane qlo / olo elements further): every
+// X3: qkv and out are split rows on two half planes (hi plane at the usual columns, lo plane qlo / olo elements further): every
 // product is taken as hi*hi + lo*hi + hi*lo (S^T from q, k; O^T from P, V with P split in registers after the exp).
 // Windows are (wd, wh, ww) blocks of the (D, H, W) token grid with a cyclic shift (sd, sh, sw) and the 27-region mask of
 // modules/swin.py:311-323; the PGTFormer layers use wd = D, sd = 0 (all frames of a spatial window in one group).
@@ -52,8 +60,8 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
                                                                    const float* __restrict__ bias, int T_, int H, int W,
                                                                    int C, int heads, int wh, int ww, int sh, int sw,
                                                                    int qlo, int olo, int wd, int sd) {
-    static_assert(!(X3 && F16), "the split type is bf16");
-    typedef El<F16> EL;
+    static_assert(!(X3 && F16), "X3 selects the split rows (half planes), F16 plain half rows");
+    typedef El<F16 || X3> EL;
     constexpr int N = 48 * NW;
     constexpr int VSTR = N * 2 + 8;   // V^T row stride in bytes (keys contiguous, 8-byte pad)
     constexpr int KS = HD / 32;       // k-steps of the S^T MFMA
@@ -200,9 +208,11 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
                 }
                 pf[kt] = make_uint2(EL::pack2(p[0], p[1]), EL::pack2(p[2], p[3]));
                 if constexpr (X3) {
-                    const float r0 = p[0] - __uint_as_float(pf[kt].x << 16), r1 = p[1] - __uint_as_float(pf[kt].x & 0xffff0000u);
-                    const float r2 = p[2] - __uint_as_float(pf[kt].y << 16), r3 = p[3] - __uint_as_float(pf[kt].y & 0xffff0000u);
-                    pl2[kt] = make_uint2(f2bf2(r0, r1), f2bf2(r2, r3));
+                    x3_opaque(pf[kt].x);      // the lo plane is taken against the packed hi bits (common.h)
+                    x3_opaque(pf[kt].y);
+                    const float r0 = p[0] - EL::lo_of(pf[kt].x), r1 = p[1] - EL::hi_of(pf[kt].x);
+                    const float r2 = p[2] - EL::lo_of(pf[kt].y), r3 = p[3] - EL::hi_of(pf[kt].y);
+                    pl2[kt] = make_uint2(EL::pack2(r0, r1), EL::pack2(r2, r3));
                 }
             }
             l[qt] = l[qt] * alpha + lsum;
@@ -233,11 +243,12 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const float v0 = o[qt][dt][0] * inv, v1 = o[qt][dt][1] * inv, v2 = o[qt][dt][2] * inv, v3 = o[qt][dt][3] * inv;
-            const uint2 w2 = make_uint2(EL::pack2(v0, v1), EL::pack2(v2, v3));
+            uint2 w2 = make_uint2(EL::pack2(v0, v1), EL::pack2(v2, v3));
+            if constexpr (X3) { x3_opaque(w2.x); x3_opaque(w2.y); }
             *reinterpret_cast<uint2*>(orow + dt * 16) = w2;
             if constexpr (X3) {
-                const uint2 wl = make_uint2(f2bf2(v0 - __uint_as_float(w2.x << 16), v1 - __uint_as_float(w2.x & 0xffff0000u)),
-                                            f2bf2(v2 - __uint_as_float(w2.y << 16), v3 - __uint_as_float(w2.y & 0xffff0000u)));
+                const uint2 wl = make_uint2(EL::pack2(v0 - EL::lo_of(w2.x), v1 - EL::hi_of(w2.x)),
+                                            EL::pack2(v2 - EL::lo_of(w2.y), v3 - EL::hi_of(w2.y)));
                 *reinterpret_cast<uint2*>(orow + olo + dt * 16) = wl;
             }
         }

@@ -9,7 +9,7 @@ import os
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpgt_hip.so")
 
-PGT_F32, PGT_BF16, PGT_BF16X3, PGT_F16 = 0, 1, 2, 3
+PGT_F32, PGT_BF16, PGT_F16X3, PGT_F16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_LEAKY02, ACT_SIGMOID = range(6)
 EPI_PLAIN, EPI_SFT = 0, 1
 

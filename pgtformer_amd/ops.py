@@ -12,14 +12,16 @@ import torch
 
 from . import hip
 from .hip import (ACT_GELU, ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU,  # noqa: F401
-                  EPI_PLAIN, EPI_SFT, PGT_BF16, PGT_BF16X3, PGT_F32)
+                  EPI_PLAIN, EPI_SFT, PGT_BF16, PGT_F16X3, PGT_F32)
 
-# "dtype" tag of split-bf16 modules / tensors (include/pgt_hip.h: PGT_BF16X3).  A split tensor with C logical channels
-# is a torch.bfloat16 tensor whose last dim is 2C: [hi (C) | lo (C)], value = hi + lo.  The ops below take `x3=True` for
-# such operands; reshapes over the leading dims work unchanged, the hi plane `t[..., :C]` is a valid bf16 view of the
-# rounded tensor.
-X3 = "bf16x3"
-X3F = "bf16x3/f32"      # split-bf16 arithmetic, fp32 storage: the module splits its fp32 input on the way in, writes fp32
+# "dtype" tag of split modules / tensors (include/pgt_hip.h: PGT_F16X3).  A split tensor with C logical channels is an
+# X3_PLANE (torch.float16) tensor whose last dim is 2C: [hi (C) | lo (C)], value = hi + lo: two IEEE-half planes, 22
+# significand bits, three MFMAs per product (two bf16 planes - 16 bits - until round 3's sweep of the code flips,
+# profiles/r3_psnr_sweep.md).  The ops below take `x3=True` for such operands; reshapes over the leading dims work unchanged,
+# the hi plane `t[..., :C]` is a valid half view of the rounded tensor.
+X3 = "f16x3"
+X3F = "f16x3/f32"       # split arithmetic, fp32 storage: the module splits its fp32 input on the way in, writes fp32
+X3_PLANE = torch.float16
 # GroupNorm statistics from the producing conv's epilogue (PGT_EPILOGUE_GN=0: always the separate statistics pass)
 import os as _os
 USE_EPILOGUE_GN = _os.environ.get("PGT_EPILOGUE_GN", "1") != "0"
@@ -60,8 +62,8 @@ def pack_x3_weight(w3):
     w3 = w3.float()
     cout, taps, cin = w3.shape
     assert cin % 64 == 0, "split-bf16 operands come in 64-channel K blocks"
-    hi = w3.to(torch.bfloat16)
-    lo = (w3 - hi.float()).to(torch.bfloat16)
+    hi = w3.to(X3_PLANE)
+    lo = (w3 - hi.float()).to(X3_PLANE)
     hi4, lo4 = hi.reshape(cout, taps, cin // 64, 1, 64), lo.reshape(cout, taps, cin // 64, 1, 64)
     return torch.cat([hi4, hi4, lo4], 3).reshape(cout, -1).contiguous()
 
@@ -74,8 +76,8 @@ def pack_x3_fold_weight(w3):
     w3 = w3.float()
     cout, taps, cin = w3.shape
     assert cout == 64 and cin % 64 == 0
-    hi = w3.to(torch.bfloat16)
-    lo = (w3 - hi.float()).to(torch.bfloat16)
+    hi = w3.to(X3_PLANE)
+    lo = (w3 - hi.float()).to(X3_PLANE)
     hi4, lo4 = hi.reshape(cout, taps, cin // 64, 1, 64), lo.reshape(cout, taps, cin // 64, 1, 64)
     top = torch.cat([hi4, hi4], 3).reshape(cout, -1)
     bot = torch.cat([lo4, torch.zeros_like(lo4)], 3).reshape(cout, -1)
@@ -86,7 +88,7 @@ def _dtype_code(dtype):
     """model-side dtype tag -> (C-ABI dtype, torch storage dtype)"""
     if isinstance(dtype, str):
         assert dtype in (X3, X3F), dtype
-        return PGT_BF16X3, torch.bfloat16
+        return PGT_F16X3, X3_PLANE
     return {torch.float32: PGT_F32, torch.bfloat16: PGT_BF16, torch.float16: hip.PGT_F16}[dtype], dtype
 
 
@@ -131,7 +133,7 @@ def to_x3(x, out=None):
     else:
         rows, lds = x2.shape[0], c
     if out is None:
-        out = torch.empty(tuple(x.shape[:-1]) + (2 * c,), device=x.device, dtype=torch.bfloat16)
+        out = torch.empty(tuple(x.shape[:-1]) + (2 * c,), device=x.device, dtype=X3_PLANE)
     assert out.is_contiguous() and out.shape[-1] == 2 * c
     with _Prof("x3_convert", 0, _nb(x, out)):
         hip.check(hip.lib().pgt_x3_split(_p(x), lds, _p(out), 2 * c, c, rows, c, _stream()), "pgt_x3_split")
@@ -140,7 +142,7 @@ def to_x3(x, out=None):
 
 def x3_to_half(x, out=None):
     """split-bf16 (..., 2C) -> IEEE half (..., C) (hi + lo rounded once: 11 significand bits; the hi plane alone has 8)."""
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 2 == 0
+    assert x.dtype == X3_PLANE and x.is_contiguous() and x.shape[-1] % 2 == 0
     c = x.shape[-1] // 2
     if out is None:
         out = torch.empty(tuple(x.shape[:-1]) + (c,), device=x.device, dtype=torch.float16)
@@ -152,7 +154,7 @@ def x3_to_half(x, out=None):
 
 def from_x3(x):
     """split-bf16 (..., 2C) -> fp32 (..., C)."""
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 2 == 0
+    assert x.dtype == X3_PLANE and x.is_contiguous() and x.shape[-1] % 2 == 0
     c = x.shape[-1] // 2
     out = torch.empty(tuple(x.shape[:-1]) + (c,), device=x.device, dtype=torch.float32)
     with _Prof("x3_convert", 0, _nb(x, out)):
@@ -333,7 +335,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     if x3:   # split-bf16 operands: x (N,H,W,2*Cin) = [hi | lo], w (Cout, kh*kw*3*Cin), y (N,Ho,Wo,2*Cout) unless out_f32
-        assert x.dtype == torch.bfloat16 and cin % 2 == 0 and sft is None and not ups and out_rows is None and out_parity is None
+        assert x.dtype == X3_PLANE and cin % 2 == 0 and sft is None and not ups and out_rows is None and out_parity is None
         cin //= 2
         if x3_fold:   # 64 output channels, w = pack_x3_fold_weight(...): (128, kh*kw*2*Cin)
             assert cout == 128 and w.shape[1] == kh * kw * 2 * cin and gn is None, (w.shape, kh, kw, cin)
@@ -383,7 +385,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
             out = torch.empty((n, ho, wo, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
         assert tuple(out.shape) == (n, ho, wo, cst), (out.shape, (n, ho, wo, cst))
     d = hip.ConvDesc()
-    d.dtype = PGT_BF16X3 if x3 else _dt(x)
+    d.dtype = PGT_F16X3 if x3 else _dt(x)
     d.N, d.H, d.W, d.Cin, d.ldx, d.ups = n, h, wd, cin, _ld_img(x), int(ups)
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l = kh, kw, stride, pad[0], pad[2]
     d.Ho, d.Wo, d.Cout, d.ldy = ho, wo, cout, _ld_img(out)
@@ -614,7 +616,7 @@ def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
     """qkv (B*T*H*W, 3C) -> (B*T*H*W, C); x3: split-bf16 rows (.., 6C) = [hi q k v | lo q k v] -> (.., 2C)."""
     rows = B * T * H * W
     if x3:
-        assert tuple(qkv.shape) == (rows, 6 * C_) and qkv.dtype == torch.bfloat16
+        assert tuple(qkv.shape) == (rows, 6 * C_) and qkv.dtype == X3_PLANE
         out = torch.empty((rows, 2 * C_), device=qkv.device, dtype=qkv.dtype)
         with _Prof("window_attention", 4.0 * rows * (T * win[0] * win[1]) * C_, _nb(qkv, out), x3=True):
             hip.check(hip.lib().pgt_window_attention_x3(_p(qkv), _ld_rows(qkv), 3 * C_, _p(out), 2 * C_, C_, _p(bias), B, T, H,

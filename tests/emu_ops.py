@@ -28,15 +28,23 @@ def _act(v, act):
 
 
 def _merge(x):
-    """split-bf16 (..., 2C) -> fp32 (..., C)"""
+    """split (..., 2C) -> fp32 (..., C)"""
     c = x.shape[-1] // 2
     return x[..., :c].float() + x[..., c:].float()
 
 
+X3_PLANE = torch.float16      # plane type of split tensors (pgtformer_amd.ops.X3_PLANE)
+
+
+def _plane(v):
+    """fp32 -> one plane: IEEE half, saturating at +-65504 like the kernels' conversions"""
+    return v.clamp(-65504.0, 65504.0).to(X3_PLANE)
+
+
 def _split(v):
-    """fp32 (..., C) -> split-bf16 (..., 2C): hi = bf16(v), lo = bf16(v - hi)"""
-    hi = v.to(torch.bfloat16)
-    lo = (v - hi.float()).to(torch.bfloat16)
+    """fp32 (..., C) -> split (..., 2C) on two half planes: hi = half(v), lo = half(v - hi)"""
+    hi = _plane(v)
+    lo = _plane(v - hi.float())
     return torch.cat([hi, lo], -1).contiguous()
 
 
@@ -66,8 +74,8 @@ def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
         w4 = F.pad(w4, (0, 0, 0, 0, 0, cin_pad - cin))
     k3 = w4.permute(0, 2, 3, 1).reshape(cout, kh * kw, -1)              # (Cout, taps, Cin_pad)
     if isinstance(dtype, str):                                          # split-bf16
-        hi = k3.to(torch.bfloat16)
-        lo = (k3 - hi.float()).to(torch.bfloat16)
+        hi = _plane(k3)
+        lo = _plane(k3 - hi.float())
         hi4, lo4 = hi.reshape(cout, kh * kw, -1, 1, 64), lo.reshape(cout, kh * kw, -1, 1, 64)
         if fold:
             top = torch.cat([hi4, hi4], 3).reshape(cout, -1)
@@ -116,7 +124,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     if x3:
-        assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and sft is None and not ups
+        assert x.dtype == X3_PLANE and w.dtype == X3_PLANE and sft is None and not ups
         cin //= 2
         x = _merge(x)
         if x3_fold:   # (128, taps*2*Cin): rows 0..63 [w_hi | w_hi], rows 64..127 [w_lo | 0] per tap and 64-channel block

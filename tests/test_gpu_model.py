@@ -328,6 +328,42 @@ def test_psnr_contract_on_windows_of_other_clips(tail_models, tag):
     assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_build_vs_ref_unclamped_db"] >= 70.0, rec
 
 
+def test_psnr_contract_sweep_against_the_fp32_build(tail_models):
+    """Regression guard for the sweep of profiles/r3_psnr_sweep.md at a size that runs in seconds: 12 windows of two more clips
+    through the benchmarked path, default mode against the fp32 build (which is pinned to the reference at 134 dB / < 1e-6 dB
+    by the tests above and so stands in for it where no reference fixture exists).  On every window whose codes all equal the
+    fp32 build's: |dPSNR vs GT| <= 1e-3 dB and PSNR(build, fp32 build) >= 75 dB; windows with a flipped code (near-ties of the
+    split-bf16 logits) are counted and reported, and must stay the exception."""
+    from pgtformer_amd.synth import make_clip
+
+    recs, flips = [], 0
+    for seed in (4077, 5077):
+        lq_u8, gt = make_clip(8, 512, seed=seed)
+        fr = torch.from_numpy(lq_u8).to(DEV)
+        outs, codes = {}, {}
+        for prec in ("fp32", "x3f16"):
+            m = tail_models[prec]
+            o, c = [], []
+            for s0 in range(0, 6, 2):                       # two windows per forward
+                y, _, _ = m.forward_nhwc(fr[s0:s0 + 4], w=1.0, win=m.window_index(2, 3, DEV), middle_only=True)
+                o.append(y.float().cpu())
+                c.append(m.last_codes.cpu().clone().reshape(2, -1))
+            outs[prec], codes[prec] = torch.cat(o, 0), torch.cat(c, 0)
+        for j in range(6):
+            g = torch.from_numpy(gt[j + 1])
+            same = bool((codes["x3f16"][j] == codes["fp32"][j]).all())
+            rec = {"clip_seed": seed, "window": j + 1, "codes_equal": same, "psnr_fp32_vs_gt_db": psnr(outs["fp32"][j], g),
+                   "dpsnr_db": psnr(outs["x3f16"][j], g) - psnr(outs["fp32"][j], g),
+                   "psnr_vs_fp32_db": psnr(outs["x3f16"][j], outs["fp32"][j])}
+            recs.append(rec)
+            flips += not same
+            if same:
+                assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_vs_fp32_db"] >= 75.0, rec
+            assert rec["psnr_fp32_vs_gt_db"] >= 25.0, rec
+    _LOG["operating_point_sweep/x3f16_vs_fp32_build"] = {"windows": recs, "windows_with_a_flipped_code": flips}
+    assert flips <= 3, recs
+
+
 def test_whole_model_pure_bf16_report(models, golden_window):
     """Pure bf16 (opt-in speed mode) is reported, not a parity mode: with random-init weights ~2 % of the codes flip."""
     g = np.load(os.path.join(GOLD, "full_golden.npz"))

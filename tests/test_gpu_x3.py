@@ -1,4 +1,4 @@
-"""GPU parity tests of the split-bf16 ("bf16x3", include/pgt_hip.h: PGT_BF16X3) kernels, operator level, through the
+"""GPU parity tests of the split-bf16 ("bf16x3", include/pgt_hip.h: PGT_F16X3) kernels, operator level, through the
 C-ABI: every x3 kernel against the fp32 torch-CPU emulation (tests/emu_ops.py) of the same operator on the same
 seeded inputs.
 
@@ -56,8 +56,8 @@ def check(name, got, want, tol=TOL):
 def test_split_merge_roundtrip():
     x = rnd((3, 7, 5, 64), 1, 3.0)
     xs = ops().to_x3(g(x))
-    assert xs.shape == (3, 7, 5, 128) and xs.dtype == torch.bfloat16
-    assert torch.equal(xs.cpu(), E.to_x3(x))                     # bit-exact split: hi = bf16(v), lo = bf16(v - hi)
+    assert xs.shape == (3, 7, 5, 128) and xs.dtype == torch.float16
+    assert torch.equal(xs.cpu(), E.to_x3(x))                     # bit-exact split: hi = half(v), lo = half(v - hi)
     back = ops().from_x3(xs).cpu()
     assert torch.equal(back, E.from_x3(E.to_x3(x)))
     assert (back - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
@@ -92,7 +92,7 @@ def test_conv2d_x3(case, bn):
     kw = dict(kh=k, kw=k, stride=stride, pad=pad4, x3=True)
     want = E.from_x3(E.conv2d(xs, ws, b, act=E.ACT_SILU, **kw))
     got = ops().conv2d(g(xs), g(ws), g(b), act=E.ACT_SILU, tile=(0, bn), **kw)
-    assert got.dtype == torch.bfloat16 and got.shape[-1] == 2 * cout
+    assert got.dtype == torch.float16 and got.shape[-1] == 2 * cout
     check(f"{name}_bn{bn}", ops().from_x3(got), want)
     # against the exact fp32 conv of the un-split operands: the split type's own error
     exact = E.conv2d(x, wt, b, act=E.ACT_SILU, kh=k, kw=k, stride=stride, pad=pad4)
@@ -246,7 +246,7 @@ def test_conv2d_x3_register_weight_kernel(case):
     for act in (E.ACT_NONE, E.ACT_SILU):
         want = E.from_x3(E.conv2d(xs, w3, b, act=act, **kw))
         got = ops().conv2d(gx, gw, gb, act=act, kernel=6, **kw)
-        assert got.dtype == torch.bfloat16 and got.shape[-1] == 2 * cout
+        assert got.dtype == torch.float16 and got.shape[-1] == 2 * cout
         check(f"{name}_act{act}", ops().from_x3(got), want)
         auto = ops().conv2d(gx, gw, gb, act=act, **kw)                       # kernel = 0 selects the same kernel
         assert torch.equal(auto, got)
@@ -288,7 +288,7 @@ def test_conv2d_x3_folded_64_channel_form(case):
     for act in (E.ACT_NONE, E.ACT_RELU, E.ACT_SILU):
         want = E.from_x3(E.conv2d(xs, wf, b, act=act, x3_fold=True, **kw))
         got = ops().conv2d(g(xs), g(wf), g(b), act=act, x3_fold=True, **kw)
-        assert got.dtype == torch.bfloat16 and got.shape[-1] == 2 * cout
+        assert got.dtype == torch.float16 and got.shape[-1] == 2 * cout
         check(f"{name}_act{act}", ops().from_x3(got), want)
         std = ops().conv2d(g(xs), g(w3), g(b), act=act, **kw)
         check(f"{name}_act{act}_vs_3seg", ops().from_x3(got), ops().from_x3(std))
