@@ -10,7 +10,7 @@ decoder's last temporal operation (the 256x256 fusion block's temporal mix) only
 window - the one the driver keeps - is computed (`--full-tail`: all three, as the reference computes and discards).
 Workload = BASELINE.json configs[1]: pgtformer-base, synthetic degraded 512x512 clip, 3-frame window,
 16-bit MFMA arithmetic with fp32 accumulation (default precision "x3f16": decoder / fusion in IEEE half, the
-code-prediction branch on split-bf16 operands so that the codes equal the fp32 reference's - the mode that holds the
+code-prediction branch on split-half operands so that the codes equal the fp32 reference's - the mode that holds the
 1e-3 dB PSNR contract, tests/test_gpu_model.py::test_psnr_contract_at_the_operating_point), random-init weights of the
 exact architecture (no checkpoint / network here).
 
@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="x3f16", choices=["x3f16", "bf16x3", "bf16", "mixed", "fp32"],
-                    help="x3f16 (default): the mode that holds the 1e-3 dB PSNR contract (split-bf16 code branch, IEEE-half decoder)")
+                    help="x3f16 (default): the mode that holds the 1e-3 dB PSNR contract (split-half code branch, IEEE-half decoder)")
     ap.add_argument("--resident", action="store_true", help="clip resident in HBM (no H2D/D2H in the timed region)")
     ap.add_argument("--no-overlap", action="store_true", help="stack 3 frames per window (no per-frame reuse)")
     ap.add_argument("--full-tail", action="store_true",
@@ -119,19 +119,19 @@ def live_roofline(runner, frames, precision, nwin):
     conv = lambda r: r["kernel"] == "igemm"   # noqa: E731
     kernels = [
         family("igemm 16-bit (bf16 / f16 operands: igemm_kernel, igemm4/5, conv3x3_c64)", lambda r: conv(r) and not r["x3"] and r["dt"] != "float32", "mfma"),
-        family("igemm split-bf16", lambda r: conv(r) and r["x3"], "mfma",
-               "algorithmic FLOPs (every reference product once); the launches execute 3 bf16 MFMAs per product"),
+        family("igemm split-half", lambda r: conv(r) and r["x3"], "mfma",
+               "algorithmic FLOPs (every reference product once); the launches execute 3 f16 MFMAs per product"),
         family("igemm exact fp32", lambda r: conv(r) and not r["x3"] and r["dt"] == "float32", "mfma",
                "3/8-input-channel first convs, fused-upsample and 19-channel BiSeNet heads on v_mfma_f32_32x32x2_f32"),
         family("mha_mfma (code transformer, L = 3072 per window)", lambda r: r["kernel"] == "mha", "mfma",
-               "algorithmic FLOPs; split-bf16 operands: 3 MFMAs per product"),
+               "algorithmic FLOPs; split-half operands: 3 MFMAs per product"),
         family("window_attn_mfma", lambda r: r["kernel"] == "window_attention", "hbm",
                "reads the qkv rows once, writes the output rows once"),
         family("layernorm", lambda r: r["kernel"] == "layernorm", "hbm"),
         family("groupnorm apply + SiLU / AdaIN apply (affine_act)", lambda r: r["kernel"] == "norm_apply_act", "hbm"),
         family("groupnorm statistics pass", lambda r: r["kernel"] == "groupnorm_stats", "hbm",
                "only the GroupNorms whose statistics do not come out of the producing conv's epilogue"),
-        family("fp32 <-> split-bf16 / half conversions", lambda r: r["kernel"] == "x3_convert", "hbm"),
+        family("fp32 <-> split-half / half conversions", lambda r: r["kernel"] == "x3_convert", "hbm"),
         family("gathers / copies / pad zeroing", lambda r: r["kernel"] == "copy_gather", "hbm"),
         family("weight-rounding compensation (sampled channel means + per-frame bias)", lambda r: r["kernel"] == "mean_field", "hbm",
                "small launches: 4096 sampled pixels per frame, a (K x Cout) matrix-vector product per frame"),
@@ -174,7 +174,7 @@ def live_roofline(runner, frames, precision, nwin):
                 break
             tsrc = f"profiles/{name} is stale (library {tj.get('lib_sha16')} != {sha}): not quoted"
     x3 = [r for r in ig if r.get("x3")]
-    executed = flops + 2.0 * sum(r["flops"] for r in x3)        # split-bf16 launches issue 3 bf16 MFMA products per product
+    executed = flops + 2.0 * sum(r["flops"] for r in x3)        # split-half launches issue 3 f16 MFMA products per product
     all_ms, all_by, all_fl = sum(r["ms"] for r in recs), sum(r["bytes"] for r in recs), sum(r["flops"] for r in recs)
     return {"bound": "mfma", "kernel": "igemm family (implicit-GEMM conv/linear: igemm_kernel, igemm4/5, conv3x3_c64)",
             "achieved": round(achieved, 2),
@@ -186,7 +186,7 @@ def live_roofline(runner, frames, precision, nwin):
             "split_bf16_launches": len(x3),
             "executed_mfma_tflops": round(executed / (t_ms * 1e-3) / 1e12, 2),
             "executed_mfma_frac": round(executed / (t_ms * 1e-3) / 1e12 / peak, 4),
-            "split_bf16_note": "algorithmic FLOPs count every product once; split-bf16 launches execute 3 MFMAs per product",
+            "split_bf16_note": "algorithmic FLOPs count every product once; split-half launches execute 3 MFMAs per product",
             "split_bf16_algorithmic_tflops": round(sum(r["flops"] for r in x3) / max(1e-9, sum(r["ms"] for r in x3) * 1e-3) / 1e12, 2) if x3 else None,
             "kernels": kernels,
             "whole_forward": {"kernel_ms_per_step": round(all_ms, 2), "launches": len(recs),
@@ -298,8 +298,8 @@ def clip_mode(args, model, dev, rank, world):
                        "parallelism": f"frame-range shard x{world}, 1 all_gather of boundary frames + 1 gather of restored frames"}}
 
 
-DTYPE_NAMES = {"x3f16": "f16 / bf16 (16-bit MFMA, fp32 accumulate: IEEE-half decoder, code branch on split-bf16 operands)",
-               "bf16x3": "bf16 (bf16 MFMA, fp32 accumulate; code branch on split-bf16 operands)", "bf16": "bf16",
+DTYPE_NAMES = {"x3f16": "f16 / bf16 (16-bit MFMA, fp32 accumulate: IEEE-half decoder, code branch on split-half operands)",
+               "bf16x3": "bf16 (bf16 MFMA, fp32 accumulate; code branch on split-half operands)", "bf16": "bf16",
                "mixed": "bf16 (decoder) / f32 (code branch)", "fp32": "f32"}
 
 

@@ -73,7 +73,7 @@ typedef struct pgt_conv_desc {
     int32_t out_f32;            /* 1: store y as fp32 even when dtype is bf16 (logits, distances) */
     int32_t force_bm, force_bn; /* 0 = heuristic; 64|128 pins the workgroup tile (tests, tuning)  */
     int32_t scalar_epilogue;    /* 1: force the element-wise epilogue (A/B tests); 0 = 16-byte path when legal */
-    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 3 = large-tile v3; 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-input-channel 3x3 with the weights in registers (bf16 / half; split-bf16: Cout % 16 == 0) */
+    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 3 = large-tile v3; 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-input-channel 3x3 with the weights in registers (bf16 / half; split-half: Cout % 16 == 0) */
     int32_t splitk;             /* 0 = auto (needs a workspace); 1 = never; 2..16 = that many K slices           */
     int32_t stages;             /* LDS pipeline depth for kernel = 3 (0 = default)                             */
     /* output placement: row index of output pixel m = orow_mul*m + orow_xmul*(m % Wo) + orow_off (orow_mul = 0: dense,
@@ -83,7 +83,7 @@ typedef struct pgt_conv_desc {
     int32_t orow_mul, orow_xmul, orow_off;
     /* dtype == PGT_F16X3: element offsets of the lo planes of x, y and the residual inside a pixel row (0 = Cin / Cout /
      * Cout, i.e. dense [hi | lo] tensors).  w then has 3*KH*KW*Cin columns: per filter tap and per 64-channel
-     * block [w_hi | w_hi | w_lo] (64 each), matching the K order [x_hi | x_lo | x_hi] of that block.  y is split as well unless out_f32.  Kernel 4 only (bf16 MFMA,
+     * block [w_hi | w_hi | w_lo] (64 each), matching the K order [x_hi | x_lo | x_hi] of that block.  y is split as well unless out_f32.  Kernels 4 and 6 (f16 MFMA,
      * Cin % 64 == 0); no SFT epilogue.                                                                              */
     int32_t x_lo, y_lo, r_lo;
     /* GroupNorm statistics of the output from the conv epilogue (pgt_conv2d_gn): gn_groups > 0 asks every workgroup tile
@@ -94,7 +94,7 @@ typedef struct pgt_conv_desc {
      * Needs Cout % 8 == 0, Ho*Wo a multiple of the kernel's tile rows (<= 512), kernels 0, 1, 4, no split-K.            */
     int32_t gn_groups, gn_sub, gn_nsub;
     int32_t gn_img0, gn_nimg;   /* this call covers images gn_img0 .. gn_img0+N-1 of a gn_nimg-image tensor (0, 0 = all N) */
-    int32_t res_f32;            /* PGT_F16X3 with out_f32: the residual is fp32 as well (ldr in floats) - split-bf16
+    int32_t res_f32;            /* PGT_F16X3 with out_f32: the residual is fp32 as well (ldr in floats) - split-half
                                  * ARITHMETIC on tensors that are stored in fp32 (BiSeNet's BasicBlocks)              */
     int32_t x3_fold;            /* PGT_F16X3, Cout == 64: the weight matrix has 128 rows and TWO K segments per tap and
                                  * 64-channel block (K = KH*KW*2*Cin, the input visited as [x_hi | x_lo]): rows 0..63 hold
@@ -204,8 +204,8 @@ int pgt_mha(int32_t dtype, const void* q, int32_t ldq, const void* k, int32_t ld
             int32_t ldv, void* out, int32_t ldo, int32_t B, int32_t L, int32_t heads, int32_t hd,
             float scale, pgt_stream_t stream);
 
-/* ---- split-bf16 (PGT_F16X3) forms of the normalisation / attention entry points ------------------------------
- * Same arithmetic as the functions above on tensors stored as [hi | lo] bf16 planes; every tensor argument carries the
+/* ---- split-half (PGT_F16X3) forms of the normalisation / attention entry points ------------------------------
+ * Same arithmetic as the functions above on tensors stored as [hi | lo] half planes; every tensor argument carries the
  * element offset of its lo plane (`*_lo`) next to its row stride.  Statistics, softmax and accumulation are fp32;
  * every MFMA product is hi*hi + lo*hi + hi*lo.  Used by the code-prediction branch (encoder levels with temporal
  * attention, quant_conv, feat_emb, the 9 TransformerSALayers, idx_pred_layer: archs/pgtformer_arch.py:626-649). */
@@ -225,11 +225,11 @@ int pgt_window_attention_x3(const void* qkv, int32_t ldqkv, int32_t qkv_lo, void
 int pgt_mha_x3(const void* q, int32_t ldq, int32_t q_lo, const void* k, int32_t ldk, int32_t k_lo, const void* v,
                int32_t ldv, int32_t v_lo, void* out, int32_t ldo, int32_t out_lo, int32_t B, int32_t L,
                int32_t heads, int32_t hd, float scale, pgt_stream_t stream);
-/* fp32 (rows, cols) <-> split-bf16 planes (hi = bf16(v), lo = bf16(v - hi)) */
+/* fp32 (rows, cols) <-> split-half planes (hi = half(v), lo = half(v - hi), saturating) */
 int pgt_x3_split(const float* src, int32_t lds, void* dst, int32_t ldd, int32_t dst_lo, int64_t rows,
                  int32_t cols, pgt_stream_t stream);
-/* split-bf16 planes -> IEEE half rows (the encoder-side feature maps entering the PGT_F16 decoder's fusion blocks,
- * archs/pgtformer_arch.py:627-630: half keeps 11 of the 16 significand bits, the bf16 hi plane alone 8) */
+/* split-half planes -> IEEE half rows (the encoder-side feature maps entering the PGT_F16 decoder's fusion blocks,
+ * archs/pgtformer_arch.py:627-630: the value rounded to half, i.e. the hi plane up to ties) */
 int pgt_x3_to_half(const void* src, int32_t lds, int32_t src_lo, void* dst, int32_t ldd, int64_t rows, int32_t cols,
                    pgt_stream_t stream);
 int pgt_x3_merge(const void* src, int32_t lds, int32_t src_lo, float* dst, int32_t ldd, int64_t rows,

@@ -180,8 +180,8 @@ class BiSeNet(HipModule):
 
     def prepare_x3f(self, device):
         """bf16x3 mode: tensors stay fp32 (the glue kernels - max-pool, gates, resizes - are fp32 kernels) but every conv
-        whose shape fits the split-bf16 LDS-DMA kernel (Cin % 64 == 0, Cout % 8 == 0, no fused up-sampling, a dense fp32
-        output) multiplies on 3 bf16 MFMAs per product instead of the fp32 MFMA (1/16 of the bf16 rate)."""
+        whose shape fits the split-half LDS-DMA kernel (Cin % 64 == 0, Cout % 8 == 0, no fused up-sampling, a dense fp32
+        output) multiplies on 3 f16 MFMAs per product instead of the fp32 MFMA (1/16 of the 16-bit rate)."""
         from ..modules.rstt_layers import prepare_tree
         from ..ops import X3F
         prepare_tree(self, device, torch.float32)
@@ -441,7 +441,7 @@ class PGTFormer(TDCRQVAE3):
     @torch.no_grad()
     def forward_nhwc(self, x, w=None, code_only=None, adain=None, win=None, codes=None, direct=None, middle_only=False):
         """Same computation, channels-last results and no layout conversion: out (B*T,512,512,3) in the
-        decoder dtype, logits fp32, lq_feat (B*T,32,32,512) in the encoder dtype ((B*T,32,32,1024) split-bf16 planes
+        decoder dtype, logits fp32, lq_feat (B*T,32,32,512) in the encoder dtype ((B*T,32,32,1024) split-half planes
         [hi | lo] in bf16x3 mode).
 
         win: None (x holds the B*T frames of B windows back to back), or an int32 device tensor (B*T,) of indices into
@@ -473,7 +473,7 @@ class PGTFormer(TDCRQVAE3):
             if win is not None:
                 c = ops.gather_frames(c, win)                               # (bt,32,32,512)
             p = c.reshape(bt * c.shape[1] * c.shape[2], c.shape[3])          # rows (b,t,y,x) == (T*H*W, B) order
-            return c, (ops.to_x3(p) if x3 else p)                           # fp32 BiSeNet map -> split-bf16 operand
+            return c, (ops.to_x3(p) if x3 else p)                           # fp32 BiSeNet map -> split-half operand
 
         side = None
         if SIDE_STREAM and raw.is_cuda:

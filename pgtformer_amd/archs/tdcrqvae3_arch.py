@@ -334,7 +334,7 @@ class Encoder(HipModule):
 
     def prepare_split(self, device):
         """bf16x3 mode: conv_in (3 input channels: no 64-channel K blocks for the LDS-DMA kernel) stays in exact fp32;
-        every level, the middle blocks and conv_out run on split-bf16 operands (the levels below the first temporal
+        every level, the middle blocks and conv_out run on split-half operands (the levels below the first temporal
         attention are computed once per FRAME by the overlap-aware driver)."""
         prepare_tree(self.conv_in, device, torch.float32)
         for m in (self.down, self.mid, self.norm_out, self.conv_out):
@@ -589,7 +589,7 @@ class TDCRQVAE3(HubMixin, HipModule):
     def prepare(self, device="cuda", precision=DEFAULT_PRECISION):
         """Repack the weights for the kernels.  precision:
           "fp32"    exact-f32 MFMA everywhere (parity mode)
-          "x3f16"   (default) the code-prediction branch on split-bf16 operands (3 bf16 MFMAs per product, 16 significand
+          "x3f16"   (default) the code-prediction branch on split-half operands (two IEEE-half planes, 3 f16 MFMAs per product, 22 significand
                     bits: the arg-max codes reproduce the fp32 reference) with its per-frame BiSeNet in fp32 storage;
                     decoder / SFT fusion in IEEE half (11 significand bits at the bf16 MFMA rate): restored frames within
                     1e-3 dB PSNR of the fp32 reference at a non-degenerate operating point (tests/golden/make_golden_r3.py)

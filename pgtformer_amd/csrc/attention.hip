@@ -449,7 +449,7 @@ extern "C" int pgt_mha(int32_t dtype, const void* q, int32_t ldq, const void* k,
     return 0;
 }
 
-// ---- split-bf16 (PGT_F16X3) forms: MFMA kernels only ------------------------------------------------------------
+// ---- split-half (PGT_F16X3) forms: MFMA kernels only ------------------------------------------------------------
 extern "C" int pgt_window_attention_x3(const void* qkv, int32_t ldqkv, int32_t qkv_lo, void* out, int32_t ldo,
                                        int32_t out_lo, const float* bias, int32_t B, int32_t T, int32_t H, int32_t W,
                                        int32_t C, int32_t heads, int32_t wh, int32_t ww, int32_t sh, int32_t sw,

@@ -27,7 +27,7 @@ constexpr int VSTR = 136;   // V^T row stride in bytes (64 keys * 2 + 8): confli
 // 16-bit operand type of a launch: bf16 (plain bf16 rows), or the half planes of split rows (X3; common.h x3p_t)
 template <bool H> struct P16 {
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {      // {lo, hi} packed
-        if constexpr (H) return f2h2(lo, hi);
+        if constexpr (H) return f2h2_nosat(lo, hi);                                // P <= 2^8, outputs are convex combinations of V rows
         else return f2bf2(lo, hi);                                               // v_cvt_pk_bf16_f32
     }
     static __device__ __forceinline__ float lo_of(uint32_t w) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __res
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // Lazy rescale, exp2 domain (m = reference exponent of this query, scale folded in): the running sum and the
         // accumulators are rescaled only when some query of the wave would exceed the reference by 2^8 - P <= 256 is as
-        // precise in bf16 / split-bf16 as P <= 1, and after the first tiles the 32 + 2 multiplies per tile disappear.
+        // precise in bf16 / split-half as P <= 1, and after the first tiles the 32 + 2 multiplies per tile disappear.
         const float tmx = mx * c;
         if (__any(tmx > m + 8.0f)) {
             const float mnew = fmaxf(m, tmx);

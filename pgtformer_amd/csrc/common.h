@@ -109,14 +109,21 @@ using x3p_t = half_t;
 // ulp on 2 of 73 728 outputs.  x3_opaque() hides the packed register from that folding (no instruction is emitted).
 __device__ __forceinline__ void x3_opaque(uint32_t& w) { asm volatile("" : "+v"(w)); }
 __device__ __forceinline__ void x3_opaque(uint4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
+// {lo, hi} packed to half, round to nearest even, NOT saturating (one v_cvt_pk_f16_f32): for values known to fit
+__device__ __forceinline__ uint32_t f2h2_nosat(float lo, float hi) {
+    const halfx2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
 __device__ __forceinline__ void split8(const float* f, uint4& hi, uint4& lo) {
-    hi = Vec16<x3p_t>::pack(f);
+    float c[8], h[8], r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = sat_half(f[e]);       // one clamp per value: hi cannot overflow, |c - hi| <= ulp / 2
+    hi = make_uint4(f2h2_nosat(c[0], c[1]), f2h2_nosat(c[2], c[3]), f2h2_nosat(c[4], c[5]), f2h2_nosat(c[6], c[7]));
     x3_opaque(hi);
-    float h[8], r[8];
     Vec16<x3p_t>::unpack(hi, h);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = f[e] - h[e];
-    lo = Vec16<x3p_t>::pack(r);
+    for (int e = 0; e < 8; ++e) r[e] = c[e] - h[e];
+    lo = make_uint4(f2h2_nosat(r[0], r[1]), f2h2_nosat(r[2], r[3]), f2h2_nosat(r[4], r[5]), f2h2_nosat(r[6], r[7]));
 }
 __device__ __forceinline__ void merge8(const uint4& hi, const uint4& lo, float* f) {
     float l[8];
@@ -127,10 +134,12 @@ __device__ __forceinline__ void merge8(const uint4& hi, const uint4& lo, float* 
 }
 // two values -> one dword of each plane ({a, b} packed)
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    hi = f2h2(a, b);
+    a = sat_half(a);
+    b = sat_half(b);
+    hi = f2h2_nosat(a, b);
     x3_opaque(hi);
     const halfx2 h = __builtin_bit_cast(halfx2, hi);
-    lo = f2h2(a - (float)h.x, b - (float)h.y);
+    lo = f2h2_nosat(a - (float)h.x, b - (float)h.y);
 }
 __device__ __forceinline__ float x3_hi_of(float f) {      // value of the hi plane of f (opaque: see x3_opaque)
     uint32_t w = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)sat_half(f));

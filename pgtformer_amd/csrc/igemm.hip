@@ -499,7 +499,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
                 (d->epi == 0 || (al(sft_dec, d->ld_dec) && al(sft_shift, d->ld_shift))) && !d->scalar_epilogue;
     hipStream_t st = (hipStream_t)stream;
 
-    if (x3) {   // split-bf16 operands: the phase-interleaved LDS-DMA kernel with the three-segment K order
+    if (x3) {   // split-half operands: the phase-interleaved LDS-DMA kernel with the three-segment K order
         PGT_CHECK(d->Cin % 64 == 0 && d->ups == 0 && d->KH * d->KW <= 30,
                   "pgt_conv2d: bf16x3 needs Cin %% 64 == 0 (Cin=%d) and no fused up-sampling", d->Cin);
         PGT_CHECK(d->epi == 0 || (!d->out_f32 && !d->x3_fold && d->ld_dec >= p.dlo + d->Cout && d->ld_shift >= p.slo + d->Cout &&

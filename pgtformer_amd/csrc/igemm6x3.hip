@@ -1,4 +1,4 @@
-// 3x3 convolution, 64 input channels, <= 64 output channels on SPLIT-bf16 operands (PGT_F16X3): the full-resolution
+// 3x3 convolution, 64 input channels, <= 64 output channels on SPLIT-half operands (PGT_F16X3): the full-resolution
 // levels of the encoder (64 -> 64 at 512x512, the code-prediction branch).  On the 256- / 128-wide tiles of igemm4.hip a
 // 64-channel layer idles half of the tile or, in the folded form, spends a fourth product on a zero quadrant; either way
 // the operands stream through LDS once per filter tap.

@@ -43,7 +43,7 @@ struct ConvP {
     int splitk, kt_per_split;   // > 1: K is cut in `splitk` slices of `kt_per_split` K tiles each
     int wo_shift, ho_shift;     // igemm4: log2(Wo), log2(Ho) when both are powers of two, else -1 (set by its launcher)
     int orow_mul, orow_xmul, orow_off;   // output row of pixel m (orow_mul = 0: m), see pgt_conv_desc
-    int x3;                     // split-bf16 operands: x = [hi | lo] planes, K runs over [x_hi | x_lo | x_hi] per tap
+    int x3;                     // split-half operands: x = [hi | lo] planes, K runs over [x_hi | x_lo | x_hi] per tap
     int xlo, ylo, rlo;          // element offset of the lo plane inside a pixel row of x / y / residual
     int res_f32;                // x3 with fp32 output: the residual is fp32 too (ldr counts floats)
     int f16;                    // 16-bit operands are IEEE half (PGT_F16) instead of bf16

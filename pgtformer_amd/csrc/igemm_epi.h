@@ -13,7 +13,7 @@ namespace {
 template <int WR, int WC> constexpr int epi_stage_bytes() { return WR * 64 * (WC * 64 + 4) * 4; }
 
 // smem: at least epi_stage_bytes<WR, WC>() bytes, no DMA in flight, all waves past their last fragment read.
-// X3: split-bf16 output (hi at n, lo at n + p.ylo), split residual (p.rlo) or split SFT operands (p.dlo / p.slo).
+// X3: split-half output (hi at n, lo at n + p.ylo), split residual (p.rlo) or split SFT operands (p.dlo / p.slo).
 // GN: also reduce the GroupNorm statistics of the tile's outputs (ConvP::gn_*).
 // T: 16-bit storage type of residual / SFT operands / output (bf16_t, or half_t for PGT_F16 launches; X3 is bf16).
 template <int WR, int WC, bool X3 = false, bool GN = false, typename T = bf16_t>

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     if (ci < Cin) v = __fmul_rn(w[((long)co * Cin + ci) * taps + tap], scale ? scale[co] : 1.f);
     stf(out + i, v);
 }
-// split-bf16 forms.  Standard: (Cout, KH*KW*3*Cin_pad), per tap and 64-channel block [w_hi | w_hi | w_lo] (the kernels visit
+// split-half forms.  Standard: (Cout, KH*KW*3*Cin_pad), per tap and 64-channel block [w_hi | w_hi | w_lo] (the kernels visit
 // the block's input planes as [x_hi | x_lo | x_hi]).  Folded (Cout == 64): (128, KH*KW*2*Cin_pad), rows 0..63 [w_hi | w_hi],
 // rows 64..127 [w_lo | 0] per tap and block (pgt_conv_desc::x3_fold).
 __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int Cin_pad,
@@ -730,7 +730,7 @@ extern "C" int pgt_pack_conv_weight(int32_t dtype, const float* w_oihw, int32_t 
     const long total = (long)Cout * KH * KW * Cin_pad;
     const dim3 g = grid1d(total);
     if (dtype == PGT_F16X3) {
-        PGT_CHECK(Cin_pad % 64 == 0, "pack_conv_weight: split-bf16 weights come in 64-channel K blocks (Cin_pad=%d)", Cin_pad);
+        PGT_CHECK(Cin_pad % 64 == 0, "pack_conv_weight: split-half weights come in 64-channel K blocks (Cin_pad=%d)", Cin_pad);
         PGT_CHECK(!x3_fold || Cout == 64, "pack_conv_weight: the folded form is for 64 output channels (Cout=%d)", Cout);
         hipLaunchKernelGGL(pack_weight_x3_kernel, g, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (x3p_t*)packed, x3_fold);
         PGT_LAUNCH_CHECK();

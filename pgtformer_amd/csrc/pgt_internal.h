@@ -11,7 +11,7 @@ int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void
 // igemm2.hip: LDS-DMA implicit GEMM (bf16, Cin % 64 == 0, 16-byte epilogue legal). `conv_p` is a ConvP.
 int pgt_igemm2_launch(const void* conv_p, int bn, int stages, hipStream_t st);
 
-// window_attn_mfma.hip: MFMA window attention, mode 0 bf16 / 1 split-bf16 / 2 fp16; (wd, wh, ww) windows with shift
+// window_attn_mfma.hip: MFMA window attention, mode 0 bf16 / 1 split-half / 2 fp16; (wd, wh, ww) windows with shift
 // (sd, sh, sw) on a (B, D, H, W) token grid; returns 1 if the shape is not covered
 int pgt_window_attn_mfma(int mode, const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int D, int H,
                          int W, int C, int heads, int wd, int wh, int ww, int sd, int sh, int sw, hipStream_t st,
@@ -25,5 +25,5 @@ int pgt_igemm4_launch(const void* conv_p, int bn, hipStream_t st);
 int pgt_igemm5_launch(const void* conv_p, hipStream_t st);
 // igemm6.hip: 3x3, Cin == 64, Cout <= 64: weights in registers, persistent workgroups, one halo image per filter row
 int pgt_igemm6_launch(const void* conv_p, hipStream_t st);
-// igemm6x3.hip: the same layers on split-bf16 operands (Cout % 16 == 0): hi / lo weights in registers, MFMA 16x16x32, three products
+// igemm6x3.hip: the same layers on split-half operands (Cout % 16 == 0): hi / lo weights in registers, MFMA 16x16x32, three products
 int pgt_igemm6x3_launch(const void* conv_p, hipStream_t st);

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
 
 }  // namespace
 
-// mode 0: bf16, 1: split-bf16 (lo planes qlo / olo elements after the hi planes), 2: fp16.  Windows (wd, wh, ww) with shift
+// mode 0: bf16, 1: split-half (lo planes qlo / olo elements after the hi planes), 2: fp16.  Windows (wd, wh, ww) with shift
 // (sd, sh, sw) on a (B, D, H, W) token grid; N = wd*wh*ww in {48, 96, 144, 192}; hd in {32, 64}.
 // Returns 1 when the shape is not covered (caller falls back or reports).
 int pgt_window_attn_mfma(int mode, const void* qkv, int ldqkv, void* out, int ldo, const float* bias, int B, int D, int H,

@@ -19,8 +19,8 @@ import torch.nn as nn
 from .. import ops
 from ..ops import ACT_GELU, ACT_NONE, ACT_SILU, X3, X3F
 
-USE_X3_FOLD = os.environ.get("PGT_X3_FOLD", "1") != "0"   # A/B switch of the folded 64-channel split-bf16 convs
-USE_X3_C64 = os.environ.get("PGT_X3_C64", "1") != "0"     # A/B switch of the register-weight split-bf16 3x3 kernel (igemm6x3.hip)
+USE_X3_FOLD = os.environ.get("PGT_X3_FOLD", "1") != "0"   # A/B switch of the folded 64-channel split-half convs
+USE_X3_C64 = os.environ.get("PGT_X3_C64", "1") != "0"     # A/B switch of the register-weight split-half 3x3 kernel (igemm6x3.hip)
 
 
 USE_WCOMP = os.environ.get("PGT_WCOMP", "1") != "0"       # A/B switch of the mean-field weight-rounding compensation
@@ -57,7 +57,7 @@ def _is_x3f(dtype):
 
 def _pack_matrix(w, device, dtype, cin_pad=None, scale=None, fold=False):
     """reference weight - (Cout, Cin, KH, KW), or any K-major (Cout, K) matrix - -> kernel operand on `device`: the repack is
-    the library's (pgt_pack_conv_weight: K-major rows, channel padding, rounding to the compute type, the split-bf16 forms)"""
+    the library's (pgt_pack_conv_weight: K-major rows, channel padding, rounding to the compute type, the split-half forms)"""
     return ops.pack_conv_weight(w.detach().to(device=device, dtype=torch.float32), dtype, cin_pad=cin_pad, scale=scale, fold=fold)
 
 
@@ -128,7 +128,7 @@ class Conv2d(nn.Conv2d, HipModule):
         self.pw = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale)
         self.pb = b
         self.pdef = _defect_t(self.weight, self.pw, scale=scale) if _wants_wcomp(dtype) else None
-        # split-bf16 layers with 64 output channels: the folded form fills the 128-column tile (pgt_conv_desc.x3_fold)
+        # split-half layers with 64 output channels: the folded form fills the 128-column tile (pgt_conv_desc.x3_fold)
         self.pw_fold = None
         if (_is_x3(dtype) or _is_x3f(dtype)) and cout == 64 and cin_k % 64 == 0 and USE_X3_FOLD:
             self.pw_fold = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale, fold=True)
@@ -147,7 +147,7 @@ class Conv2d(nn.Conv2d, HipModule):
         w = self.pw_fold if fold else self.pw
         if fold:
             kw = dict(kw, x3_fold=True)
-        if _is_x3f(self.dt):     # fp32 in / fp32 out, split-bf16 MFMA arithmetic in between
+        if _is_x3f(self.dt):     # fp32 in / fp32 out, split-half MFMA arithmetic in between
             return ops.conv2d(ops.to_x3(x), w, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
                               stride=self.stride[0], pad=self.pad4, x3=True, out_f32=True, **kw)
         b = self.pb

@@ -61,7 +61,7 @@ def pack_x3_weight(w3):
     (x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo)."""
     w3 = w3.float()
     cout, taps, cin = w3.shape
-    assert cin % 64 == 0, "split-bf16 operands come in 64-channel K blocks"
+    assert cin % 64 == 0, "split-half operands come in 64-channel K blocks"
     hi = w3.to(X3_PLANE)
     lo = (w3 - hi.float()).to(X3_PLANE)
     hi4, lo4 = hi.reshape(cout, taps, cin // 64, 1, 64), lo.reshape(cout, taps, cin // 64, 1, 64)
@@ -95,7 +95,7 @@ def _dtype_code(dtype):
 def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
     """Reference weight -> the conv / linear kernels' operand, on the device (pgt_pack_conv_weight).  w: fp32 device tensor
     (Cout, Cin, KH, KW) (nn.Conv2d) or (Cout, Cin) (nn.Linear, or any K-major matrix); dtype: torch.float32 / bfloat16 /
-    float16, or X3 / X3F (split-bf16: [w_hi | w_hi | w_lo] per 64-channel block; fold=True: the 64-output-channel folded form);
+    float16, or X3 / X3F (split-half: [w_hi | w_hi | w_lo] per 64-channel block; fold=True: the 64-output-channel folded form);
     cin_pad: zero-pad the input channels; scale: optional fp32 (Cout,) factor applied before rounding (BatchNorm fold)."""
     assert w.dtype == torch.float32 and w.dim() in (2, 4)
     w = w.contiguous()
@@ -123,7 +123,7 @@ def fold_batchnorm(gamma, beta, mean, var, eps, bias=None):
 
 
 def to_x3(x, out=None):
-    """fp32 (..., C) -> split-bf16 (..., 2C)."""
+    """fp32 (..., C) -> split-half (..., 2C)."""
     assert x.dtype == torch.float32 and x.stride(-1) == 1
     c = x.shape[-1]
     x2 = x.reshape(-1, c) if x.is_contiguous() else None
@@ -141,7 +141,7 @@ def to_x3(x, out=None):
 
 
 def x3_to_half(x, out=None):
-    """split-bf16 (..., 2C) -> IEEE half (..., C) (hi + lo rounded once: 11 significand bits; the hi plane alone has 8)."""
+    """split-half (..., 2C) -> IEEE half (..., C) (hi + lo rounded once: 11 significand bits; the hi plane alone has 8)."""
     assert x.dtype == X3_PLANE and x.is_contiguous() and x.shape[-1] % 2 == 0
     c = x.shape[-1] // 2
     if out is None:
@@ -153,7 +153,7 @@ def x3_to_half(x, out=None):
 
 
 def from_x3(x):
-    """split-bf16 (..., 2C) -> fp32 (..., C)."""
+    """split-half (..., 2C) -> fp32 (..., C)."""
     assert x.dtype == X3_PLANE and x.is_contiguous() and x.shape[-1] % 2 == 0
     c = x.shape[-1] // 2
     out = torch.empty(tuple(x.shape[:-1]) + (c,), device=x.device, dtype=torch.float32)
@@ -334,7 +334,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     write one tensor (the caller binds the statistics to the tensor after the last launch)."""
     n, h, wd, cin = x.shape
     cout = w.shape[0]
-    if x3:   # split-bf16 operands: x (N,H,W,2*Cin) = [hi | lo], w (Cout, kh*kw*3*Cin), y (N,Ho,Wo,2*Cout) unless out_f32
+    if x3:   # split-half operands: x (N,H,W,2*Cin) = [hi | lo], w (Cout, kh*kw*3*Cin), y (N,Ho,Wo,2*Cout) unless out_f32
         assert x.dtype == X3_PLANE and cin % 2 == 0 and sft is None and not ups and out_rows is None and out_parity is None
         cin //= 2
         if x3_fold:   # 64 output channels, w = pack_x3_fold_weight(...): (128, kh*kw*2*Cin)
@@ -420,7 +420,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         d.epi, d.ld_dec, d.ld_shift, d.sft_w = EPI_SFT, _ld_img(dec), _ld_img(shift), float(sw)
         assert dec.dtype == x.dtype and shift.dtype == x.dtype
     if res is not None and x3 and res.dtype == torch.float32:
-        assert out_f32 and tuple(res.shape) == tuple(out.shape)      # split-bf16 arithmetic on fp32-stored tensors
+        assert out_f32 and tuple(res.shape) == tuple(out.shape)      # split-half arithmetic on fp32-stored tensors
         d.res_f32 = 1
     elif res is not None:
         assert res.dtype == x.dtype and tuple(res.shape[:-1]) == tuple(out.shape[:-1]) and res.shape[-1] == (2 * cout if x3 else cout)
@@ -464,7 +464,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
 
 
 def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False, gn=None):
-    """x: (rows, Cin) -> (rows, Cout); x3: split-bf16 rows (rows, 2*Cin) -> (rows, 2*Cout) (or fp32 (rows, Cout)).
+    """x: (rows, Cin) -> (rows, Cout); x3: split-half rows (rows, 2*Cin) -> (rows, 2*Cout) (or fp32 (rows, Cout)).
     gn=(groups, n_images): the rows are n_images images of rows / n_images tokens each; the epilogue leaves the GroupNorm
     statistics of the output per image (attached to the returned tensor, see conv2d)."""
     rows, cin = x.shape
@@ -613,7 +613,7 @@ def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):
 
 
 def window_attention(qkv, bias, B, T, H, W, C_, heads, win, shift, x3=False):
-    """qkv (B*T*H*W, 3C) -> (B*T*H*W, C); x3: split-bf16 rows (.., 6C) = [hi q k v | lo q k v] -> (.., 2C)."""
+    """qkv (B*T*H*W, 3C) -> (B*T*H*W, C); x3: split-half rows (.., 6C) = [hi q k v | lo q k v] -> (.., 2C)."""
     rows = B * T * H * W
     if x3:
         assert tuple(qkv.shape) == (rows, 6 * C_) and qkv.dtype == X3_PLANE
@@ -651,7 +651,7 @@ def window_attention3d(qkv, bias, B, D, H, W, C_, heads, win, shift, pad_row=Non
 
 
 def mha(q, k, v, B, L, heads, hd, scale, x3=None):
-    """q,k,v (B*L, heads*hd) views -> (B*L, heads*hd).  x3=(q_lo, k_lo, v_lo): q, k, v are the hi planes of split-bf16
+    """q,k,v (B*L, heads*hd) views -> (B*L, heads*hd).  x3=(q_lo, k_lo, v_lo): q, k, v are the hi planes of split-half
     rows whose lo planes start that many elements further; returns split rows (B*L, 2*heads*hd)."""
     if x3 is not None:
         e = heads * hd

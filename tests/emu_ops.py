@@ -43,8 +43,9 @@ def _plane(v):
 
 def _split(v):
     """fp32 (..., C) -> split (..., 2C) on two half planes: hi = half(v), lo = half(v - hi)"""
-    hi = _plane(v)
-    lo = _plane(v - hi.float())
+    v = v.clamp(-65504.0, 65504.0)          # one clamp per value (common.h split8): hi cannot overflow, |v - hi| <= ulp / 2
+    hi = v.to(X3_PLANE)
+    lo = (v - hi.float()).to(X3_PLANE)
     return torch.cat([hi, lo], -1).contiguous()
 
 
@@ -73,7 +74,7 @@ def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
     if cin_pad is not None and cin_pad > cin:
         w4 = F.pad(w4, (0, 0, 0, 0, 0, cin_pad - cin))
     k3 = w4.permute(0, 2, 3, 1).reshape(cout, kh * kw, -1)              # (Cout, taps, Cin_pad)
-    if isinstance(dtype, str):                                          # split-bf16
+    if isinstance(dtype, str):                                          # split-half
         hi = _plane(k3)
         lo = _plane(k3 - hi.float())
         hi4, lo4 = hi.reshape(cout, kh * kw, -1, 1, 64), lo.reshape(cout, kh * kw, -1, 1, 64)

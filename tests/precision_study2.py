@@ -9,7 +9,7 @@ group (512x512 level, 256->512 up-sampling, 256x256 level + fusion, the rest).
   groups        22-bit weights in one decoder level at a time / in all but one: whose weight rounding carries the systematic error
   compensation  half everywhere + the mean-field compensation of the weight rounding (what the product does: per-frame bias
                 (W - W16) mean(x) from the library's pixel sample), for the residual-block / fusion convs only and for every layer
-  planes        the code-prediction branch on two bf16 planes (the product's split-bf16) against two half planes: logit error
+  planes        the code-prediction branch on two bf16 planes (the split type of rounds 2-3a) against two half planes (the product's): logit error
                 and flipped codes against the exact oracle
 Results: profiles/r3_psnr_sweep.md.
 """

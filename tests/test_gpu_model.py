@@ -5,7 +5,7 @@ Metrics are also written to gpurun_out/parity_model.json.
 
 Tolerances:  f32 path: max|d| <= 1e-3*max|ref| per module, whole-model PSNR(build, reference) >= 80 dB on
 the clamped middle frame and 100 % code agreement except tokens whose reference top-2 logit margin is
-< 1e-3.  x3f16 (the default / benchmarked mode: split-bf16 code branch, IEEE-half decoder): the SAME code criterion
+< 1e-3.  x3f16 (the default / benchmarked mode: split-half code branch, IEEE-half decoder): the SAME code criterion
 (every code equal to the reference's except where the reference's own top-2 margin is < 1e-3), logits within 2e-3, and
 north_star's PSNR contract at the fitted-tail operating point (tests/golden/make_golden_r3.py: reference frames inside
 [0, 1], PSNR(reference, GT) = 28.7 dB): |PSNR(build, GT) - PSNR(reference, GT)| <= 1e-3 dB with UNCLAMPED
@@ -177,7 +177,7 @@ def _reduced_record(out, logits, lq, codes, g, gt):
 
 @pytest.mark.parametrize("prec", ["x3f16", "bf16x3", "mixed"])
 def test_whole_model_default_mode_matches_reference(models, golden_window, prec):
-    """The modes with a split-bf16 (or fp32) code branch reproduce the reference: every arg-max code
+    """The modes with a split-half (or fp32) code branch reproduce the reference: every arg-max code
     (archs/pgtformer_arch.py:663) equals the fp32 reference's except where the reference's own top-2 logit margin is < 1e-3,
     logits / lq_feat to fp32-class error, and the restored frames to >= 55 dB with the IEEE-half decoder (x3f16, the
     default), >= 35 dB with the bf16 decoder.  (Random-tail weights: the frames are noise against the GT - the PSNR contract
@@ -333,7 +333,7 @@ def test_psnr_contract_sweep_against_the_fp32_build(tail_models):
     through the benchmarked path, default mode against the fp32 build (which is pinned to the reference at 134 dB / < 1e-6 dB
     by the tests above and so stands in for it where no reference fixture exists).  On every window whose codes all equal the
     fp32 build's: |dPSNR vs GT| <= 1e-3 dB and PSNR(build, fp32 build) >= 75 dB; windows with a flipped code (near-ties of the
-    split-bf16 logits) are counted and reported, and must stay the exception."""
+    split-half logits) are counted and reported, and must stay the exception."""
     from pgtformer_amd.synth import make_clip
 
     recs, flips = [], 0
@@ -423,7 +423,7 @@ def test_overlap_aware_windows_equal_stacked_windows(models):
         _LOG[f"overlap_vs_stacked/{prec}"] = {"out_max_abs": d_out, "logits_max_abs": d_log, "psnr_db": p_db,
                                               "same_codes": same_codes}
         # the two calls see different frame counts, so tile / split-K choices (hence fp32 summation orders) may differ:
-        # fp32 agrees to round-off.  Default mode: identical codes and logits to split-bf16 round-off; the bf16 decoder
+        # fp32 agrees to round-off.  Default mode: identical codes and logits to split-half round-off; the bf16 decoder
         # of this random-init network amplifies flipped bf16 roundings of its inputs to its own noise floor (PSNR(build,
         # reference) is 35.4 dB for the same reason), so the two outputs are held to that floor, not to bit equality
         assert d_log <= 2e-4 and same_codes, (prec, d_log)
@@ -450,7 +450,7 @@ def test_parsing_map_and_public_paths_match_host_oracle(models, cfg, full_sd, go
     _LOG["public_paths/fp32"] = rec
     assert rec["code_only_logits_equal"]
     assert rec["w0_noadain_out_err"] < 2e-3 * max(1.0, float(o_out.abs().max())), rec
-    # the default mode's parsing map: BiSeNet convs on split-bf16 arithmetic, fp32 storage
+    # the default mode's parsing map: BiSeNet convs on split-half arithmetic, fp32 storage
     mx = models["bf16x3"]
     mx(x.to(DEV), code_only=True)
     parx = mx.last_parsing.float().cpu()[..., :57].permute(0, 3, 1, 2)

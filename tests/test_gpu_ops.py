@@ -635,7 +635,7 @@ def test_epilogue_statistics_linear_and_subpixel_and_x3(dtype):
     s_w, b_w = E.groupnorm_affine(out.float().cpu(), gam, bet)
     check("gn_subpixel_scale", s_e, s_w, torch.float32, 20.0)
     check("gn_subpixel_shift", b_e, b_w, torch.float32, 20.0)
-    # split-bf16 conv
+    # split-half conv
     xs = E.to_x3(rnd((2, 32, 32, 128), 219))
     w3 = O.pack_x3_weight(rnd((256, 9, 128), 220, 1 / 34))
     ys = O.conv2d(g(xs), g(w3), None, kh=3, kw=3, pad=(1, 1, 1, 1), x3=True, gn=32)
@@ -672,7 +672,7 @@ def F_pad8(t):
 
 def test_weight_repack_behind_the_abi_matches_the_host_restatement():
     """pgt_pack_conv_weight / pgt_fold_batchnorm (the repack a non-Python host needs after loading a reference checkpoint:
-    K-major rows, channel padding, BatchNorm fold, rounding, the split-bf16 forms) against the torch restatement: packed
+    K-major rows, channel padding, BatchNorm fold, rounding, the split-half forms) against the torch restatement: packed
     operands bit for bit, the BatchNorm factors to one unit in the last place."""
     O = ops()
     w4 = rnd((72, 57, 3, 3), 950, torch.float32, 0.1)
@@ -687,7 +687,7 @@ def test_weight_repack_behind_the_abi_matches_the_host_restatement():
     assert torch.equal(O.pack_conv_weight(g(wx), O.X3).cpu(), E.pack_conv_weight(wx, O.X3))
     assert torch.equal(O.pack_conv_weight(g(wx), O.X3).cpu(), O.pack_x3_weight(wx.permute(0, 2, 3, 1).reshape(64, 9, 128)))
     assert torch.equal(O.pack_conv_weight(g(wx), O.X3, fold=True).cpu(), O.pack_x3_fold_weight(wx.permute(0, 2, 3, 1).reshape(64, 9, 128)))
-    w57 = rnd((512, 57, 1, 1), 954, torch.float32, 0.1)                 # convpos: 57 -> 64 input channels, split-bf16
+    w57 = rnd((512, 57, 1, 1), 954, torch.float32, 0.1)                 # convpos: 57 -> 64 input channels, split-half
     assert torch.equal(O.pack_conv_weight(g(w57), O.X3, cin_pad=64).cpu(), E.pack_conv_weight(w57, O.X3, cin_pad=64))
     gam, bet, mu, var, b0 = 1 + 0.1 * rnd((72,), 955), 0.1 * rnd((72,), 956), 0.1 * rnd((72,), 957), rnd((72,), 958).abs() + 0.5, rnd((72,), 959)
     s_g, b_g = O.fold_batchnorm(g(gam), g(bet), g(mu), g(var), 1e-5, g(b0))

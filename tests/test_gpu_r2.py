@@ -211,7 +211,7 @@ def test_sample_rows_is_an_inverse_cdf_draw():
 
 
 def test_stage1_bf16x3_codes_match_reference(gold, cfg, full_sd, golden_window):
-    """The default mode's stage-I path: split-bf16 encoder -> fp32 quantiser: codes equal the reference's."""
+    """The default mode's stage-I path: split-half encoder -> fp32 quantiser: codes equal the reference's."""
     from pgtformer_amd import PGTFormer
     from pgtformer_amd.archs.tdcrqvae3_arch import TDCRQVAE3
 

@@ -147,7 +147,7 @@ def test_fuse_block_bf16_restructuring_matches_fp32_path(monkeypatch):
 
 @pytest.mark.slow
 def test_whole_model_bf16x3_host_logic_and_numerics(cfg, full_sd, golden_window, monkeypatch):
-    """bf16x3 mode through the CPU emulation (split-bf16 tensors = hi + lo, weights [w_hi | w_hi | w_lo], fp32
+    """bf16x3 mode through the CPU emulation (split-half tensors = hi + lo, weights [w_hi | w_hi | w_lo], fp32
     accumulation): the host plumbing of the split type AND its numerical sufficiency - the arg-max codes must equal the
     fp32 reference's everywhere (the plain bf16 mode flips ~2 % of them), the decoder runs in bf16."""
     from pgtformer_amd import PGTFormer
@@ -177,7 +177,7 @@ def test_whole_model_bf16x3_host_logic_and_numerics(cfg, full_sd, golden_window,
 
 @pytest.mark.slow
 def test_default_mode_host_logic_and_psnr_contract_at_the_operating_point(cfg, full_sd, golden_window, monkeypatch):
-    """The default precision mode (x3f16: split-bf16 code branch, IEEE-half decoder) through the CPU emulation of its
+    """The default precision mode (x3f16: split-half code branch, IEEE-half decoder) through the CPU emulation of its
     arithmetic, on the fitted-tail weight scheme (tests/golden/make_golden_r3.py: reference frames inside [0, 1], PSNR(reference,
     GT) = 28.7 dB on the middle frame): host plumbing of the half decoder (x3 -> half feature hand-over, fp32 AdaIN style
     statistics, fp32 output of conv_out) and the numerical sufficiency of 11 significand bits for north_star's contract
