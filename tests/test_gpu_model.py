@@ -332,8 +332,8 @@ def test_psnr_contract_sweep_against_the_fp32_build(tail_models):
     """Regression guard for the sweep of profiles/r3_psnr_sweep.md at a size that runs in seconds: 12 windows of two more clips
     through the benchmarked path, default mode against the fp32 build (which is pinned to the reference at 134 dB / < 1e-6 dB
     by the tests above and so stands in for it where no reference fixture exists).  On every window whose codes all equal the
-    fp32 build's: |dPSNR vs GT| <= 1e-3 dB and PSNR(build, fp32 build) >= 75 dB; windows with a flipped code (near-ties of the
-    split-half logits) are counted and reported, and must stay the exception."""
+    fp32 build's: |dPSNR vs GT| <= 1e-3 dB and PSNR(build, fp32 build) >= 75 dB; windows with a flipped code (near-ties at the
+    level of the fp32 build's own logit error) are counted and reported, and must stay the exception."""
     from pgtformer_amd.synth import make_clip
 
     recs, flips = [], 0
@@ -361,7 +361,7 @@ def test_psnr_contract_sweep_against_the_fp32_build(tail_models):
                 assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_vs_fp32_db"] >= 75.0, rec
             assert rec["psnr_fp32_vs_gt_db"] >= 25.0, rec
     _LOG["operating_point_sweep/x3f16_vs_fp32_build"] = {"windows": recs, "windows_with_a_flipped_code": flips}
-    assert flips <= 3, recs
+    assert flips <= 1, recs        # (two bf16 planes: 3 of these 12 windows; two half planes: 1, clip 4077 window 6)
 
 
 def test_whole_model_pure_bf16_report(models, golden_window):
