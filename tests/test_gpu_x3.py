@@ -305,3 +305,20 @@ def test_conv2d_x3_folded_64_channel_form(case):
     check(f"{name}_f32", got, E.conv2d(xs, wf, b, res=rf, x3_fold=True, **kw2))
     again = ops().conv2d(g(xs), g(wf), g(b), res=g(rf), x3_fold=True, **kw2)
     assert torch.equal(got, again)
+
+
+def test_split_planes_saturate_instead_of_overflowing():
+    """Half planes have a range (65504): conversions into them clamp instead of producing inf - a split tensor stays finite
+    whatever goes in (common.h split8: one clamp per value, hi cannot overflow, lo = clamped value - hi)."""
+    x = torch.tensor([[1e6, -3e5, 65504.0, 70000.0, 1.0, -2.5e-8, 0.1, 1e-3]], dtype=torch.float32).repeat(4, 2)
+    xs = ops().to_x3(g(x)).cpu()
+    assert torch.equal(xs, E.to_x3(x)) and torch.isfinite(xs.float()).all()
+    back = ops().from_x3(g(xs)).cpu()
+    assert torch.equal(back[0, :4], torch.tensor([65504.0, -65504.0, 65504.0, 65504.0]))
+    # 22 bits where the lo plane is normal; below 2^-3 it is subnormal: absolute resolution 2^-24 (error <= 3e-8)
+    assert abs(float(back[0, 4]) - 1.0) == 0 and abs(float(back[0, 6]) - 0.1) < 3.1e-8 and abs(float(back[0, 7]) - 1e-3) < 3.1e-8
+    # a split conv whose outputs leave the range: finite, clamped
+    w = ops().pack_conv_weight(g(torch.full((64, 64), 40.0)), ops().X3)
+    big = ops().to_x3(g(torch.full((1, 1, 512, 64), 100.0)))
+    y = ops().from_x3(ops().conv2d(big, w, None, x3=True))
+    assert torch.isfinite(y).all() and float(y.max()) == 65504.0
