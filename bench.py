@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--full-tail", action="store_true",
                     help="push all 3 frames of every window through the decoder's per-frame tail, as the reference does before "
                          "discarding two of them (default: middle frames only after the last temporal operation)")
-    ap.add_argument("--windows-per-forward", type=int, default=16,
+    ap.add_argument("--windows-per-forward", type=int, default=32,
                     help="independent 3-frame windows batched into one forward (reference semantics: B separate calls)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--lanes", type=int, default=2,
@@ -259,7 +259,7 @@ def clip_mode(args, model, dev, rank, world):
     lq_u8, _ = make_clip(e0 - s0, 512, seed=1234, start=s0)
     mine = torch.from_numpy(lq_u8).pin_memory()
     out_host = torch.empty((F, 512, 512, 3), dtype=torch.uint8).pin_memory() if rank == 0 else None
-    runner = WindowRunner(model, 1.0, not args.no_graph, 512, 512, batch=min(B, max(1, e0 - s0)), overlap=not args.no_overlap,
+    runner = WindowRunner(model, 1.0, not args.no_graph, 512, 512, batch=min(B, max(1, (e0 - s0 + args.lanes - 1) // args.lanes)), overlap=not args.no_overlap,
                           full_tail=args.full_tail, lanes=args.lanes)
 
     def one_pass():

@@ -432,7 +432,7 @@ def main(argv=None):
     ap.add_argument("--weights", default=None, help="checkpoint: directory (config.json + model.safetensors), hub id, "
                                                     ".safetensors or .pth")
     ap.add_argument("--synthetic", action="store_true", help="random-init weights (smoke tests only)")
-    ap.add_argument("--batch", type=int, default=16, help="sliding windows per forward")
+    ap.add_argument("--batch", type=int, default=32, help="sliding windows per forward")
     ap.add_argument("--lanes", type=int, default=2, help="forwards in flight (HIP graphs on separate streams)")
     ap.add_argument("--segment", type=int, default=256, help="frames held in host memory at a time (multiple of --batch)")
     args = ap.parse_args(argv)

@@ -366,7 +366,8 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                 st = GnStats(n, 1, ho0 * wo0, cout, gn, x.device)
         for i in range(0, n, per):
             sl = slice(i, min(n, i + per))
-            conv2d(x[sl], w, bias if bias is None or bias.dim() == 1 else bias[sl], kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, act=act,
+            fpi = bias.shape[0] // n if (bias is not None and bias.dim() == 2) else 0      # bias vectors (frames) per image
+            conv2d(x[sl], w, bias if fpi == 0 else bias[sl.start * fpi:sl.stop * fpi], kh=kh, kw=kw, stride=stride, pad=pad, ups=ups, act=act,
                    res=None if res is None else res[sl], post_relu=post_relu,
                    sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
                    tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3,
@@ -472,6 +473,13 @@ def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, 
     if out is None:
         out = torch.empty((rows, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     nimg = gn[1] if gn is not None else 1
+    if gn is None and rows * _ld_rows(x) * x.element_size() >= (1 << 31):
+        # the kernels take 32-bit byte offsets: present a >= 2 GiB row matrix as several equal "images", which conv2d runs
+        # as chunks (whole frames per image when the bias is per frame)
+        per = ((1 << 31) - 1) // (_ld_rows(x) * x.element_size())
+        frames = bias.shape[0] if (bias is not None and bias.dim() == 2) else 0
+        nimg = next((d for d in range(2, 65537) if rows % d == 0 and rows // d <= per and (frames == 0 or frames % d == 0)), None)
+        assert nimg is not None, f"linear: cannot split {rows} rows into < 2 GiB chunks"
     assert rows % nimg == 0
     hw = rows // nimg
     x4 = x.as_strided((nimg, 1, hw, cin), (hw * _ld_rows(x), 0, _ld_rows(x), 1))

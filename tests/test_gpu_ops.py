@@ -826,3 +826,22 @@ def test_compensated_half_conv_is_closer_to_fp32():
         errs[on] = float(e.mean(dim=(1, 2)).abs().mean())       # per-(frame, channel) mean error = the bias part
     _LOG.append({"name": "compensated_half_conv_bias_error", "off": errs[False], "on": errs[True]})
     assert errs[True] < 0.25 * errs[False], errs
+
+
+def test_linear_rows_beyond_2gib():
+    """A token matrix of 2 GiB or more (a 48-window batch at 128x128: 2.4 M rows of split channels) runs as equal row chunks -
+    the kernels take 32-bit byte offsets - with a per-frame bias following its frames; rows sampled across every chunk are
+    compared with the emulation (a linear is row-independent)."""
+    O = ops()
+    rows, cin, cout, frames = 3 * (1 << 20), 512, 64, 192           # 3 GiB of half; 16384 rows per frame
+    x = torch.empty((rows, cin), dtype=torch.float16, device=DEV).normal_(generator=torch.Generator(device=DEV).manual_seed(5))
+    w = rnd((cout, cin), 41, torch.float16, 0.05)
+    bias = rnd((frames, cout), 42)
+    res = torch.empty((rows, cout), dtype=torch.float16, device=DEV).normal_(generator=torch.Generator(device=DEV).manual_seed(6))
+    got = O.linear(x, g(w), g(bias), act=E.ACT_GELU, res=res)
+    pick = torch.cat([torch.arange(0, 64), torch.arange(rows // 2 - 32, rows // 2 + 32), torch.arange(rows - 64, rows),
+                      torch.arange(0, rows, 99991)])
+    fr = pick // (rows // frames)
+    want = E.linear(x[pick.to(DEV)].cpu(), w, None, act=E.ACT_NONE).float() + bias[fr]
+    want = E._act(want, E.ACT_GELU) + res[pick.to(DEV)].cpu().float()
+    check("linear_3gib_rows", got[pick.to(DEV)], want.to(torch.float16), torch.float16)
