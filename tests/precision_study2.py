@@ -185,19 +185,21 @@ def run_planes(seed, i):
     x = torch.from_numpy(window_from_clip(lq_u8, i).astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
     oc, ol, og, oln = O._conv, O._lin, O._gn, O._ln
 
-    def run(q):
+    def run(q0, part=lambda p: True):
+        """q0 applied to the operands / stored activations of the layers whose parameter prefix satisfies `part`"""
         mx = [0.0]
+        def q(p, t): return q0(t) if part(p) else t
         def conv(sd_, p, xx, stride=1, padding=0):
-            y = F.conv2d(q(xx), q(sd_[p + ".weight"]), sd_.get(p + ".bias"), stride=stride, padding=padding)
+            y = F.conv2d(q(p, xx), q(p, sd_[p + ".weight"]), sd_.get(p + ".bias"), stride=stride, padding=padding)
             mx[0] = max(mx[0], float(xx.abs().max()), float(y.abs().max()))
-            return q(y)
+            return q(p, y)
         def lin(sd_, p, xx):
-            y = F.linear(q(xx), q(sd_[p + ".weight"]), sd_.get(p + ".bias"))
+            y = F.linear(q(p, xx), q(p, sd_[p + ".weight"]), sd_.get(p + ".bias"))
             mx[0] = max(mx[0], float(xx.abs().max()), float(y.abs().max()))
-            return q(y)
+            return q(p, y)
         O._conv, O._lin = conv, lin
-        O._gn = lambda sd_, p, xx, eps=1e-6: q(og(sd_, p, xx, eps))
-        O._ln = lambda sd_, p, xx, eps=1e-5: q(oln(sd_, p, xx, eps))
+        O._gn = lambda sd_, p, xx, eps=1e-6: q(p, og(sd_, p, xx, eps))
+        O._ln = lambda sd_, p, xx, eps=1e-5: q(p, oln(sd_, p, xx, eps))
         try:
             return O.pgtformer_forward(sd, cfg, x, w=1.0, code_only=True)[0], mx[0]
         finally:
@@ -206,10 +208,15 @@ def run_planes(seed, i):
     top2 = ref.topk(2, -1).values
     gap = top2[..., 0] - top2[..., 1]
     print(f"== clip {seed} window {i}: max |activation| {mx:.1f}, smallest top-2 logit gap {float(gap.min()):.2e}, gaps < 1e-4: {int((gap < 1e-4).sum())}", flush=True)
-    for name, q in (("two bf16 planes (16 bits)", q_x3), ("two half planes (22 bits)", q_h2)):
-        lg = run(q)[0]
-        print(f"  {name:28s} logits: max err {float((lg - ref).abs().max()):.2e}  rms {float((lg - ref).pow(2).mean().sqrt()):.2e}   "
-              f"flipped codes {int((lg.argmax(-1) != ref.argmax(-1)).sum())}/{ref.argmax(-1).numel()}", flush=True)
+    parts = {"whole code branch": lambda p: True,
+             "encoder + quant_conv only": lambda p: p.startswith("encoder") or p.startswith("quant_conv"),
+             "BiSeNet + convpos only": lambda p: p.startswith("conditionnet") or p.startswith("convpos"),
+             "feat_emb + transformer + head only": lambda p: p.startswith("feat_emb") or p.startswith("ft_layers") or p.startswith("idx_pred")}
+    for pname, part in parts.items():
+        for name, q in (("two bf16 planes (16 bits)", q_x3), ("two half planes (22 bits)", q_h2)):
+            lg = run(q, part)[0]
+            print(f"  {pname:36s} {name:28s} logits: max err {float((lg - ref).abs().max()):.2e}  rms {float((lg - ref).pow(2).mean().sqrt()):.2e}   "
+                  f"flipped codes {int((lg.argmax(-1) != ref.argmax(-1)).sum())}/{ref.argmax(-1).numel()}", flush=True)
 
 
 def report(name, out, c):
