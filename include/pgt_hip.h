@@ -73,7 +73,7 @@ typedef struct pgt_conv_desc {
     int32_t out_f32;            /* 1: store y as fp32 even when dtype is bf16 (logits, distances) */
     int32_t force_bm, force_bn; /* 0 = heuristic; 64|128 pins the workgroup tile (tests, tuning)  */
     int32_t scalar_epilogue;    /* 1: force the element-wise epilogue (A/B tests); 0 = 16-byte path when legal */
-    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 3 = large-tile v3; 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-input-channel 3x3 with the weights in registers (bf16 / half; split-half: Cout % 16 == 0) */
+    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 3 = large-tile v3; 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-input-channel 3x3 with the weights in registers (bf16 / half; split-half: Cout % 16 == 0); 7 = streaming linear for Cin == 256, Cout % 256 == 0 (bf16 / half, plain epilogue, 16-bit output): weights in registers, rows through LDS */
     int32_t splitk;             /* 0 = auto (needs a workspace); 1 = never; 2..16 = that many K slices           */
     int32_t stages;             /* LDS pipeline depth for kernel = 3 (0 = default)                             */
     /* output placement: row index of output pixel m = orow_mul*m + orow_xmul*(m % Wo) + orow_off (orow_mul = 0: dense,
@@ -106,7 +106,7 @@ typedef struct pgt_conv_desc {
     int32_t bias_rows;          /* 0: `bias` holds Cout values.  > 0: `bias` is a (N*Ho*Wo / bias_rows, Cout) fp32 matrix, one
                                  * vector per bias_rows consecutive output pixels - a bias per frame (bias_rows = Ho*Wo; for
                                  * token rows: tokens per frame), the form pgt_mean_field_bias produces.  A multiple of 512
-                                 * that divides N*Ho*Wo; single-plane dtypes; kernels 0, 1, 4, 5, 6.                       */
+                                 * that divides N*Ho*Wo; single-plane dtypes; kernels 0, 1, 4, 5, 6, 7.                       */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,

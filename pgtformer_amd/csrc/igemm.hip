@@ -522,6 +522,20 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         return rc;
     }
 
+    // ---- K = 256 linears on very many rows: the streaming kernel (igemm7.hip), the static choice from 65 536 rows up
+    {
+        const bool v7 = d->dtype != PGT_F32 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->ups == 0 && d->Cin == 256 &&
+                        d->Cout % 256 == 0 && d->epi == 0 && !d->out_f32 && d->gn_groups == 0 && d->orow_mul == 0 && p.vec_epi &&
+                        d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W && d->ldx % 8 == 0 && d->ldy % 8 == 0 &&
+                        (!residual || d->ldr % 8 == 0) && ((uintptr_t)x & 15) == 0;
+        PGT_CHECK(d->kernel != 7 || v7, "pgt_conv2d: kernel=7 is the K = 256 linear: bf16 / half, 1x1, Cin == 256, Cout %% 256 == 0, plain epilogue, 16-bit output");
+        // (wider layers - the 256 -> 768 q|k|v projection - would re-read their rows once per 256 columns: measured 38 % slower
+        //  than the phased kernel, so only Cout == 256 takes it by default)
+        if (v7 && (d->kernel == 7 || (d->kernel == 0 && d->Cout == 256 && p.M >= 65536 && d->force_bm == 0 && d->force_bn == 0 &&
+                                      d->splitk <= 1 && !d->scalar_epilogue)))
+            return pgt_igemm7_launch(&p, st);
+    }
+
     // ---- split-K: slices write fp32 partial tiles to the workspace, a second kernel sums + applies the epilogue
     const int slices = (workspace && p.vec_epi) ? planned_splitk(d) : 1;
     if (slices > 1) {

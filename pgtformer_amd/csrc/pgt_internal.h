@@ -27,3 +27,5 @@ int pgt_igemm5_launch(const void* conv_p, hipStream_t st);
 int pgt_igemm6_launch(const void* conv_p, hipStream_t st);
 // igemm6x3.hip: the same layers on split-half operands (Cout % 16 == 0): hi / lo weights in registers, MFMA 16x16x32, three products
 int pgt_igemm6x3_launch(const void* conv_p, hipStream_t st);
+// igemm7.hip: streaming linear for K = 256 on many rows (weights in registers, rows through LDS, two workgroups per CU)
+int pgt_igemm7_launch(const void* conv_params, hipStream_t st);

@@ -845,3 +845,40 @@ def test_linear_rows_beyond_2gib():
     want = E.linear(x[pick.to(DEV)].cpu(), w, None, act=E.ACT_NONE).float() + bias[fr]
     want = E._act(want, E.ACT_GELU) + res[pick.to(DEV)].cpu().float()
     check("linear_3gib_rows", got[pick.to(DEV)], want.to(torch.float16), torch.float16)
+
+
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("case", ["ragged_256", "qkv_768", "views_resid", "tokens_frames"])
+def test_linear_k256_streaming_kernel(dtype, case):
+    """igemm7 (K = 256 linears on many rows: weights in registers, rows through a double-buffered LDS image, fp32 stage):
+    ragged row counts, 768 output columns, strided operands with residual and GELU, a per-frame bias - forced (kernel=7)
+    and, from 65 536 rows up, as the library's own choice; against the emulation and the phased kernel (kernel=4)."""
+    O = ops()
+    cout, rows, frames = 256, 4096 + 17, 0
+    if case == "qkv_768":
+        cout, rows = 768, 2048 + 31
+    elif case == "tokens_frames":
+        rows, frames = 131072, 8
+    x = rnd((rows, 256), 51, dtype)
+    w = rnd((cout, 256), 52, dtype, 0.06)
+    bias = rnd((frames, cout), 53) if frames else rnd((cout,), 53)
+    kw = {}
+    want_kw = {}
+    if case == "views_resid":
+        wide = rnd((rows, 640), 54, dtype)
+        x = wide[:, 128:384]                               # a channel slice: ldx = 640
+        resw = rnd((rows, 512), 55, dtype)
+        kw = dict(act=E.ACT_GELU, res=resw[:, 256:])
+    elif case == "tokens_frames":
+        kw = dict(act=E.ACT_GELU, res=rnd((rows, cout), 55, dtype))
+    xg = g(wide)[:, 128:384] if case == "views_resid" else g(x)
+    kwg = {k: (g(resw)[:, 256:] if (k == "res" and case == "views_resid") else (g(v) if torch.is_tensor(v) else v)) for k, v in kw.items()}
+    want = E.linear(x, w, bias, **kw)
+    x4 = xg.as_strided((1, 1, rows, 256), (0, 0, xg.stride(0), 1))
+    r4 = None if "res" not in kwg else kwg["res"].as_strided((1, 1, rows, cout), (0, 0, kwg["res"].stride(0), 1))
+    for kern in ((7, 4, 0) if rows >= 65536 else (7, 4)):
+        got = O.conv2d(x4, g(w), g(bias), act=kw.get("act", E.ACT_NONE), res=r4, kernel=kern)
+        check(f"linear_k256_{case}_k{kern}", got.reshape(rows, cout), want, dtype)
+        if kern == 7:
+            ref7 = got.clone()
+    assert torch.equal(got.reshape(rows, cout), ref7.reshape(rows, cout)) or rows < 65536     # kernel 0 == kernel 7 from 65 536 rows
