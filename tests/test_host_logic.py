@@ -222,3 +222,53 @@ def test_overlap_aware_windows_equal_stacked_windows(cpu_model, monkeypatch):
     _, lb, qb = cpu_model.forward_nhwc(frames[win.long()].contiguous(), w=1.0, code_only=True)
     assert la.shape == lb.shape == (6, 32, 32, 1, 1024)
     assert torch.equal(la, lb) and torch.equal(qa, qb)
+
+
+def test_weight_rounding_compensation_host_logic(monkeypatch):
+    """DESIGN.md section 2.2 on the CPU emulation: the defect matrix of a prepared half conv is sum over taps of (W - half(W))
+    (also with a folded BatchNorm scale and zero-padded input channels), the per-frame bias it gives puts the frame-constant
+    part of the rounding error back (a conv on per-frame CONSTANT inputs becomes exact), a layer whose frames are not whole
+    512-row tiles keeps its plain bias, and fp32 / split layers carry no defect."""
+    import pgtformer_amd.modules.rstt_layers as R
+    from pgtformer_amd import ops
+    emu_ops.install(monkeypatch)
+    torch.manual_seed(11)
+    conv = R.Conv2d(24, 32, 3, padding=1, cin_pad=32)
+    bn = torch.nn.BatchNorm2d(32)
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.normal_(); bn.bias.data.normal_()
+    conv._bn_ref = (bn.eval(),)
+    R.prepare_tree(conv, torch.device("cpu"), torch.float16)
+    scale, _ = ops.fold_batchnorm(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, conv.bias.detach())
+    w = conv.weight.detach().float() * scale.view(-1, 1, 1, 1)
+    want = (w - w.half().float()).sum(dim=(2, 3))                          # (Cout, Cin)
+    assert conv.pdef.shape == (32, 32) and conv.pdef.dtype == torch.float32                # (Cin_pad, Cout)
+    assert torch.allclose(conv.pdef[:24].t(), want, rtol=0, atol=1e-9) and not conv.pdef[24:].any()
+    # per-frame constant inputs (exactly representable in half): W16 x + b + D mean(x) == W x + b away from the zero-padded border
+    x = torch.zeros((3, 32, 32, 32))
+    x[..., :24] = (torch.randint(1, 64, (3, 1, 1, 24)) / 16.0)
+    y = conv.run(x.half()).float()
+    bias_bn = (conv.bias.detach() - bn.running_mean) * scale + bn.bias.detach()
+    exact = torch.einsum("ok,nk->no", w.sum(dim=(2, 3)), x[:, 0, 0, :24]) + bias_bn
+    assert (y[:, 8, 8, :] - exact).abs().max() < 2e-3 * exact.abs().max()      # only the output's own half rounding is left
+    R.USE_WCOMP = False
+    try:
+        plain = R.Conv2d(24, 32, 3, padding=1, cin_pad=32)
+        plain.load_state_dict(conv.state_dict())
+        plain._bn_ref = (bn,)
+        R.prepare_tree(plain, torch.device("cpu"), torch.float16)
+        assert plain.pdef is None
+    finally:
+        R.USE_WCOMP = True
+    # frames that are not whole 512-row tiles: the plain (Cout,) bias is used
+    assert R._frame_bias(torch.zeros((2, 8, 8, 32), dtype=torch.float16), conv.pdef, conv.pb) is conv.pb
+    assert R._frame_bias(torch.zeros((2, 32, 32, 32), dtype=torch.float16), conv.pdef, conv.pb).shape == (2, 32)
+    # token rows: per-frame bias only with a frame count that divides the rows into whole tiles
+    lin = R.Linear(64, 48)
+    R.prepare_tree(lin, torch.device("cpu"), torch.float16)
+    t = torch.randn(4 * 1024, 64).half()
+    assert R._frame_bias(t, lin.pdef, lin.pb, None) is lin.pb and R._frame_bias(t, lin.pdef, lin.pb, 4).shape == (4, 48)
+    assert R._frame_bias(t, lin.pdef, lin.pb, 16) is lin.pb                   # 256 rows per frame: not a whole tile
+    for dt in (torch.float32, ops.X3):
+        other = R.Linear(64, 64)
+        R.prepare_tree(other, torch.device("cpu"), dt)
+        assert other.pdef is None
