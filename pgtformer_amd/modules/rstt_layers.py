@@ -86,8 +86,9 @@ def _defect_t(w, pw, scale=None, sum_taps=True):
 
 
 def _frame_bias(x, pdef, pb, frames=None):
-    """per-frame bias of a compensated layer: x (N,H,W,C) image batch, or (rows, C) tokens of `frames` frames; None when the
-    layer is not compensated or its frames are not whole 512-row tiles (pgt_conv_desc::bias_rows)"""
+    """bias operand of a layer: the (frames, Cout) per-frame bias of a compensated layer - x (N,H,W,C) image batch, or
+    (rows, C) tokens of `frames` frames - or the plain (Cout,) bias `pb` when the layer is not compensated or its frames are
+    not whole 512-row tiles (pgt_conv_desc::bias_rows)"""
     if pdef is None:
         return pb
     if x.dim() == 2:
