@@ -167,10 +167,41 @@ int pgt_sampled_channel_mean(int32_t dtype, const void* x, int32_t ldx, int32_t 
 int pgt_sampled_pixel(int32_t HW, int32_t i);
 int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* bias, int32_t R, int32_t K, int32_t Cout,
                         float* out, pgt_stream_t stream);
+/* The sampled mean for a layer that reads NORMALISED rows (pgt_ln_linear below): mean[n][c] over frame n's sample of
+ * half((x[p][c] - mu_p) * rstd_p), mu_p / rstd_p = the LayerNorm statistics of row p over its C channels (C = 256 or 512;
+ * PGT_F16 / PGT_BF16). */
+int pgt_sampled_rownorm_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C, float eps,
+                             float* mean, pgt_stream_t stream);
 /* AdaIN coefficients: scale = sqrt(var_s+eps)/sqrt(var_c+eps), shift = mean_s - mean_c*scale
  * (adaptive_instance_normalization, codeformer_arch.py:32-46); n = N*C entries */
 int pgt_adain_affine(const float* mean_c, const float* var_c, const float* mean_s, const float* var_s,
                      float eps, float* scale, float* shift, int32_t n, pgt_stream_t stream);
+
+/* ---- fused token-row chains of the 256-channel window-attention blocks (round 4) -------------------------------------
+ * A VSTSREncoderTransformerBlock (modules/rstt_layers.py:284-338) is, per token row: LN1 -> [q | k | v] Linear -> window
+ * attention -> proj Linear + shortcut -> LN2 -> fc1 -> GELU -> fc2 + residual.  Layer by layer a row crosses HBM 14 times; these
+ * two entry points keep it on chip between its element-wise and GEMM steps (rows in registers as the MFMA B operand, weights
+ * streaming through an LDS ring), so that only the block's input / output and the attention operands touch HBM.
+ *
+ * pgt_fold_layernorm: LN(x) W^T + b = xhat (W diag(gamma))^T + (b + W beta), xhat = (x - mean) / sqrt(var + eps).  w: fp32
+ * (Cout, Cin) as the reference stores nn.Linear weights; w_out (may alias w) is then packed with pgt_pack_conv_weight;
+ * bias_out (Cout) replaces the bias (bias may be NULL = 0).
+ * pgt_ln_linear: y = half(xhat) W'^T + bias' on rows of Cin = 256 channels, PGT_F16; W' (Cout, 256) K-major half rows, Cout a
+ * multiple of 128 up to 768; bias' (Cout) fp32, or with bias_rows > 0 a (rows / bias_rows, Cout) matrix - one vector per
+ * bias_rows consecutive rows (a multiple of 256 that divides rows), the form pgt_mean_field_bias produces from
+ * pgt_sampled_rownorm_mean.  Replaces norm1 + q / kv Linear (:298, :195-213).
+ * pgt_attn_proj_mlp: x1 = attn Wproj^T + b_proj + shortcut (rounded to half);  y = x1 + fc2(GELU(fc1(LN2(x1)))) with
+ * w3 = [Wproj; Wfc1 diag(gamma2); Wfc2] stacked (768, 256) K-major half rows, b_fc1 carrying W1 beta2 (pgt_fold_layernorm),
+ * b_proj optionally per frame (b_proj_rows as bias_rows above, a multiple of 128).  Replaces proj + shortcut add (:230-232,
+ * :329), norm2, Mlp (:126-132, mlp_ratio = 1: archs/tdcrqvae3_arch.py:499) and the residual add (:335-337).  GELU is the
+ * exact-erf form (erf to 1.5e-7).  y may alias neither input. */
+int pgt_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int32_t Cout, int32_t Cin,
+                       float* w_out, float* bias_out, pgt_stream_t stream);
+int pgt_ln_linear(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t Cin, float eps, const void* w,
+                  const float* bias, int32_t bias_rows, int32_t Cout, void* y, int32_t ldy, pgt_stream_t stream);
+int pgt_attn_proj_mlp(int32_t dtype, const void* attn, int32_t lda, const void* shortcut, int32_t lds, int32_t rows, int32_t C,
+                      const void* w3, const float* b_proj, int32_t b_proj_rows, const float* b_fc1, const float* b_fc2,
+                      float eps, void* y, int32_t ldy, pgt_stream_t stream);
 
 /* ---- attention -------------------------------------------------------------------------------
  * (T,Wh,Ww)-window multi-head self-attention with cyclic shift, relative-position bias and the

@@ -503,6 +503,52 @@ __global__ __launch_bounds__(256) void sampled_mean_kernel(const T* __restrict__
     }
 }
 
+// The same mean for a layer that reads the NORMALISED rows of x (pgt_ln_linear: the LayerNorm's affine part lives in its
+// weights): mean[n][c] over the frame's sample of half((x[p][c] - mu_p) * rstd_p), mu_p / rstd_p the LayerNorm statistics of
+// row p over its C channels.  One workgroup per frame, one wavefront per sampled row at a time, partial sums combined in
+// wave order (deterministic).
+template <typename T, int EPL>
+__global__ __launch_bounds__(1024) void sampled_rownorm_mean_kernel(const T* __restrict__ x, int ldx, int HW, int C, float eps,
+                                                                    float* __restrict__ mean) {
+    __shared__ float part[16][64 * EPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x;
+    int run, cells, cell;
+    mean_sample_geometry(HW, &run, &cells, &cell);
+    const int S = cells * run;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    const T* base = x + (long)n * HW * ldx + lane * EPL;
+    for (int i = wave; i < S; i += 16) {
+        float v[EPL];
+        RowIO<T, EPL, true>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s += v[e];
+        const float mu = wave_sum(s) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { v[e] -= mu; ss += v[e] * v[e]; }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            T r;
+            stf(&r, v[e] * rstd);          // the rounding the consuming kernel applies to its operand
+            acc[e] += ldf(&r);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) part[wave][lane * EPL + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += part[k][c];
+        mean[(long)n * C + c] = tot / (float)S;
+    }
+}
+
 // out[r][o] = bias[o] + sum_k defect_t[k][o] * mean[r][k]: a workgroup = OL outputs x kMfbFrames frames, K cut in 256 / OL
 // slices that are summed in slice order - one fixed order whatever the grid
 constexpr int kMfbFrames = 4;
@@ -746,6 +792,20 @@ extern "C" int pgt_sampled_channel_mean(int32_t dtype, const void* x, int32_t ld
         hipLaunchKernelGGL((sampled_mean_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, C, mean);
     else
         PGT_CHECK(false, "sampled_channel_mean: bad dtype %d", dtype);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_sampled_rownorm_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C, float eps,
+                                        float* mean, pgt_stream_t stream) {
+    PGT_CHECK(x && mean && N >= 1 && HW >= 1, "sampled_rownorm_mean: null argument");
+    PGT_CHECK((C == 256 || C == 512) && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "sampled_rownorm_mean: C=%d (256 or 512), ldx=%d (multiple of 8)", C, ldx);
+    hipStream_t st = (hipStream_t)stream;
+#define SRM(T_, E_) hipLaunchKernelGGL((sampled_rownorm_mean_kernel<T_, E_>), dim3(N), dim3(1024), 0, st, (const T_*)x, ldx, HW, C, eps, mean)
+    if (dtype == PGT_BF16) { if (C == 256) SRM(bf16_t, 4); else SRM(bf16_t, 8); }
+    else if (dtype == PGT_F16) { if (C == 256) SRM(half_t, 4); else SRM(half_t, 8); }
+    else PGT_CHECK(false, "sampled_rownorm_mean: bad dtype %d", dtype);
+#undef SRM
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,426 @@
+// Token-row chains of the 256-channel window-attention blocks, fused (round 4).
+//
+// A VSTSREncoderTransformerBlock (reference: modules/rstt_layers.py:284-338, Mlp :126-132, the q / kv / proj Linears of
+// WindowAttention3D :195-234) is, per token row of C = 256 channels,
+//      LN1 -> [q | k | v] Linear ............. window attention ............. proj Linear + shortcut -> LN2 -> fc1 -> GELU -> fc2 + x1
+// Run layer by layer, a row crosses HBM 14 times (10 KB per row in half, 20 KB in split-half) for 0.84 MFLOP: every one of
+// those launches is HBM-bound.  The two kernels here keep a row ON CHIP between its element-wise and
+// GEMM steps, so that only the attention operands and the block's input / output touch HBM (5 KB per row):
+//
+//   chain 0  "ln_linear":  y = LN(x) W^T + b                       (x: rows x 256, W: Cout x 256, Cout a multiple of 128)
+//   chain 1  "proj_mlp":   x1 = a Wp^T + bp + s;  y = x1 + fc2(GELU(fc1(LN(x1))))      (a = attention output, s = shortcut)
+//
+// Design - the ROWS live in registers, the WEIGHTS stream through LDS:
+//   * swapped GEMM on v_mfma_f32_16x16x32_f16: C^T[out column, row] = W[out column, k] . X^T[k, row].  A wave owns 16 rows
+//     (RT = 1) or 32 (RT = 2: two row tiles under the same weight fragments); its B operand - X^T, 8 k-steps of 32 - is the
+//     row itself, 16 bytes per lane and k-step: lane (g, n) holds x[row n][32 ks + 8 g .. + 8].
+//   * the weights of 32 output columns (one CHUNK: 32 x 512 B = 16 KiB, K-major rows as pgt_pack_conv_weight writes them)
+//     enter a ring of NS LDS slots by LDS-DMA (buffer_load ... lds), XOR-swizzled on the source side so that the A-fragment
+//     ds_read_b128 is conflict-free; every wave reads every chunk once.  A chunk is two 16-column MFMA tiles whose rows are
+//     interleaved so that lane (g, n) ends up with the EIGHT CONSECUTIVE output columns 32 q + 8 g .. + 8 of row n:
+//       - that is one 16-byte store of the output row, and
+//       - packed to half it is exactly the B fragment of k-step q of the NEXT GEMM: the chain never leaves the registers
+//         (x1, LN2(x1) and the GELU'd hidden row are 32 VGPRs each).
+//   * LayerNorm: a row is spread over 4 lanes (64 values each): two-pass statistics in registers, two cross-lane adds.
+//   * one barrier per chunk (DMA of chunk c + NS - 1 is issued right after the barrier that retires chunk c - 1); counted
+//     s_waitcnt vmcnt so that NS - 2 chunks stay in flight across the barrier.
+//   * persistent workgroups (8 waves = 128 RT rows per tile), one per CU.
+// Numerics are those of the unfused launches: x1, LN outputs and the hidden row are rounded to half exactly where the
+// layer-by-layer path stores them; accumulation and statistics are fp32.  GELU is the exact-erf form with erf from
+// Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the half rounding that follows it).
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+#include "pgt_internal.h"
+#include "igemm_common.h"
+
+namespace {
+
+typedef _Float16 rc_half8 __attribute__((ext_vector_type(8)));
+
+#define RC_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RC_BARRIER() do { RC_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); RC_FENCE(); } while (0)
+#define RC_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+struct RowChainP {
+    const char* x;        // chain 0: input rows; chain 1: attention output rows
+    const char* res;      // chain 1: shortcut rows (the block's input)
+    char* y;
+    const char* w;        // chain 0: (ncol, 256); chain 1: [Wproj; Wfc1; Wfc2] = (768, 256); K-major half rows
+    const float* b0;      // chain 0: bias (ncol); chain 1: proj bias (256); one vector per b0_rows rows when b0_rows > 0
+    const float* b1;      // chain 1: fc1 bias
+    const float* b2;      // chain 1: fc2 bias
+    int ldx, ldr, ldy;    // row strides in elements
+    int M, ncol, b0_rows;
+    float eps;
+};
+
+constexpr int kRcNS = 4;                        // ring slots
+constexpr int kRcChunk = 32 * 512;              // bytes of one weight chunk (32 output columns x 256 k, half)
+constexpr int kRcMaxCol = 768;
+constexpr int kRcLds = kRcNS * kRcChunk + 2 * kRcMaxCol * 4;   // ring + two bias buffers
+
+__device__ __forceinline__ f32x4 rc_mma(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rc_half8, a), __builtin_bit_cast(rc_half8, b), c, 0, 0, 0);
+}
+
+// exact-erf GELU with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 on erf)
+__device__ __forceinline__ float rc_gelu(float x) {
+    const float z = x * 0.70710678118654752440f, az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(az * az * -1.44269504088896340736f);
+    const float er = copysignf(fmaf(-p, e, 1.0f), z);
+    const float hx = 0.5f * x;
+    return fmaf(hx, er, hx);
+}
+
+// LayerNorm statistics of the 16 rows a wave holds as B fragments (lane (g, n): 8 values of row n per k-step), applied WITHOUT
+// the affine part: b <- half((b - mean) * rstd).  gamma and beta live in the weights of the GEMM that follows
+// (pgt_fold_layernorm: W' = W diag(gamma), b' = b + W beta - LN(x) W^T + b = xhat W'^T + b'), so the normalisation needs no
+// per-channel operands.  Two-pass statistics in fp32, as layernorm_kernel (norms.hip).
+__device__ __forceinline__ void rc_normalize(uint4 (&b)[8], float eps) {
+    float v[64];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) Vec16<half_t>::unpack(b[ks], v + 8 * ks);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) s += v[e];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 256.0f);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) { v[e] -= mean; ss = fmaf(v[e], v[e], ss); }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + eps);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[8 * ks + e] *= rstd;
+        b[ks] = Vec16<half_t>::pack(v + 8 * ks);
+    }
+}
+
+// NW waves per workgroup (8 or 16), RT row tiles of 16 rows per wave
+template <int MODE, int RT, int NW>
+__global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntiles) {
+    static_assert(MODE == 0 || RT == 1, "the three-GEMM chain keeps one row tile per wave");
+    static_assert(NW == 8 || NW == 16, "16 DMA pieces per chunk are dealt to 8 or 16 waves");
+    constexpr int kRcWaves = NW;
+    constexpr int kRcPPC = 16 / NW;                     // DMA pieces (1 KiB) per wave and chunk
+    constexpr int TR = kRcWaves * 16 * RT;              // rows per workgroup tile
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float* const bias_l = reinterpret_cast<float*>(smem + kRcNS * kRcChunk);    // two buffers of kRcMaxCol floats
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const int NQ = MODE == 0 ? p.ncol / 32 : 24;        // chunks per tile
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * NQ;                    // chunks this workgroup consumes
+    const unsigned lds0 = lds_addr(smem);
+    const v4i rsrc_w = make_rsrc(p.w, (unsigned)(NQ * kRcChunk));
+
+    // ---- DMA role: piece j = PPC wave + i holds chunk rows 2 j, 2 j + 1; lane l -> row a = 2 j + (l >> 5), slot l & 31, which
+    //      receives source chunk (slot ^ f(a)), f(a) = ((a >> 3) << 2) | (a & 3)
+    unsigned dma_off[kRcPPC];
+#pragma unroll
+    for (int i = 0; i < kRcPPC; ++i) {
+        const int a = 2 * (kRcPPC * wave + i) + (lane >> 5);
+        const int f = ((a >> 3) << 2) | (a & 3);
+        dma_off[i] = (unsigned)(a * 512 + (((lane & 31) ^ f) << 4));
+    }
+    int iss_q = 0, iss_slot = 0, iss_idx = 0;           // next chunk to issue: index inside the tile, ring slot, running index
+    auto issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < kRcPPC; ++i)
+            bufdma16(dma_off[i], rsrc_w, iss_q * kRcChunk, lds0 + iss_slot * kRcChunk + (kRcPPC * wave + i) * 1024);
+        iss_q = iss_q + 1 == NQ ? 0 : iss_q + 1;
+        iss_slot = (iss_slot + 1) & (kRcNS - 1);
+        ++iss_idx;
+    };
+    for (int i = 0; i < kRcNS - 1 && i < total; ++i) issue();
+
+    // ---- static operands into LDS (visible after the first chunk barrier)
+    if (MODE == 1) {
+        if (tid < 256) { bias_l[256 + tid] = p.b1[tid]; bias_l[kRcMaxCol + 256 + tid] = p.b1[tid]; }
+        else if (tid < 512) { bias_l[256 + tid] = p.b2[tid - 256]; bias_l[kRcMaxCol + 256 + tid] = p.b2[tid - 256]; }
+    }
+    const int nb0 = MODE == 0 ? p.ncol : 256;
+    if (p.b0_rows == 0)
+        for (int i = tid; i < nb0; i += 64 * kRcWaves) bias_l[i] = p.b0 ? p.b0[i] : 0.f;
+    int cur_frame = -1, cur_buf = 0;
+
+    // A fragment of (16-column tile t, k-step ks) of a slot: lane (g, m = n) reads chunk row 8 (m >> 2) + 4 t + (m & 3), 16-byte
+    // chunk 4 ks + g, stored in slot (4 ks + g) ^ m: byte (abase ^ (ks << 6)) + 2048 t
+    const int abase = (8 * (n >> 2) + (n & 3)) * 512 + ((g ^ n) << 4);
+    int idx = 0;                                        // running index of the chunk being consumed
+    // one chunk: retire its DMA, release the slot of the previous one, keep the ring full, multiply
+    auto chunk_mma = [&](f32x4 (&acc)[RT][2], const uint4 (&b)[RT][8]) {
+        const int after = total - 1 - idx;              // chunks issued after this one (capped by the ring)
+        if (after >= kRcNS - 2) RC_VMWAIT((kRcNS - 2) * kRcPPC);
+        else if (after == 1) RC_VMWAIT(kRcPPC);
+        else RC_VMWAIT(0);
+        RC_BARRIER();
+        if (iss_idx < total) issue();
+        const char* sp = smem + (idx & (kRcNS - 1)) * kRcChunk;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        constexpr int KG = MODE == 0 ? 4 : 2;           // k-steps whose fragments are in flight together (2 x KG x 4 VGPRs)
+#pragma unroll
+        for (int k4 = 0; k4 < 8; k4 += KG) {
+            uint4 a0[KG], a1[KG];
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                a0[j] = *reinterpret_cast<const uint4*>(sp + (abase ^ ((k4 + j) << 6)));
+                a1[j] = *reinterpret_cast<const uint4*>(sp + 2048 + (abase ^ ((k4 + j) << 6)));
+            }
+#pragma unroll
+            for (int j = 0; j < KG; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][0] = rc_mma(a0[j], b[rt][k4 + j], acc[rt][0]);
+                    acc[rt][1] = rc_mma(a1[j], b[rt][k4 + j], acc[rt][1]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ++idx;
+    };
+    // the 8 consecutive columns 32 q + 8 g .. + 8 of this lane's row: accumulator (t, r) = column 4 t + r of them
+    auto cols8 = [&](const f32x4 (&acc)[2], float* v) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * t + r] = acc[t][r];
+    };
+    auto add_bias = [&](float* v, const float* bp) {
+        float bv[8];
+        *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(bp);
+        *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(bp + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+    };
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = (long)tile * TR;
+        // ---- per-frame bias of the first GEMM: refreshed into the other LDS buffer when the tile enters a new frame
+        if (p.b0_rows > 0) {
+            const int frame = (int)(row0 / p.b0_rows);
+            if (frame != cur_frame) {
+                cur_frame = frame;
+                cur_buf ^= 1;
+                for (int i = tid; i < nb0; i += 64 * kRcWaves) bias_l[cur_buf * kRcMaxCol + i] = p.b0[(long)frame * nb0 + i];
+            }
+        }
+        const float* bl = bias_l + cur_buf * kRcMaxCol;
+        // ---- this wave's rows as B fragments
+        long rows[RT];
+        uint4 b[RT][8];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            rows[rt] = row0 + (wave * RT + rt) * 16 + n;
+            const long rr = rows[rt] < p.M ? rows[rt] : p.M - 1;
+            const uint4* xp = reinterpret_cast<const uint4*>(p.x + (rr * p.ldx + 8 * g) * 2);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) b[rt][ks] = xp[4 * ks];
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) rc_normalize(b[rt], p.eps);
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 acc[RT][2];
+                chunk_mma(acc, b);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float v[8];
+                    cols8(acc[rt], v);
+                    add_bias(v, bl + 32 * q + 8 * g);
+                    if (rows[rt] < p.M)
+                        *reinterpret_cast<uint4*>(p.y + (rows[rt] * p.ldy + 32 * q + 8 * g) * 2) = Vec16<half_t>::pack(v);
+                }
+            }
+        } else {
+            // shortcut rows, in the layout of the GEMM output (8 consecutive columns per chunk)
+            uint4 sc[8];
+            {
+                const long rr = rows[0] < p.M ? rows[0] : p.M - 1;
+                const uint4* rp = reinterpret_cast<const uint4*>(p.res + (rr * p.ldr + 8 * g) * 2);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sc[q] = rp[4 * q];
+            }
+            uint4 x1[1][8];
+            // ---- proj + bias + shortcut -> x1 (rounded to half: the tensor the layer-by-layer path stores)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 acc[1][2];
+                chunk_mma(acc, b);
+                float v[8], s[8];
+                cols8(acc[0], v);
+                add_bias(v, bl + 32 * q + 8 * g);
+                Vec16<half_t>::unpack(sc[q], s);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += s[e];
+                x1[0][q] = Vec16<half_t>::pack(v);
+                x3_opaque(x1[0][q]);                    // finished HERE: keeps the compiler from sinking the epilogues below the loop
+            }
+            // ---- LN2
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b[0][q] = x1[0][q];
+            rc_normalize(b[0], p.eps);
+            // ---- fc1 + bias + GELU -> hidden row (half)
+            uint4 hid[1][8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 acc[1][2];
+                chunk_mma(acc, b);
+                float v[8];
+                cols8(acc[0], v);
+                add_bias(v, bl + 256 + 32 * q + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rc_gelu(v[e]);
+                hid[0][q] = Vec16<half_t>::pack(v);
+                x3_opaque(hid[0][q]);
+            }
+            // ---- fc2 + bias + x1 -> out
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 acc[1][2];
+                chunk_mma(acc, hid);
+                float v[8], s[8];
+                cols8(acc[0], v);
+                add_bias(v, bl + 512 + 32 * q + 8 * g);
+                Vec16<half_t>::unpack(x1[0][q], s);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += s[e];
+                if (rows[0] < p.M)
+                    *reinterpret_cast<uint4*>(p.y + (rows[0] * p.ldy + 32 * q + 8 * g) * 2) = Vec16<half_t>::pack(v);
+            }
+        }
+    }
+    RC_VMWAIT(0);
+}
+
+int rc_cus();
+
+template <int MODE, int RT, int NW> int rc_launch(const RowChainP& p, hipStream_t st) {
+    constexpr int TR = NW * 16 * RT;
+    const int ntiles = (p.M + TR - 1) / TR;
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowchain_kernel<MODE, RT, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kRcLds);
+        if (e != hipSuccess) { pgt_set_error("rowchain: cannot reserve %d B of LDS: %s", kRcLds, hipGetErrorString(e)); return -12; }
+        attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const int cus = rc_cus();
+    if (cus <= 0) { pgt_set_error("rowchain: cannot query the device"); return -5; }
+    const int grid = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL((rowchain_kernel<MODE, RT, NW>), dim3(grid), dim3(64 * NW), kRcLds, st, p, ntiles);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+int rc_common_checks(const char* who, const RowChainP& p, int tr) {
+    PGT_CHECK(p.x && p.y && p.w && p.M >= 1, "%s: null argument", who);
+    PGT_CHECK(p.ldx % 8 == 0 && p.ldy % 8 == 0 && ((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.y & 15) == 0 && ((uintptr_t)p.w & 15) == 0,
+              "%s: rows must be 16-byte aligned (ldx=%d ldy=%d)", who, p.ldx, p.ldy);
+    PGT_CHECK(p.b0_rows == 0 || (p.b0 && p.b0_rows % tr == 0 && p.M % p.b0_rows == 0),
+              "%s: bias_rows=%d must be a multiple of the %d-row tile and divide rows=%d", who, p.b0_rows, tr, p.M);
+    return 0;
+}
+
+int rc_cus() {
+    static std::atomic<int> n_cu{0};
+    if (n_cu.load(std::memory_order_relaxed) == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n_cu.store(prop.multiProcessorCount, std::memory_order_relaxed);
+    }
+    return n_cu.load(std::memory_order_relaxed);
+}
+
+// w_out[o][k] = w[o][k] * gamma[k];  bias_out[o] = bias[o] + sum_k w[o][k] * beta[k]   (one wavefront per output row, fixed order)
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             int Cout, int Cin, float* __restrict__ w_out, float* __restrict__ bias_out) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= Cout) return;
+    float s = 0.f;
+    for (int k = lane; k < Cin; k += 64) {
+        const float v = w[(long)o * Cin + k];
+        w_out[(long)o * Cin + k] = v * gamma[k];
+        s = fmaf(v, beta[k], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) bias_out[o] = (bias ? bias[o] : 0.f) + s;
+}
+
+}  // namespace
+
+// LayerNorm's affine part folded into the Linear that follows it: LN(x) W^T + b = xhat (W diag(gamma))^T + (b + W beta), xhat the
+// normalised row.  w: fp32 (Cout, Cin) as the reference stores it; w_out (may alias w) is then packed with pgt_pack_conv_weight.
+extern "C" int pgt_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int32_t Cout,
+                                  int32_t Cin, float* w_out, float* bias_out, pgt_stream_t stream) {
+    PGT_CHECK(w && gamma && beta && w_out && bias_out && Cout >= 1 && Cin >= 1, "fold_layernorm: null argument");
+    hipLaunchKernelGGL(fold_layernorm_kernel, dim3((Cout + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, bias, Cout, Cin, w_out, bias_out);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = xhat W'^T + bias' on rows of 256 channels (PGT_F16), xhat = (x - mean) / sqrt(var + eps) rounded to half: norm1 + the fused
+// [q | k | v] projection of a window-attention block (modules/rstt_layers.py:298, 195-213) - or any LayerNorm -> Linear pair with
+// Cin = 256 - with the LayerNorm's gamma / beta folded into w / bias by pgt_fold_layernorm.
+extern "C" int pgt_ln_linear(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t Cin, float eps, const void* w,
+                             const float* bias, int32_t bias_rows, int32_t Cout, void* y, int32_t ldy, pgt_stream_t stream) {
+    PGT_CHECK(dtype == PGT_F16, "ln_linear: dtype %d (PGT_F16 only)", dtype);
+    PGT_CHECK(Cin == 256 && Cout >= 128 && Cout % 128 == 0 && Cout <= kRcMaxCol, "ln_linear: Cin=%d (256), Cout=%d (multiple of 128, <= %d)", Cin, Cout, kRcMaxCol);
+    RowChainP p{};
+    p.x = (const char*)x; p.y = (char*)y; p.w = (const char*)w;
+    p.b0 = bias; p.b0_rows = bias_rows; p.eps = eps;
+    p.ldx = ldx; p.ldy = ldy; p.M = rows; p.ncol = Cout;
+    PGT_CHECK(ldx >= Cin && ldy >= Cout, "ln_linear: ldx=%d ldy=%d", ldx, ldy);
+    const int cus = rc_cus();
+    PGT_CHECK(cus > 0, "ln_linear: cannot query the device");
+    // two row tiles per wave (256-row workgroup tiles: half the weight traffic and half the LDS reads per row) once they still
+    // fill the chip.  PGT_RC_LN = r1w8 | r2w8 | r1w16 pins the variant (tuning).
+    const char* e = getenv("PGT_RC_LN");
+    const int forced = !e ? 0 : !strcmp(e, "r1w8") ? 1 : !strcmp(e, "r2w8") ? 2 : !strcmp(e, "r1w16") ? 3 : 0;
+    int var = forced ? forced : (rows >= 256 * cus ? 2 : 1);
+    if (var != 1 && bias_rows % 256 != 0) var = 1;
+    if (int rc = rc_common_checks("ln_linear", p, var == 1 ? 128 : 256)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return var == 1 ? rc_launch<0, 1, 8>(p, st) : var == 2 ? rc_launch<0, 2, 8>(p, st) : rc_launch<0, 1, 16>(p, st);
+}
+
+// The tail of a window-attention block in one launch: x1 = attn Wproj^T + b_proj + shortcut; y = x1 + fc2(GELU(fc1(LN2(x1))))
+// (modules/rstt_layers.py:230-232 proj, :329 shortcut add, :335-337 norm2 + Mlp + residual; Mlp :126-132 with mlp_ratio = 1,
+// archs/tdcrqvae3_arch.py:499).  w3 = the three (256, 256) weights stacked [Wproj; Wfc1'; Wfc2], K-major half rows, Wfc1' / b_fc1
+// carrying norm2's gamma / beta (pgt_fold_layernorm).
+extern "C" int pgt_attn_proj_mlp(int32_t dtype, const void* attn, int32_t lda, const void* shortcut, int32_t lds, int32_t rows,
+                                 int32_t C, const void* w3, const float* b_proj, int32_t b_proj_rows, const float* b_fc1,
+                                 const float* b_fc2, float eps, void* y, int32_t ldy, pgt_stream_t stream) {
+    PGT_CHECK(dtype == PGT_F16, "attn_proj_mlp: dtype %d (PGT_F16 only)", dtype);
+    PGT_CHECK(C == 256, "attn_proj_mlp: C=%d (256)", C);
+    PGT_CHECK(shortcut && b_fc1 && b_fc2 && lds % 8 == 0 && ((uintptr_t)shortcut & 15) == 0 && lds >= C && lda >= C && ldy >= C,
+              "attn_proj_mlp: null / misaligned argument");
+    RowChainP p{};
+    p.x = (const char*)attn; p.res = (const char*)shortcut; p.y = (char*)y; p.w = (const char*)w3;
+    p.b0 = b_proj; p.b0_rows = b_proj_rows; p.b1 = b_fc1; p.b2 = b_fc2; p.eps = eps;
+    p.ldx = lda; p.ldr = lds; p.ldy = ldy; p.M = rows; p.ncol = 768;
+    if (int rc = rc_common_checks("attn_proj_mlp", p, 128)) return rc;
+    return rc_launch<1, 1, 8>(p, (hipStream_t)stream);
+}

@@ -600,6 +600,83 @@ def mean_field_bias(mean, defect_t, bias=None):
     return out
 
 
+def sampled_rownorm_mean(x, eps=1e-5):
+    """fp32 (N, C): per frame and channel, the mean over the library's pixel sample of the NORMALISED rows of x (N, HW, C) - each
+    row minus its mean, times its rstd, rounded to x.dtype: the operand pgt_ln_linear multiplies (pgt_sampled_rownorm_mean)."""
+    n, hw, c = x.shape
+    mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    ld = x.stride(1) if hw > 1 else c
+    assert x.stride(2) == 1 and (n == 1 or x.stride(0) == hw * ld)
+    with _Prof("mean_field", 0, float(n * min(hw, 1024) * c * x.element_size())):
+        hip.check(hip.lib().pgt_sampled_rownorm_mean(_dt(x), _p(x), ld, n, hw, c, float(eps), _p(mean), _stream()), "pgt_sampled_rownorm_mean")
+    return mean
+
+
+def fold_layernorm(w, gamma, beta, bias=None):
+    """LayerNorm's affine part folded into the Linear that follows: returns (W diag(gamma), bias + W beta) fp32 on the device
+    (pgt_fold_layernorm); w (Cout, Cin) fp32."""
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
+    cout, cin = w.shape
+    w_out = torch.empty_like(w)
+    b_out = torch.empty((cout,), dtype=torch.float32, device=w.device)
+    hip.check(hip.lib().pgt_fold_layernorm(_p(w), _p(gamma), _p(beta), _p(bias), cout, cin, _p(w_out), _p(b_out), _stream()), "pgt_fold_layernorm")
+    return w_out, b_out
+
+
+def ln_linear(x, w, bias, eps=1e-5, out=None):
+    """y = half((x - mean) * rstd) @ w.T + bias: LayerNorm (affine part folded into w / bias by fold_layernorm) and the Linear that
+    follows it in one launch.  x (rows, 256) half; w (Cout, 256) packed half; bias (Cout,) or per frame (frames, Cout)."""
+    rows, cin = x.shape
+    cout = w.shape[0]
+    assert x.dtype == torch.float16 and w.dtype == torch.float16 and w.is_contiguous() and w.shape[1] == cin
+    if out is None:
+        out = torch.empty((rows, cout), device=x.device, dtype=x.dtype)
+    brows = 0
+    if bias is not None and bias.dim() == 2:
+        assert bias.shape[1] == cout and bias.is_contiguous() and rows % bias.shape[0] == 0
+        brows = rows // bias.shape[0]
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    hip.check(hip.lib().pgt_ln_linear(_dt(x), _p(x), _ld_rows(x), rows, cin, float(eps), _p(w), _p(bias), brows, cout, _p(out),
+                                      _ld_rows(out), _stream()), "pgt_ln_linear")
+    if prof is not None:
+        e1.record()
+        prof.append({"kernel": "igemm", "flops": 2.0 * rows * cin * cout, "bytes": float(_nb(x, out, w)),
+                     "shape": (1, 1, rows, cin, cout, 1, 1, 0), "events": (e0, e1), "cfg": ("ln_linear", 0, 0), "x3": False,
+                     "dt": "float16", "chain": "ln_linear"})
+    return out
+
+
+def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
+    """The tail of a window-attention block in one launch: x1 = ao @ Wproj.T + b_proj + shortcut; y = x1 + fc2(GELU(fc1(LN(x1)))).
+    w3 = [Wproj; Wfc1 diag(gamma2); Wfc2] (768, 256) packed half; b_proj (256,) or per frame (frames, 256)."""
+    rows, c = ao.shape
+    assert ao.dtype == torch.float16 and shortcut.dtype == torch.float16 and tuple(shortcut.shape) == (rows, c)
+    assert w3.dtype == torch.float16 and tuple(w3.shape) == (3 * c, c) and w3.is_contiguous()
+    if out is None:
+        out = torch.empty((rows, c), device=ao.device, dtype=ao.dtype)
+    assert out.data_ptr() != ao.data_ptr() and out.data_ptr() != shortcut.data_ptr()
+    brows = 0
+    if b_proj is not None and b_proj.dim() == 2:
+        assert b_proj.shape[1] == c and b_proj.is_contiguous() and rows % b_proj.shape[0] == 0
+        brows = rows // b_proj.shape[0]
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    hip.check(hip.lib().pgt_attn_proj_mlp(_dt(ao), _p(ao), _ld_rows(ao), _p(shortcut), _ld_rows(shortcut), rows, c, _p(w3),
+                                          _p(b_proj), brows, _p(b_fc1), _p(b_fc2), float(eps), _p(out), _ld_rows(out), _stream()),
+              "pgt_attn_proj_mlp")
+    if prof is not None:
+        e1.record()
+        prof.append({"kernel": "igemm", "flops": 6.0 * rows * c * c, "bytes": float(_nb(ao, shortcut, out, w3)),
+                     "shape": (1, 1, rows, c, 3 * c, 1, 1, 0), "events": (e0, e1), "cfg": ("proj_mlp", 0, 0), "x3": False,
+                     "dt": "float16", "chain": "proj_mlp"})
+    return out
+
+
 def sampled_pixels(hw):
     """pixel indices of the library's sample of an hw-pixel frame (host-side mirror for tests / emulation)"""
     L = hip.lib()

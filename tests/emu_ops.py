@@ -254,6 +254,35 @@ def mean_field_bias(mean, defect_t, bias=None):
     return y if bias is None else y + bias.float()
 
 
+def _rownorm(x, eps):
+    """(x - mean) * rstd per row, rounded to x.dtype: the operand of the fused LayerNorm -> Linear kernels (rowchain.hip)"""
+    xf = x.float()
+    mu = xf.mean(-1, keepdim=True)
+    d = xf - mu
+    return (d * (d.pow(2).mean(-1, keepdim=True) + eps).rsqrt()).to(x.dtype)
+
+
+def sampled_rownorm_mean(x, eps=1e-5):
+    return _rownorm(x[:, sampled_pixels(x.shape[1]), :], eps).float().mean(1)
+
+
+def fold_layernorm(w, gamma, beta, bias=None):
+    w = w.float()
+    b = w @ beta.float()
+    return (w * gamma.float()[None, :]).contiguous(), (b if bias is None else b + bias.float())
+
+
+def ln_linear(x, w, bias, eps=1e-5, out=None):
+    return linear(_rownorm(x, eps), w, bias, out=out)
+
+
+def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
+    c = ao.shape[1]
+    x1 = linear(ao, w3[:c], b_proj, res=shortcut)
+    h = linear(_rownorm(x1, eps), w3[c:2 * c], b_fc1, act=ACT_GELU)
+    return linear(h, w3[2 * c:], b_fc2, res=x1, out=out)
+
+
 def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):
     scale = (var_s + eps).sqrt() / (var_c + eps).sqrt()
     return scale, mean_s - mean_c * scale
@@ -489,7 +518,8 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "adain_affine", "window_attention", "mha", "argmax_rows", "rq_argmin", "embed_rows", "row_sumsq",
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "sample_rows", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
-       "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update", "sampled_channel_mean", "mean_field_bias"]
+       "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update", "sampled_channel_mean", "mean_field_bias",
+       "sampled_rownorm_mean", "fold_layernorm", "ln_linear", "attn_proj_mlp"]
 
 
 def install(monkeypatch):
