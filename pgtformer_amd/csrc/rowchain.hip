@@ -36,6 +36,30 @@
 #include "pgt_internal.h"
 #include "igemm_common.h"
 
+// Probe hooks (tools/rowchain_probe.py compiles this file with -DRC_PROBE=<bits>; the library build has none):
+//   1 no MFMAs   2 no A-fragment reads   4 no weight DMA   8 GELU -> identity   16 no normalisation   32 no output stores
+//   64 rows not loaded   128 no chunk barriers / waits (timing only: results are wrong)
+//   256 workgroup 0 leaves its shader-clock ticks (s_memtime) and 100 MHz ticks in the first 16 bytes of y: the clock it ran at
+#ifndef RC_PROBE
+#define RC_PROBE 0
+#endif
+// build switches (A/B through tools/rowchain_probe.py --define)
+#ifndef RC_PIPE
+#define RC_PIPE 1          // chain 1: the element-wise step of chunk q runs inside chunk q + 1
+#endif
+#ifndef RC_PREFETCH
+#define RC_PREFETCH 0      // chain 1: next tile's rows requested during the last GEMM (measured: no gain, +48 VGPRs)
+#endif
+#ifndef RC_PREFETCH0
+#define RC_PREFETCH0 0     // chain 0: next tile's rows requested three chunks before the tile ends (measured: no gain)
+#endif
+#ifndef RC_KG1
+#define RC_KG1 2           // chain 1: k-steps per fragment group
+#endif
+#ifndef RC_KG0
+#define RC_KG0 4           // chain 0: k-steps per fragment group
+#endif
+
 namespace {
 
 typedef _Float16 rc_half8 __attribute__((ext_vector_type(8)));
@@ -113,7 +137,7 @@ __device__ __forceinline__ void rc_normalize(uint4 (&b)[8], float eps) {
 template <int MODE, int RT, int NW>
 __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntiles) {
     static_assert(MODE == 0 || RT == 1, "the three-GEMM chain keeps one row tile per wave");
-    static_assert(NW == 8 || NW == 16, "16 DMA pieces per chunk are dealt to 8 or 16 waves");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "16 DMA pieces per chunk are dealt to 4, 8 or 16 waves");
     constexpr int kRcWaves = NW;
     constexpr int kRcPPC = 16 / NW;                     // DMA pieces (1 KiB) per wave and chunk
     constexpr int TR = kRcWaves * 16 * RT;              // rows per workgroup tile
@@ -123,6 +147,9 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
+#if RC_PROBE & 256
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_readcyclecounter();
+#endif
     const int NQ = MODE == 0 ? p.ncol / 32 : 24;        // chunks per tile
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total = my_tiles * NQ;                    // chunks this workgroup consumes
@@ -147,12 +174,15 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
         iss_slot = (iss_slot + 1) & (kRcNS - 1);
         ++iss_idx;
     };
-    for (int i = 0; i < kRcNS - 1 && i < total; ++i) issue();
+    for (int i = 0; i < kRcNS - 1 && i < total && !(RC_PROBE & 4); ++i) issue();
 
     // ---- static operands into LDS (visible after the first chunk barrier)
     if (MODE == 1) {
-        if (tid < 256) { bias_l[256 + tid] = p.b1[tid]; bias_l[kRcMaxCol + 256 + tid] = p.b1[tid]; }
-        else if (tid < 512) { bias_l[256 + tid] = p.b2[tid - 256]; bias_l[kRcMaxCol + 256 + tid] = p.b2[tid - 256]; }
+        for (int i = tid; i < 512; i += 64 * kRcWaves) {
+            const float v = i < 256 ? p.b1[i] : p.b2[i - 256];
+            bias_l[256 + i] = v;
+            bias_l[kRcMaxCol + 256 + i] = v;
+        }
     }
     const int nb0 = MODE == 0 ? p.ncol : 256;
     if (p.b0_rows == 0)
@@ -163,33 +193,50 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
     // chunk 4 ks + g, stored in slot (4 ks + g) ^ m: byte (abase ^ (ks << 6)) + 2048 t
     const int abase = (8 * (n >> 2) + (n & 3)) * 512 + ((g ^ n) << 4);
     int idx = 0;                                        // running index of the chunk being consumed
-    // one chunk: retire its DMA, release the slot of the previous one, keep the ring full, multiply
-    auto chunk_mma = [&](f32x4 (&acc)[RT][2], const uint4 (&b)[RT][8]) {
+    // One chunk: retire its DMA, release the slot of the previous one, keep the ring full, multiply.  `between(part)` is called
+    // once per k-group, after that group's fragment reads have been issued and before its MFMAs: the place where the
+    // element-wise work of the PREVIOUS chunk goes, so that it overlaps this chunk's LDS latency and matrix pipe time.
+    constexpr int KG = MODE == 0 ? RC_KG0 : RC_KG1;     // k-steps per group (2 KG fragments = 8 KG VGPRs in flight)
+    constexpr int NPART = 8 / KG;
+    // `extra`: this wave requested the next tile's rows (kXL ordinary loads) AFTER the DMA of the chunk waited for here: the
+    // counter retires in order, so they may stay in flight (waiting them out here is what made a prefetch useless)
+    constexpr int kXL = MODE == 0 ? 8 * RT : 16;
+    auto chunk_mma = [&](f32x4 (&acc)[RT][2], const uint4 (&b)[RT][8], auto&& between, bool extra = false) {
         const int after = total - 1 - idx;              // chunks issued after this one (capped by the ring)
-        if (after >= kRcNS - 2) RC_VMWAIT((kRcNS - 2) * kRcPPC);
-        else if (after == 1) RC_VMWAIT(kRcPPC);
-        else RC_VMWAIT(0);
-        RC_BARRIER();
-        if (iss_idx < total) issue();
+        if (!(RC_PROBE & 128)) {
+            if (after >= kRcNS - 2) {
+                if (extra) RC_VMWAIT((kRcNS - 2) * kRcPPC + kXL);
+                else RC_VMWAIT((kRcNS - 2) * kRcPPC);
+            } else if (after == 1) RC_VMWAIT(kRcPPC);
+            else RC_VMWAIT(0);
+            RC_BARRIER();
+        }
+        if (!(RC_PROBE & 4) && iss_idx < total) issue();
         const char* sp = smem + (idx & (kRcNS - 1)) * kRcChunk;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        constexpr int KG = MODE == 0 ? 4 : 2;           // k-steps whose fragments are in flight together (2 x KG x 4 VGPRs)
 #pragma unroll
         for (int k4 = 0; k4 < 8; k4 += KG) {
             uint4 a0[KG], a1[KG];
 #pragma unroll
             for (int j = 0; j < KG; ++j) {
+                if (RC_PROBE & 2) { a0[j] = a1[j] = make_uint4(lane, k4 + j, 0x3c003c00u, idx); continue; }
                 a0[j] = *reinterpret_cast<const uint4*>(sp + (abase ^ ((k4 + j) << 6)));
                 a1[j] = *reinterpret_cast<const uint4*>(sp + 2048 + (abase ^ ((k4 + j) << 6)));
             }
+            between(k4 / KG);
 #pragma unroll
             for (int j = 0; j < KG; ++j)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
+                    if (RC_PROBE & 1) {
+                        acc[rt][0][j & 3] += __uint_as_float(a0[j].x ^ b[rt][k4 + j].y);
+                        acc[rt][1][j & 3] += __uint_as_float(a1[j].z ^ b[rt][k4 + j].w);
+                        continue;
+                    }
                     acc[rt][0] = rc_mma(a0[j], b[rt][k4 + j], acc[rt][0]);
                     acc[rt][1] = rc_mma(a1[j], b[rt][k4 + j], acc[rt][1]);
                 }
@@ -197,6 +244,7 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
         }
         ++idx;
     };
+    auto nothing = [](int) {};
     // the 8 consecutive columns 32 q + 8 g .. + 8 of this lane's row: accumulator (t, r) = column 4 t + r of them
     auto cols8 = [&](const f32x4 (&acc)[2], float* v) {
 #pragma unroll
@@ -211,7 +259,16 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bv[e];
     };
+    auto load_rows = [&](uint4 (&dst)[8], const char* base, int ld, long row, int tile) {
+        const long rr = row < p.M ? row : p.M - 1;
+        const uint4* xp = reinterpret_cast<const uint4*>(base + (rr * ld + 8 * g) * 2);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) dst[ks] = (RC_PROBE & 64) ? make_uint4(0x3c003800u + lane, 0x38003c00u, tile, ks) : xp[4 * ks];
+    };
 
+    uint4 nb[MODE == 1 ? 8 : 1], nsc[MODE == 1 ? 8 : 1];      // chain 1: the next tile's rows, requested during this tile's last GEMM
+    uint4 nb0r[MODE == 0 ? RT : 1][8];                         // chain 0: the same, requested kRcNS - 1 chunks before the tile ends
+    bool have_next = false;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = (long)tile * TR;
         // ---- per-frame bias of the first GEMM: refreshed into the other LDS buffer when the tile enters a new frame
@@ -228,87 +285,129 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
         long rows[RT];
         uint4 b[RT][8];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            rows[rt] = row0 + (wave * RT + rt) * 16 + n;
-            const long rr = rows[rt] < p.M ? rows[rt] : p.M - 1;
-            const uint4* xp = reinterpret_cast<const uint4*>(p.x + (rr * p.ldx + 8 * g) * 2);
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) b[rt][ks] = xp[4 * ks];
-        }
+        for (int rt = 0; rt < RT; ++rt) rows[rt] = row0 + (wave * RT + rt) * 16 + n;
         if constexpr (MODE == 0) {
+            if (have_next) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) rc_normalize(b[rt], p.eps);
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) b[rt][ks] = nb0r[rt][ks];
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) load_rows(b[rt], p.x, p.ldx, rows[rt], tile);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) if (!(RC_PROBE & 16)) rc_normalize(b[rt], p.eps);
+            have_next = false;
             for (int q = 0; q < NQ; ++q) {
+                if (RC_PREFETCH0 && q == NQ - (kRcNS - 1) && tile + (int)gridDim.x < ntiles) {
+                    // the next tile's rows: requested kRcNS - 1 chunks before the end of this one
+                    have_next = true;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        load_rows(nb0r[rt], p.x, p.ldx, (long)(tile + gridDim.x) * TR + (wave * RT + rt) * 16 + n, tile);
+                }
                 f32x4 acc[RT][2];
-                chunk_mma(acc, b);
+                chunk_mma(acc, b, nothing, have_next);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     float v[8];
                     cols8(acc[rt], v);
                     add_bias(v, bl + 32 * q + 8 * g);
-                    if (rows[rt] < p.M)
+                    if (rows[rt] < p.M && (!(RC_PROBE & 32) || v[0] == 123.456f))
                         *reinterpret_cast<uint4*>(p.y + (rows[rt] * p.ldy + 32 * q + 8 * g) * 2) = Vec16<half_t>::pack(v);
                 }
             }
         } else {
             // shortcut rows, in the layout of the GEMM output (8 consecutive columns per chunk)
             uint4 sc[8];
-            {
-                const long rr = rows[0] < p.M ? rows[0] : p.M - 1;
-                const uint4* rp = reinterpret_cast<const uint4*>(p.res + (rr * p.ldr + 8 * g) * 2);
+            if (have_next) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) sc[q] = rp[4 * q];
+                for (int q = 0; q < 8; ++q) { b[0][q] = nb[q]; sc[q] = nsc[q]; }
+            } else {
+                load_rows(b[0], p.x, p.ldx, rows[0], tile);
+                load_rows(sc, p.res, p.ldr, rows[0], tile);
             }
-            uint4 x1[1][8];
+            uint4 x1[1][8], hid[1][8];
+            f32x4 accs[2][1][2];                        // this chunk's accumulators and the previous chunk's (epilogue pending)
+            // The element-wise step of chunk q runs inside chunk q + 1 (RC_PIPE), one quarter per k-group: v holds the chunk's 8
+            // columns across the groups.
+            float v[8];
             // ---- proj + bias + shortcut -> x1 (rounded to half: the tensor the layer-by-layer path stores)
+            auto epi0 = [&](int q, const f32x4 (&acc)[2], int part) {
+                if (part == 0) { cols8(acc, v); add_bias(v, bl + 32 * q + 8 * g); }
+                if (part == NPART - 1) {
+                    float s[8];
+                    Vec16<half_t>::unpack(sc[q], s);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f32x4 acc[1][2];
-                chunk_mma(acc, b);
-                float v[8], s[8];
-                cols8(acc[0], v);
-                add_bias(v, bl + 32 * q + 8 * g);
-                Vec16<half_t>::unpack(sc[q], s);
+                    for (int e = 0; e < 8; ++e) v[e] += s[e];
+                    x1[0][q] = Vec16<half_t>::pack(v);
+                    x3_opaque(x1[0][q]);                // finished HERE: keeps the compiler from sinking the epilogues below the loop
+                }
+            };
+            // ---- fc1 + bias + GELU -> hidden row (half)
+            auto epi1 = [&](int q, const f32x4 (&acc)[2], int part) {
+                if (part == 0) { cols8(acc, v); add_bias(v, bl + 256 + 32 * q + 8 * g); }
+                constexpr int per = 8 / NPART;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += s[e];
-                x1[0][q] = Vec16<half_t>::pack(v);
-                x3_opaque(x1[0][q]);                    // finished HERE: keeps the compiler from sinking the epilogues below the loop
-            }
+                for (int e = part * per; e < (part + 1) * per; ++e) v[e] = (RC_PROBE & 8) ? v[e] : rc_gelu(v[e]);
+                if (part == NPART - 1) {
+                    hid[0][q] = Vec16<half_t>::pack(v);
+                    x3_opaque(hid[0][q]);
+                }
+            };
+            // ---- fc2 + bias + x1 -> out
+            auto epi2 = [&](int q, const f32x4 (&acc)[2], int part) {
+                if (part == 0) { cols8(acc, v); add_bias(v, bl + 512 + 32 * q + 8 * g); }
+                if (part == NPART - 1) {
+                    float s[8];
+                    Vec16<half_t>::unpack(x1[0][q], s);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += s[e];
+                    if (rows[0] < p.M && (!(RC_PROBE & 32) || v[0] == 123.456f))
+                        *reinterpret_cast<uint4*>(p.y + (rows[0] * p.ldy + 32 * q + 8 * g) * 2) = Vec16<half_t>::pack(v);
+                }
+            };
+            auto gemm = [&](const uint4 (&bop)[1][8], auto&& epi, bool pre = false) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool extra = pre && q < kRcNS - 1;
+                    if (RC_PIPE) {
+                        chunk_mma(accs[q & 1], bop, [&](int part) { if (q > 0) epi(q - 1, accs[(q - 1) & 1][0], part); }, extra);
+                    } else {
+                        chunk_mma(accs[0], bop, nothing, extra);
+#pragma unroll
+                        for (int part = 0; part < NPART; ++part) epi(q, accs[0][0], part);
+                    }
+                }
+                if (RC_PIPE) {
+#pragma unroll
+                    for (int part = 0; part < NPART; ++part) epi(7, accs[1][0], part);
+                }
+            };
+            gemm(b, epi0);
             // ---- LN2
 #pragma unroll
             for (int q = 0; q < 8; ++q) b[0][q] = x1[0][q];
-            rc_normalize(b[0], p.eps);
-            // ---- fc1 + bias + GELU -> hidden row (half)
-            uint4 hid[1][8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f32x4 acc[1][2];
-                chunk_mma(acc, b);
-                float v[8];
-                cols8(acc[0], v);
-                add_bias(v, bl + 256 + 32 * q + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = rc_gelu(v[e]);
-                hid[0][q] = Vec16<half_t>::pack(v);
-                x3_opaque(hid[0][q]);
+            if (!(RC_PROBE & 16)) rc_normalize(b[0], p.eps);
+            gemm(b, epi1);
+            // ---- the next tile's rows are requested here: they have the whole last GEMM to arrive
+            have_next = RC_PREFETCH && tile + (int)gridDim.x < ntiles;
+            if (have_next) {
+                const long nrow = (long)(tile + gridDim.x) * TR + wave * 16 + n;
+                load_rows(nb, p.x, p.ldx, nrow, tile);
+                load_rows(nsc, p.res, p.ldr, nrow, tile);
             }
-            // ---- fc2 + bias + x1 -> out
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f32x4 acc[1][2];
-                chunk_mma(acc, hid);
-                float v[8], s[8];
-                cols8(acc[0], v);
-                add_bias(v, bl + 512 + 32 * q + 8 * g);
-                Vec16<half_t>::unpack(x1[0][q], s);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += s[e];
-                if (rows[0] < p.M)
-                    *reinterpret_cast<uint4*>(p.y + (rows[0] * p.ldy + 32 * q + 8 * g) * 2) = Vec16<half_t>::pack(v);
-            }
+            gemm(hid, epi2, have_next);
         }
     }
     RC_VMWAIT(0);
+#if RC_PROBE & 256
+    if (blockIdx.x == 0 && tid == 0) {
+        reinterpret_cast<unsigned long long*>(p.y)[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        reinterpret_cast<unsigned long long*>(p.y)[1] = __builtin_readcyclecounter() - clk_r0;
+    }
+#endif
 }
 
 int rc_cus();
@@ -327,7 +426,8 @@ template <int MODE, int RT, int NW> int rc_launch(const RowChainP& p, hipStream_
     }
     const int cus = rc_cus();
     if (cus <= 0) { pgt_set_error("rowchain: cannot query the device"); return -5; }
-    const int grid = ntiles < cus ? ntiles : cus;
+    const int wgs = cus * (NW == 4 ? 2 : 1);           // 4-wave workgroups: two per CU (LDS 2 x 70 KiB, 8 waves), out of step with each other
+    const int grid = ntiles < wgs ? ntiles : wgs;
     hipLaunchKernelGGL((rowchain_kernel<MODE, RT, NW>), dim3(grid), dim3(64 * NW), kRcLds, st, p, ntiles);
     PGT_LAUNCH_CHECK();
     return 0;
@@ -398,12 +498,18 @@ extern "C" int pgt_ln_linear(int32_t dtype, const void* x, int32_t ldx, int32_t 
     // two row tiles per wave (256-row workgroup tiles: half the weight traffic and half the LDS reads per row) once they still
     // fill the chip.  PGT_RC_LN = r1w8 | r2w8 | r1w16 pins the variant (tuning).
     const char* e = getenv("PGT_RC_LN");
-    const int forced = !e ? 0 : !strcmp(e, "r1w8") ? 1 : !strcmp(e, "r2w8") ? 2 : !strcmp(e, "r1w16") ? 3 : 0;
+    const int forced = !e ? 0 : !strcmp(e, "r1w8") ? 1 : !strcmp(e, "r2w8") ? 2 : !strcmp(e, "r1w16") ? 3 : !strcmp(e, "r2w4") ? 4 : !strcmp(e, "r1w4") ? 5 : 0;
     int var = forced ? forced : (rows >= 256 * cus ? 2 : 1);
-    if (var != 1 && bias_rows % 256 != 0) var = 1;
-    if (int rc = rc_common_checks("ln_linear", p, var == 1 ? 128 : 256)) return rc;
+    if ((var == 2 || var == 3) && bias_rows % 256 != 0) var = 1;
+    if (int rc = rc_common_checks("ln_linear", p, var == 5 ? 64 : (var == 1 || var == 4) ? 128 : 256)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    return var == 1 ? rc_launch<0, 1, 8>(p, st) : var == 2 ? rc_launch<0, 2, 8>(p, st) : rc_launch<0, 1, 16>(p, st);
+    switch (var) {
+        case 1: return rc_launch<0, 1, 8>(p, st);
+        case 2: return rc_launch<0, 2, 8>(p, st);
+        case 3: return rc_launch<0, 1, 16>(p, st);
+        case 4: return rc_launch<0, 2, 4>(p, st);
+        default: return rc_launch<0, 1, 4>(p, st);
+    }
 }
 
 // The tail of a window-attention block in one launch: x1 = attn Wproj^T + b_proj + shortcut; y = x1 + fc2(GELU(fc1(LN2(x1))))
@@ -421,6 +527,8 @@ extern "C" int pgt_attn_proj_mlp(int32_t dtype, const void* attn, int32_t lda, c
     p.x = (const char*)attn; p.res = (const char*)shortcut; p.y = (char*)y; p.w = (const char*)w3;
     p.b0 = b_proj; p.b0_rows = b_proj_rows; p.b1 = b_fc1; p.b2 = b_fc2; p.eps = eps;
     p.ldx = lda; p.ldr = lds; p.ldy = ldy; p.M = rows; p.ncol = 768;
-    if (int rc = rc_common_checks("attn_proj_mlp", p, 128)) return rc;
-    return rc_launch<1, 1, 8>(p, (hipStream_t)stream);
+    const char* e = getenv("PGT_RC_MLP");              // w8 | w4 pins the variant (tuning)
+    const bool w4 = e && !strcmp(e, "w4");
+    if (int rc = rc_common_checks("attn_proj_mlp", p, w4 ? 64 : 128)) return rc;
+    return w4 ? rc_launch<1, 1, 4>(p, (hipStream_t)stream) : rc_launch<1, 1, 8>(p, (hipStream_t)stream);
 }
