@@ -203,6 +203,16 @@ int pgt_attn_proj_mlp(int32_t dtype, const void* attn, int32_t lda, const void* 
                       const void* w3, const float* b_proj, int32_t b_proj_rows, const float* b_fc1, const float* b_fc2,
                       float eps, void* y, int32_t ldy, pgt_stream_t stream);
 
+/* Split-half (PGT_F16X3) forms of the chains, for the encoder-side blocks: x / y split rows (lo planes x_lo / y_lo elements
+ * after the hi planes), every product x_lo w_hi + x_hi w_lo + x_hi w_hi on the f16 MFMA, fp32 statistics; w in the
+ * pgt_pack_conv_weight(PGT_F16X3) form of the FOLDED matrix.  pgt_ln_linear_x3: y = xhat W'^T + b' (norm1 + [q | k | v]).
+ * pgt_ln_mlp_x3: y = x + fc2(GELU(fc1(LN(x)))) with w2 = [Wfc1 diag(gamma); Wfc2] stacked (512 packed rows), exact erf GELU; x is
+ * re-read for the residual (y must not alias it).  The proj + shortcut step of a split block stays a pgt_conv2d launch. */
+int pgt_ln_linear_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t rows, int32_t Cin, float eps, const void* w,
+                     const float* bias, int32_t Cout, void* y, int32_t ldy, int32_t y_lo, pgt_stream_t stream);
+int pgt_ln_mlp_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t rows, int32_t C, float eps, const void* w2,
+                  const float* b_fc1, const float* b_fc2, void* y, int32_t ldy, int32_t y_lo, pgt_stream_t stream);
+
 /* ---- attention -------------------------------------------------------------------------------
  * (T,Wh,Ww)-window multi-head self-attention with cyclic shift, relative-position bias and the
  * 9-region shift mask (WindowAttention3D.forward rstt_layers.py:195-234 + window_partition/reverse
@@ -366,6 +376,14 @@ int pgt_gather_frames(const void* src, int64_t src_row_stride, void* dst, int64_
 /* dst[r, 0:row_bytes] = 0 for `rows` rows of stride ldd_bytes (16-byte granules): the zero pad channels of the
  * [enc | dec | fut | 0] concat buffers and of the 57 -> 64 channel parsing map (replaces torch.zeros / zero_()) */
 int pgt_zero2d(void* dst, int64_t ldd_bytes, int64_t rows, int32_t row_bytes, pgt_stream_t stream);
+
+/* ---- range telemetry of the default precision mode ---------------------------------------------------------------------
+ * PGT_F16 / PGT_F16X3 stores saturate at +-65504 instead of producing inf: a checkpoint whose activations leave the half range
+ * would be clamped silently.  pgt_count_saturated adds to *count (int32 on the device, zeroed by the caller) the number of
+ * elements of a (rows x cols) IEEE-half matrix with row stride ldx (elements; the hi plane of a split tensor) that sit at the
+ * limit or are not finite.  The Python driver runs it over every 16-bit tensor of the first forward (WindowRunner
+ * check_range) and refuses to continue when a layer saturates - precision "bf16x3" has no such limit in the decoder. */
+int pgt_count_saturated(const void* x, int64_t ldx, int64_t rows, int32_t cols, int32_t* count, pgt_stream_t stream);
 
 /* ---- driver edges (inference.py:6-19) ----------------------------------------------------------
  * input window -> channels-last 8-channel (RGB + 5 zero) tensors: raw = v/255 (encoder input) and

@@ -560,6 +560,28 @@ class PGTFormer(TDCRQVAE3):
         return out, logits, lq_feat
 
     @torch.no_grad()
+    def check_range(self, window_u8, w=1.0, win=None, full_tail=False):
+        """Range telemetry of the 16-bit modes: ONE eager forward of `window_u8` (as restore_middle_u8 takes it) in which every
+        operator counts the elements of its IEEE-half outputs that sit at the saturation limit +-65504 or are not finite
+        (ops.RANGE_CHECK, pgt_count_saturated).  Returns the list of (operator, shape, count) with count > 0 - empty when the
+        checkpoint's activations fit the half range.  The half decoder of the default mode clamps silently otherwise:
+        callers fall back to prepare(device, "bf16x3") (bf16 decoder: no range limit)."""
+        recs, hooks = [], []
+        for name, mod in self.named_modules():          # records carry the innermost module whose forward() is running
+            hooks.append(mod.register_forward_pre_hook(lambda m, a, n=name: ops.RANGE_CTX.append(n)))
+            hooks.append(mod.register_forward_hook(lambda m, a, o: ops.RANGE_CTX.pop() and None))
+        ops.RANGE_CHECK = recs
+        try:
+            self.forward_nhwc(window_u8, w=w, win=win, middle_only=not full_tail)
+        finally:
+            ops.RANGE_CHECK = None
+            del ops.RANGE_CTX[:]
+            for h in hooks:
+                h.remove()
+        self.last_range_launches = len(recs)
+        return [r for r in ops.range_report(recs) if r[2] > 0]
+
+    @torch.no_grad()
     def restore_middle_u8(self, window_u8, w=1.0, win=None, out=None, full_tail=False):
         """Driver fast path (reference: inference.py:12-19): uint8 (3,H,W,3) window -> restored middle
         frame as uint8 (H,W,3) with floor(clamp(x,0,1)*255), without leaving the device.

@@ -592,7 +592,11 @@ class TDCRQVAE3(HubMixin, HipModule):
           "x3f16"   (default) the code-prediction branch on split-half operands (two IEEE-half planes, 3 f16 MFMAs per product, 22 significand
                     bits: the arg-max codes reproduce the fp32 reference) with its per-frame BiSeNet in fp32 storage;
                     decoder / SFT fusion in IEEE half (11 significand bits at the bf16 MFMA rate): restored frames within
-                    1e-3 dB PSNR of the fp32 reference at a non-degenerate operating point (tests/golden/make_golden_r3.py)
+                    1e-3 dB PSNR of the fp32 reference at a non-degenerate operating point (tests/golden/make_golden_r3.py).
+                    RANGE: every fp32 -> half store saturates at +-65504 (no inf); a checkpoint whose decoder / code-branch
+                    activations leave that range is clamped silently, so the first forward is checked - PGTFormer.check_range,
+                    run by driver.WindowRunner on the first batch (raises, naming the layers; PGT_RANGE_CHECK=0 disables) -
+                    and such a checkpoint is run with "bf16x3"
           "bf16x3"  as x3f16 with a bf16 decoder (8 significand bits: 5e-3 dB at that operating point; no half range limit)
           "mixed"   decoder bf16, the whole code-prediction branch in exact fp32
           "bf16"    bf16 everywhere (fastest; ~2 % of the codes differ from the fp32 reference with random weights)"""

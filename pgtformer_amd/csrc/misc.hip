@@ -715,6 +715,41 @@ extern "C" int pgt_zero2d(void* dst, int64_t ldd_bytes, int64_t rows, int32_t ro
     return 0;
 }
 
+// ---- range telemetry of the IEEE-half tensors (PGT_F16 / the hi plane of PGT_F16X3) ---------------------------------------
+// fp32 -> half stores of the kernels SATURATE at +-65504 instead of producing inf (common.h sat_half): a tensor that hits the
+// limit is silently clamped.  This pass counts the elements of a (rows x cols, row stride ld) half matrix that sit at the
+// limit or are not finite (|bits| >= 0x7bff) into *count (int32, added atomically: the caller zeroes it).
+namespace {
+__global__ __launch_bounds__(256) void count_saturated_kernel(const uint16_t* __restrict__ x, long ld, long rows, int chunks,
+                                                              int* __restrict__ count) {
+    const long total = rows * chunks;
+    int c = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / chunks;
+        const int k = (int)(i - r * chunks);
+        const uint4 q = *reinterpret_cast<const uint4*>(x + r * ld + k * 8);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c += ((w[j] & 0x7fffu) >= 0x7bffu) + (((w[j] >> 16) & 0x7fffu) >= 0x7bffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+}  // namespace
+
+extern "C" int pgt_count_saturated(const void* x, int64_t ldx, int64_t rows, int32_t cols, int32_t* count, pgt_stream_t stream) {
+    PGT_CHECK(x && count && rows >= 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0,
+              "count_saturated: cols=%d and ldx must be multiples of 8, x 16-byte aligned", cols);
+    if (rows == 0) return 0;
+    long blocks = (rows * (cols / 8) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(count_saturated_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (long)ldx,
+                       (long)rows, cols / 8, count);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t pgt_packed_weight_bytes(int32_t dtype, int32_t Cout, int32_t Cin_pad, int32_t KH, int32_t KW, int32_t x3_fold) {
     const size_t k = (size_t)KH * KW * Cin_pad;
     if (dtype == PGT_F32) return (size_t)Cout * k * 4;

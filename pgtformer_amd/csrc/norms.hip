@@ -520,22 +520,34 @@ __global__ __launch_bounds__(1024) void sampled_rownorm_mean_kernel(const T* __r
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     const T* base = x + (long)n * HW * ldx + lane * EPL;
-    for (int i = wave; i < S; i += 16) {
-        float v[EPL];
-        RowIO<T, EPL, true>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
-        float s = 0.f;
+    // rows wave, wave + 16, ...: eight at a time, all of their loads issued before the first reduction (one row per iteration
+    // is a chain of dependent HBM round trips: 82 us per launch, measured)
+    constexpr int NB = 8;
+    for (int i0 = wave; i0 < S; i0 += 16 * NB) {
+        float v[NB][EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) s += v[e];
-        const float mu = wave_sum(s) / (float)C;
-        float ss = 0.f;
+        for (int u = 0; u < NB; ++u) {
+            const int i = i0 + 16 * u;
+            RowIO<T, EPL, true>::ld(base + (long)mean_sample_pixel(i < S ? i : i0, cell, run) * ldx, v[u]);
+        }
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) { v[e] -= mu; ss += v[e] * v[e]; }
-        const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+        for (int u = 0; u < NB; ++u) {
+            float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            T r;
-            stf(&r, v[e] * rstd);          // the rounding the consuming kernel applies to its operand
-            acc[e] += ldf(&r);
+            for (int e = 0; e < EPL; ++e) s += v[u][e];
+            const float mu = wave_sum(s) / (float)C;
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { v[u][e] -= mu; ss += v[u][e] * v[u][e]; }
+            const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+            if (i0 + 16 * u < S) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    T r;
+                    stf(&r, v[u][e] * rstd);          // the rounding the consuming kernel applies to its operand
+                    acc[e] += ldf(&r);
+                }
+            }
         }
     }
 #pragma unroll

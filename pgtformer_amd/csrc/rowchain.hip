@@ -410,6 +410,208 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Split-half (PGT_F16X3) forms for the encoder-side blocks: rows and weights on two IEEE-half planes, every product taken as
+// x_lo w_hi + x_hi w_lo + x_hi w_hi (small terms first, as every split kernel of the library), fp32 accumulation / statistics.
+//   MODE 0  y = xhat W'^T + b'                                   (LayerNorm -> Linear, Cout a multiple of 128 up to 768)
+//   MODE 2  y = x + fc2(GELU(fc1(xhat)))                         (LayerNorm -> Mlp -> residual; x is re-read for the residual)
+// A chunk is 32 output columns x [w_hi (512 B) | w_lo (512 B)] = 32 KiB, taken from the [w_hi | w_hi | w_lo]-per-64-channel
+// rows of pgt_pack_conv_weight(PGT_F16X3); the ring holds four of them.  The three-GEMM chain of the half form would need
+// three split rows per wave (192 VGPRs): proj + shortcut stays on the phased kernel for split blocks.
+constexpr int kRcChunkX = 2 * kRcChunk;
+constexpr int kRcLdsX = kRcNS * kRcChunkX + kRcMaxCol * 4;
+
+template <int MODE, int RT>
+__global__ __launch_bounds__(512) void rowchain_x3_kernel(RowChainP p, int ntiles, int xlo, int ylo) {
+    static_assert(MODE == 0 || (MODE == 2 && RT == 1), "modes");
+    constexpr int NWV = 8, PPC = 4;                     // 32 DMA pieces per chunk: waves 0-3 the hi plane, 4-7 the lo plane
+    constexpr int TR = NWV * 16 * RT;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float* const bias_l = reinterpret_cast<float*>(smem + kRcNS * kRcChunkX);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const int NQ = MODE == 0 ? p.ncol / 32 : 16;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * NQ;
+    const unsigned lds0 = lds_addr(smem);
+    const v4i rsrc_w = make_rsrc(p.w, (unsigned)(NQ * 32 * 1536));
+    // piece j = 4 wave + i: plane j >> 4, rows 2 (j & 15), + 1 of the chunk; lane -> row a, slot l & 31 <- source chunk ck
+    unsigned dma_off[PPC];
+#pragma unroll
+    for (int i = 0; i < PPC; ++i) {
+        const int j = PPC * wave + i, plane = j >> 4;
+        const int a = 2 * (j & 15) + (lane >> 5);
+        const int f = ((a >> 3) << 2) | (a & 3);
+        const int ck = (lane & 31) ^ f;                                  // 16-byte chunk of the 256 k: 64-channel block ck >> 3
+        dma_off[i] = (unsigned)(a * 1536 + (ck >> 3) * 384 + plane * 256 + (ck & 7) * 16);
+    }
+    int iss_q = 0, iss_slot = 0, iss_idx = 0;
+    auto issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < PPC; ++i) {
+            const int j = PPC * wave + i;
+            bufdma16(dma_off[i], rsrc_w, iss_q * (32 * 1536), lds0 + iss_slot * kRcChunkX + (j >> 4) * kRcChunk + (j & 15) * 1024);
+        }
+        iss_q = iss_q + 1 == NQ ? 0 : iss_q + 1;
+        iss_slot = (iss_slot + 1) & (kRcNS - 1);
+        ++iss_idx;
+    };
+    for (int i = 0; i < kRcNS - 1 && i < total; ++i) issue();
+    for (int i = tid; i < NQ * 32; i += 512)
+        bias_l[i] = MODE == 0 ? (p.b0 ? p.b0[i] : 0.f) : (i < 256 ? p.b0[i] : p.b1[i - 256]);
+
+    const int abase = (8 * (n >> 2) + (n & 3)) * 512 + ((g ^ n) << 4);
+    int idx = 0;
+    auto chunk_mma = [&](f32x4 (&acc)[RT][2], const uint4 (&bh)[RT][8], const uint4 (&bl)[RT][8]) {
+        const int after = total - 1 - idx;
+        if (after >= kRcNS - 2) RC_VMWAIT((kRcNS - 2) * PPC);
+        else if (after == 1) RC_VMWAIT(PPC);
+        else RC_VMWAIT(0);
+        RC_BARRIER();
+        if (iss_idx < total) issue();
+        const char* sp = smem + (idx & (kRcNS - 1)) * kRcChunkX;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            acc[rt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2 += 2) {             // two k-steps = 8 fragments (hi / lo planes of two column tiles) in flight
+            uint4 ah[2][2], al[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ah[j][t] = *reinterpret_cast<const uint4*>(sp + 2048 * t + (abase ^ ((k2 + j) << 6)));
+                    al[j][t] = *reinterpret_cast<const uint4*>(sp + kRcChunk + 2048 * t + (abase ^ ((k2 + j) << 6)));
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[rt][t] = rc_mma(ah[j][t], bl[rt][k2 + j], acc[rt][t]);     // small terms first
+                        acc[rt][t] = rc_mma(al[j][t], bh[rt][k2 + j], acc[rt][t]);
+                        acc[rt][t] = rc_mma(ah[j][t], bh[rt][k2 + j], acc[rt][t]);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ++idx;
+    };
+    auto cols8 = [&](const f32x4 (&acc)[2], const float* bp, float* v) {
+        float bv[8];
+        *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(bp);
+        *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(bp + 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * t + r] = acc[t][r] + bv[4 * t + r];
+    };
+    // rows (hi + lo) -> normalised rows as split B fragments; statistics as layernorm_kernel<.., X3> (norms.hip)
+    auto load_norm = [&](uint4 (&bh)[8], uint4 (&bl)[8], long row) {
+        const long rr = row < p.M ? row : p.M - 1;
+        const uint4* xh = reinterpret_cast<const uint4*>(p.x + (rr * p.ldx + 8 * g) * 2);
+        const uint4* xl = reinterpret_cast<const uint4*>(p.x + (rr * p.ldx + xlo + 8 * g) * 2);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { bh[ks] = xh[4 * ks]; bl[ks] = xl[4 * ks]; }
+        float v[64];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) merge8(bh[ks], bl[ks], v + 8 * ks);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 64; ++e) s += v[e];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / 256.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 64; ++e) { v[e] -= mean; ss = fmaf(v[e], v[e], ss); }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = 1.0f / sqrtf(ss * (1.0f / 256.0f) + p.eps);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[8 * ks + e] *= rstd;
+            split8(v + 8 * ks, bh[ks], bl[ks]);
+        }
+    };
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = (long)tile * TR;
+        long rows[RT];
+        uint4 bh[RT][8], bl[RT][8];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            rows[rt] = row0 + (wave * RT + rt) * 16 + n;
+            load_norm(bh[rt], bl[rt], rows[rt]);
+        }
+        if constexpr (MODE == 0) {
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 acc[RT][2];
+                chunk_mma(acc, bh, bl);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    float v[8];
+                    cols8(acc[rt], bias_l + 32 * q + 8 * g, v);
+                    uint4 oh, ol;
+                    split8(v, oh, ol);
+                    if (rows[rt] < p.M) {
+                        char* yp = p.y + (rows[rt] * p.ldy + 32 * q + 8 * g) * 2;
+                        *reinterpret_cast<uint4*>(yp) = oh;
+                        *reinterpret_cast<uint4*>(yp + (long)ylo * 2) = ol;
+                    }
+                }
+            }
+        } else {
+            uint4 hh[1][8], hl[1][8];
+            // ---- fc1 + bias + exact GELU -> hidden row (split)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 acc[1][2];
+                chunk_mma(acc, bh, bl);
+                float v[8];
+                cols8(acc[0], bias_l + 32 * q + 8 * g, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752440f));
+                split8(v, hh[0][q], hl[0][q]);
+                x3_opaque(hh[0][q]);
+                x3_opaque(hl[0][q]);
+            }
+            // ---- the residual rows (the kernel's own input), requested before the last GEMM
+            uint4 rh[8], rl[8];
+            {
+                const long rr = rows[0] < p.M ? rows[0] : p.M - 1;
+                const uint4* xh = reinterpret_cast<const uint4*>(p.x + (rr * p.ldx + 8 * g) * 2);
+                const uint4* xl = reinterpret_cast<const uint4*>(p.x + (rr * p.ldx + xlo + 8 * g) * 2);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { rh[q] = xh[4 * q]; rl[q] = xl[4 * q]; }
+            }
+            // ---- fc2 + bias + x -> out
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 acc[1][2];
+                chunk_mma(acc, hh, hl);
+                float v[8], r[8];
+                cols8(acc[0], bias_l + 256 + 32 * q + 8 * g, v);
+                merge8(rh[q], rl[q], r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+                uint4 oh, ol;
+                split8(v, oh, ol);
+                if (rows[0] < p.M) {
+                    char* yp = p.y + (rows[0] * p.ldy + 32 * q + 8 * g) * 2;
+                    *reinterpret_cast<uint4*>(yp) = oh;
+                    *reinterpret_cast<uint4*>(yp + (long)ylo * 2) = ol;
+                }
+            }
+        }
+    }
+    RC_VMWAIT(0);
+}
+
 int rc_cus();
 
 template <int MODE, int RT, int NW> int rc_launch(const RowChainP& p, hipStream_t st) {
@@ -510,6 +712,57 @@ extern "C" int pgt_ln_linear(int32_t dtype, const void* x, int32_t ldx, int32_t 
         case 4: return rc_launch<0, 2, 4>(p, st);
         default: return rc_launch<0, 1, 4>(p, st);
     }
+}
+
+namespace {
+template <int MODE, int RT> int rc_launch_x3(const RowChainP& p, int xlo, int ylo, hipStream_t st) {
+    constexpr int TR = 128 * RT;
+    const int ntiles = (p.M + TR - 1) / TR;
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rowchain_x3_kernel<MODE, RT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kRcLdsX);
+        if (e != hipSuccess) { pgt_set_error("rowchain: cannot reserve %d B of LDS: %s", kRcLdsX, hipGetErrorString(e)); return -12; }
+        attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const int cus = rc_cus();
+    if (cus <= 0) { pgt_set_error("rowchain: cannot query the device"); return -5; }
+    hipLaunchKernelGGL((rowchain_x3_kernel<MODE, RT>), dim3(ntiles < cus ? ntiles : cus), dim3(512), kRcLdsX, st, p, ntiles, xlo, ylo);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+// Split-half forms (PGT_F16X3; the encoder-side blocks).  x / y: split rows, lo planes x_lo / y_lo elements after the hi planes;
+// w: pgt_pack_conv_weight(PGT_F16X3) of the folded matrix ((Cout, 3 * 256) halves: [w_hi | w_hi | w_lo] per 64-channel block).
+extern "C" int pgt_ln_linear_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t rows, int32_t Cin, float eps, const void* w,
+                                const float* bias, int32_t Cout, void* y, int32_t ldy, int32_t y_lo, pgt_stream_t stream) {
+    PGT_CHECK(Cin == 256 && Cout >= 128 && Cout % 128 == 0 && Cout <= kRcMaxCol, "ln_linear_x3: Cin=%d (256), Cout=%d (multiple of 128, <= %d)", Cin, Cout, kRcMaxCol);
+    PGT_CHECK(x_lo % 8 == 0 && y_lo % 8 == 0 && x_lo >= Cin && y_lo >= Cout && ldx >= x_lo + Cin && ldy >= y_lo + Cout, "ln_linear_x3: lo planes (x_lo=%d y_lo=%d)", x_lo, y_lo);
+    RowChainP p{};
+    p.x = (const char*)x; p.y = (char*)y; p.w = (const char*)w;
+    p.b0 = bias; p.eps = eps; p.ldx = ldx; p.ldy = ldy; p.M = rows; p.ncol = Cout;
+    if (int rc = rc_common_checks("ln_linear_x3", p, 128)) return rc;
+    const int cus = rc_cus();
+    const char* e = getenv("PGT_RC_LNX3");              // r1 | r2 pins the variant (tuning)
+    const bool r2 = e ? !strcmp(e, "r2") : rows >= 256 * cus;
+    return r2 ? rc_launch_x3<0, 2>(p, x_lo, y_lo, (hipStream_t)stream) : rc_launch_x3<0, 1>(p, x_lo, y_lo, (hipStream_t)stream);
+}
+
+// y = x + fc2(GELU(fc1(LN(x)))) on split rows: norm2 + Mlp + residual of a window-attention block (modules/rstt_layers.py:335-337,
+// 126-132) in one launch.  w2 = [Wfc1 diag(gamma); Wfc2] stacked (512 rows) in the PGT_F16X3 packed form, b_fc1 carrying W1 beta.
+extern "C" int pgt_ln_mlp_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t rows, int32_t C, float eps, const void* w2,
+                             const float* b_fc1, const float* b_fc2, void* y, int32_t ldy, int32_t y_lo, pgt_stream_t stream) {
+    PGT_CHECK(C == 256 && b_fc1 && b_fc2, "ln_mlp_x3: C=%d (256), biases required", C);
+    PGT_CHECK(x_lo % 8 == 0 && y_lo % 8 == 0 && x_lo >= C && y_lo >= C && ldx >= x_lo + C && ldy >= y_lo + C, "ln_mlp_x3: lo planes (x_lo=%d y_lo=%d)", x_lo, y_lo);
+    PGT_CHECK(x != y, "ln_mlp_x3: y must not alias x (x is re-read for the residual)");
+    RowChainP p{};
+    p.x = (const char*)x; p.y = (char*)y; p.w = (const char*)w2;
+    p.b0 = b_fc1; p.b1 = b_fc2; p.eps = eps; p.ldx = ldx; p.ldy = ldy; p.M = rows; p.ncol = 512;
+    if (int rc = rc_common_checks("ln_mlp_x3", p, 128)) return rc;
+    return rc_launch_x3<2, 1>(p, x_lo, y_lo, (hipStream_t)stream);
 }
 
 // The tail of a window-attention block in one launch: x1 = attn Wproj^T + b_proj + shortcut; y = x1 + fc2(GELU(fc1(LN2(x1))))

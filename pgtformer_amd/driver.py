@@ -28,8 +28,15 @@ class WindowRunner:
     per-window recomputation).  The model computes the outer two frames of a window only as far as the middle frame depends
     on them (up to the decoder's last temporal operation): the driver keeps `[0][1]` (reference inference.py:15)."""
 
-    def __init__(self, model, w=1.0, use_graph=True, height=512, width=512, batch=1, overlap=True, full_tail=False, lanes=1):
+    def __init__(self, model, w=1.0, use_graph=True, height=512, width=512, batch=1, overlap=True, full_tail=False, lanes=1,
+                 check_range=None):
         self.model, self.w = model, w
+        # range telemetry of the IEEE-half modes: the first real batch also runs once eagerly with every operator counting
+        # the outputs that sit at the half saturation limit (PGTFormer.check_range); a saturating layer raises instead of
+        # producing silently clamped frames.  check_range=None: on for the precisions that store halves, PGT_RANGE_CHECK=0 off.
+        if check_range is None:
+            check_range = os.environ.get("PGT_RANGE_CHECK", "1") != "0" and getattr(model, "precision", "") in ("x3f16", "bf16x3")
+        self._range_pending = bool(check_range) and model.dev.type == "cuda"
         self.full_tail = full_tail     # True: all 3 frames of every window through the decoder's per-frame tail (discarded)
         self.dev = model.dev
         self.t = model.t
@@ -93,6 +100,15 @@ class WindowRunner:
     def _launch(self, lane=0):
         """one forward on the frames currently in the lane's static input -> (batch,H,W,3) uint8 (overwritten by the next
         launch of that lane); runs on the current stream."""
+        if self._range_pending:
+            self._range_pending = False
+            kw = {"win": self.win} if self.overlap else {}
+            bad = self.model.check_range(self.static_ins[lane], w=self.w, full_tail=self.full_tail, **kw)
+            if bad:
+                from .hip import PgtError
+                raise PgtError("activations leave the IEEE-half range in precision %r (stores saturate at +-65504): %s ... - "
+                               "prepare the model with precision='bf16x3' (bf16 decoder, no range limit) or 'fp32'"
+                               % (self.model.precision, bad[:4]))
         if self.graphs[lane] is None:
             res = self._forward(self.static_ins[lane], lane)
         else:

@@ -47,6 +47,8 @@ SIGNATURES = {
     "pgt_sampled_rownorm_mean": [i32, vp, i32, i32, i32, i32, f32, vp, vp],
     "pgt_fold_layernorm": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
     "pgt_ln_linear": [i32, vp, i32, i32, i32, f32, vp, vp, i32, i32, vp, i32, vp],
+    "pgt_ln_linear_x3": [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, i32, vp],
+    "pgt_ln_mlp_x3": [vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, i32, vp],
     "pgt_attn_proj_mlp": [i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, vp, f32, vp, i32, vp],
     "pgt_mean_field_bias": [vp, vp, vp, i32, i32, i32, vp, vp],
     "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -81,6 +83,7 @@ SIGNATURES = {
     "pgt_copy2d": [i32, vp, i32, i32, vp, i32, i64, i32, vp],
     "pgt_gather_frames": [vp, i64, vp, i64, vp, i32, i64, i32, vp],
     "pgt_zero2d": [vp, i64, i64, i32, vp],
+    "pgt_count_saturated": [vp, i64, i64, i32, vp, vp],
     "pgt_prep_input": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
     "pgt_nhwc_to_nchw_f32": [i32, vp, i32, i32, i32, i32, i32, vp, vp],
     "pgt_frame_to_u8": [i32, vp, i32, i32, i32, vp, vp],

@@ -26,6 +26,7 @@ USE_X3_C64 = os.environ.get("PGT_X3_C64", "1") != "0"     # A/B switch of the re
 USE_WCOMP = os.environ.get("PGT_WCOMP", "1") != "0"       # A/B switch of the mean-field weight-rounding compensation
 USE_WCOMP_LINEAR = os.environ.get("PGT_WCOMP_LINEAR", "1") != "0"   # ... of the token-row linears (window-attention blocks)
 USE_ROWCHAIN = os.environ.get("PGT_ROWCHAIN", "1") != "0"           # A/B switch of the fused token-row chains (rowchain.hip)
+USE_ROWCHAIN_X3 = os.environ.get("PGT_ROWCHAIN_X3", "1") != "0"     # ... of their split-half forms (encoder-side blocks)
 
 
 class HipModule(nn.Module):
@@ -285,20 +286,27 @@ class VSTSREncoderTransformerBlock(HipModule):
         """Operands of the fused token-row chains (ops.ln_linear, ops.attn_proj_mlp: half layers of 256 channels): norm1 folded
         into the [q | k | v] projection, norm2 into fc1 (pgt_fold_layernorm), proj / fc1 / fc2 stacked into one matrix."""
         self.fused = False
-        if not (USE_ROWCHAIN and dtype == torch.float16 and self.dim == 256 and self.attn.q.bias is not None):
+        if not (USE_ROWCHAIN and self.dim == 256 and self.attn.q.bias is not None):
             return
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()   # noqa: E731
         a, m = self.attn, self.mlp
-        wq, self.f_bqkv = ops.fold_layernorm(f32(torch.cat([a.q.weight.detach(), a.kv.weight.detach()], 0)), f32(self.norm1.weight),
-                                             f32(self.norm1.bias), f32(torch.cat([a.q.bias.detach(), a.kv.bias.detach()], 0)))
-        self.f_wqkv = _pack_matrix(wq, device, dtype)
-        self.f_dqkv = _defect_t(wq, self.f_wqkv) if _wants_wcomp(dtype) else None
-        w1, self.f_b1 = ops.fold_layernorm(f32(m.fc1.weight), f32(self.norm2.weight), f32(self.norm2.bias), f32(m.fc1.bias))
-        self.f_w3 = torch.cat([_pack_matrix(f32(a.proj.weight), device, dtype), _pack_matrix(w1, device, dtype),
-                               _pack_matrix(f32(m.fc2.weight), device, dtype)], 0).contiguous()
-        self.f_bp, self.f_b2 = f32(a.proj.bias), f32(m.fc2.bias)
-        self.f_dproj = _defect_t(a.proj.weight, self.f_w3[:self.dim]) if _wants_wcomp(dtype) else None
-        self.fused = True
+        if dtype == torch.float16 or _is_x3(dtype):
+            wq, self.f_bqkv = ops.fold_layernorm(f32(torch.cat([a.q.weight.detach(), a.kv.weight.detach()], 0)), f32(self.norm1.weight),
+                                                 f32(self.norm1.bias), f32(torch.cat([a.q.bias.detach(), a.kv.bias.detach()], 0)))
+            self.f_wqkv = _pack_matrix(wq, device, dtype)
+            w1, self.f_b1 = ops.fold_layernorm(f32(m.fc1.weight), f32(self.norm2.weight), f32(self.norm2.bias), f32(m.fc1.bias))
+            self.f_b2 = f32(m.fc2.bias)
+        if dtype == torch.float16:
+            self.f_dqkv = _defect_t(wq, self.f_wqkv) if _wants_wcomp(dtype) else None
+            self.f_w3 = torch.cat([_pack_matrix(f32(a.proj.weight), device, dtype), _pack_matrix(w1, device, dtype),
+                                   _pack_matrix(f32(m.fc2.weight), device, dtype)], 0).contiguous()
+            self.f_bp = f32(a.proj.bias)
+            self.f_dproj = _defect_t(a.proj.weight, self.f_w3[:self.dim]) if _wants_wcomp(dtype) else None
+            self.fused = True
+        elif _is_x3(dtype) and USE_ROWCHAIN_X3:
+            # split blocks (encoder side): LN1 -> q|k|v and LN2 -> Mlp -> residual fused; proj + shortcut stays a linear launch
+            self.f_w2 = torch.cat([_pack_matrix(w1, device, dtype), _pack_matrix(f32(m.fc2.weight), device, dtype)], 0).contiguous()
+            self.fused = True
 
     def forward(self, xt, B, H, W, out=None, gn_images=None):
         """xt: (B*D*H*W, C) tokens in (b,d,y,x) order; out: optional (rows, C) view receiving the result.
@@ -307,7 +315,12 @@ class VSTSREncoderTransformerBlock(HipModule):
         win, shift = get_window_size((H, W), self.window_size, self.shift_size)
         x3 = _is_x3(self.dt)
         nf = B * self.num_frames                      # frames of H*W tokens (rows in (b, d, y, x) order)
-        if getattr(self, "fused", False) and xt.dtype == torch.float16 and xt.shape[0] % 128 == 0:
+        if getattr(self, "fused", False) and x3 and xt.shape[0] % 128 == 0:
+            qkv = ops.ln_linear(xt, self.f_wqkv, self.f_bqkv, self.norm1.eps, x3=True)
+            ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift, x3=True)
+            x1 = self.attn.proj.run(ao, frames=nf, res=xt)
+            return ops.ln_mlp(x1, self.f_w2, self.f_b1, self.f_b2, self.norm2.eps, out=out, x3=True)
+        if getattr(self, "fused", False) and not x3 and xt.dtype == torch.float16 and xt.shape[0] % 128 == 0:
             # two launches either side of the attention (rowchain.hip); the compensated per-frame bias of the q|k|v projection is
             # taken from the sampled mean of the NORMALISED rows, the proj one from the attention output; fc1 / fc2 run on rows
             # that never reach HBM and keep their plain bias

@@ -623,29 +623,59 @@ def fold_layernorm(w, gamma, beta, bias=None):
     return w_out, b_out
 
 
-def ln_linear(x, w, bias, eps=1e-5, out=None):
+def ln_linear(x, w, bias, eps=1e-5, out=None, x3=False):
     """y = half((x - mean) * rstd) @ w.T + bias: LayerNorm (affine part folded into w / bias by fold_layernorm) and the Linear that
-    follows it in one launch.  x (rows, 256) half; w (Cout, 256) packed half; bias (Cout,) or per frame (frames, Cout)."""
-    rows, cin = x.shape
+    follows it in one launch.  x (rows, 256) half; w (Cout, 256) packed half; bias (Cout,) or per frame (frames, Cout).
+    x3: split rows (rows, 512) -> (rows, 2 Cout), w in the split packed form (Cout, 768), the normalised row split as well."""
+    rows = x.shape[0]
     cout = w.shape[0]
-    assert x.dtype == torch.float16 and w.dtype == torch.float16 and w.is_contiguous() and w.shape[1] == cin
+    cin = x.shape[1] // 2 if x3 else x.shape[1]
+    assert x.dtype == torch.float16 and w.dtype == torch.float16 and w.is_contiguous() and w.shape[1] == (3 * cin if x3 else cin)
     if out is None:
-        out = torch.empty((rows, cout), device=x.device, dtype=x.dtype)
+        out = torch.empty((rows, 2 * cout if x3 else cout), device=x.device, dtype=x.dtype)
     brows = 0
     if bias is not None and bias.dim() == 2:
-        assert bias.shape[1] == cout and bias.is_contiguous() and rows % bias.shape[0] == 0
+        assert not x3 and bias.shape[1] == cout and bias.is_contiguous() and rows % bias.shape[0] == 0
         brows = rows // bias.shape[0]
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    hip.check(hip.lib().pgt_ln_linear(_dt(x), _p(x), _ld_rows(x), rows, cin, float(eps), _p(w), _p(bias), brows, cout, _p(out),
-                                      _ld_rows(out), _stream()), "pgt_ln_linear")
+    if x3:
+        hip.check(hip.lib().pgt_ln_linear_x3(_p(x), _ld_rows(x), cin, rows, cin, float(eps), _p(w), _p(bias), cout, _p(out),
+                                             _ld_rows(out), cout, _stream()), "pgt_ln_linear_x3")
+    else:
+        hip.check(hip.lib().pgt_ln_linear(_dt(x), _p(x), _ld_rows(x), rows, cin, float(eps), _p(w), _p(bias), brows, cout, _p(out),
+                                          _ld_rows(out), _stream()), "pgt_ln_linear")
     if prof is not None:
         e1.record()
         prof.append({"kernel": "igemm", "flops": 2.0 * rows * cin * cout, "bytes": float(_nb(x, out, w)),
-                     "shape": (1, 1, rows, cin, cout, 1, 1, 0), "events": (e0, e1), "cfg": ("ln_linear", 0, 0), "x3": False,
+                     "shape": (1, 1, rows, cin, cout, 1, 1, 0), "events": (e0, e1), "cfg": ("ln_linear", 0, 0), "x3": bool(x3),
                      "dt": "float16", "chain": "ln_linear"})
+    return out
+
+
+def ln_mlp(x, w2, b_fc1, b_fc2, eps=1e-5, out=None, x3=True):
+    """y = x + fc2(GELU(fc1(LN(x)))) on split rows (rows, 512) in one launch (pgt_ln_mlp_x3): w2 = [Wfc1 diag(gamma); Wfc2] in the
+    split packed form (512, 768), b_fc1 carrying W1 beta (fold_layernorm)."""
+    assert x3, "the half blocks take attn_proj_mlp"
+    rows, c2 = x.shape
+    c = c2 // 2
+    assert x.dtype == torch.float16 and w2.dtype == torch.float16 and tuple(w2.shape) == (2 * c, 3 * c) and w2.is_contiguous()
+    if out is None:
+        out = torch.empty((rows, c2), device=x.device, dtype=x.dtype)
+    assert out.data_ptr() != x.data_ptr()
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    hip.check(hip.lib().pgt_ln_mlp_x3(_p(x), _ld_rows(x), c, rows, c, float(eps), _p(w2), _p(b_fc1), _p(b_fc2), _p(out),
+                                      _ld_rows(out), c, _stream()), "pgt_ln_mlp_x3")
+    if prof is not None:
+        e1.record()
+        prof.append({"kernel": "igemm", "flops": 4.0 * rows * c * c, "bytes": float(_nb(x, x, out, w2)),
+                     "shape": (1, 1, rows, c, 2 * c, 1, 1, 0), "events": (e0, e1), "cfg": ("ln_mlp", 0, 0), "x3": True,
+                     "dt": "float16", "chain": "ln_mlp"})
     return out
 
 
@@ -978,3 +1008,55 @@ def frame_to_u8(x, out=None):
     assert out.is_contiguous() and tuple(out.shape) == (h, w, 3)
     hip.check(hip.lib().pgt_frame_to_u8(_dt(x), _p(x), x.stride(1), h, w, _p(out), _stream()), "pgt_frame_to_u8")
     return out
+
+
+# ---- range telemetry (include/pgt_hip.h: pgt_count_saturated) ------------------------------------------------------------------
+# fp32 -> half stores saturate at +-65504 (PGT_F16 / the planes of PGT_F16X3).  With RANGE_CHECK set to a list every operator
+# below counts the elements of its IEEE-half outputs that sit at the limit (or are not finite) and appends
+# (operator, output shape, int32 device counter): PGTFormer.check_range / WindowRunner run one such pass on the first frames
+# they see and refuse to continue when a layer saturates (a checkpoint whose activations leave the half range needs
+# precision="bf16x3").
+RANGE_CHECK = None
+RANGE_CTX = []          # names of the modules whose forward() is executing (PGTFormer.check_range registers the hooks)
+
+
+def _note_range(name, out):
+    if RANGE_CHECK is None:
+        return
+    for t in (out if isinstance(out, (tuple, list)) else (out,)):
+        if not torch.is_tensor(t) or t.dtype != torch.float16 or not t.is_cuda or t.numel() == 0 or t.shape[-1] % 8:
+            continue
+        if t.dim() == 4:
+            rows, ld = t.shape[0] * t.shape[1] * t.shape[2], _ld_img(t)
+        elif t.dim() == 2:
+            rows, ld = t.shape[0], _ld_rows(t)
+        else:
+            continue
+        if ld % 8 or t.data_ptr() % 16:
+            continue
+        cnt = torch.zeros((1,), dtype=torch.int32, device=t.device)
+        hip.check(hip.lib().pgt_count_saturated(_p(t), ld, rows, t.shape[-1], _p(cnt), _stream()), "pgt_count_saturated")
+        RANGE_CHECK.append(((RANGE_CTX[-1] + ":" if RANGE_CTX else "") + name, tuple(t.shape), cnt))
+
+
+def _range_wrap(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        out = fn(*a, **k)
+        # (placed outputs - out_rows / out_parity - cover a view that several launches fill: its other rows are not written yet)
+        if RANGE_CHECK is not None and k.get("out_rows") is None and k.get("out_parity") is None:
+            _note_range(fn.__name__, out)
+        return out
+    return wrapped
+
+
+for _n in ("conv2d", "affine_act", "layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp", "window_attention", "window_attention3d", "mha",
+           "to_x3", "x3_to_half"):
+    globals()[_n] = _range_wrap(globals()[_n])
+
+
+def range_report(records):
+    """[(operator, shape, saturated count)] of the records a RANGE_CHECK pass collected (synchronises)."""
+    return [(n, s, int(c.item())) for n, s, c in records]

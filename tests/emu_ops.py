@@ -272,8 +272,24 @@ def fold_layernorm(w, gamma, beta, bias=None):
     return (w * gamma.float()[None, :]).contiguous(), (b if bias is None else b + bias.float())
 
 
-def ln_linear(x, w, bias, eps=1e-5, out=None):
+def _rownorm_x3(x, eps):
+    """split rows -> normalised rows, split again (the operand of the split-half chain kernels)"""
+    xf = _merge(x)
+    mu = xf.mean(-1, keepdim=True)
+    d = xf - mu
+    return _split(d * (d.pow(2).mean(-1, keepdim=True) + eps).rsqrt())
+
+
+def ln_linear(x, w, bias, eps=1e-5, out=None, x3=False):
+    if x3:
+        return linear(_rownorm_x3(x, eps), w, bias, out=out, x3=True)
     return linear(_rownorm(x, eps), w, bias, out=out)
+
+
+def ln_mlp(x, w2, b_fc1, b_fc2, eps=1e-5, out=None, x3=True):
+    c = x.shape[1] // 2
+    h = linear(_rownorm_x3(x, eps), w2[:c], b_fc1, act=ACT_GELU, x3=True)
+    return linear(h, w2[c:], b_fc2, res=x, out=out, x3=True)
 
 
 def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
@@ -519,7 +535,7 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "sample_rows", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
        "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update", "sampled_channel_mean", "mean_field_bias",
-       "sampled_rownorm_mean", "fold_layernorm", "ln_linear", "attn_proj_mlp"]
+       "sampled_rownorm_mean", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp"]
 
 
 def install(monkeypatch):

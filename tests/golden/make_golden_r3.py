@@ -267,5 +267,50 @@ def more_windows():
     print("r3_golden_more.npz", os.path.getsize(os.path.join(HERE, "r3_golden_more.npz")) // 1024, "KiB")
 
 
+SWEEP_CLIPS, SWEEP_WINDOWS = (4077, 5077), range(1, 7)     # the 12 windows of tests/test_gpu_model.py::test_psnr_contract_sweep_*
+
+
+def sweep_windows():
+    """`--sweep`: the REFERENCE on the 12 windows of the regression sweep (windows 1..6 of the 8-frame clips 4077 and 5077, same
+    operating point) -> r4_golden_sweep.npz: per window the arg-max codes, the reference's own top-2 logit margins (what decides
+    whether a differing code is a near-tie of the reference or an error of the build) and every 8th fp32 row of the middle frame."""
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    from archs.pgtformer_arch import PGTFormer                       # reference
+
+    from pgtformer_amd.config import default_config
+    from pgtformer_amd.manifest import pgtformer_manifest
+    from pgtformer_amd.synth import make_clip, window_from_clip
+    from pgtformer_amd.weightgen import generate_state_dict
+    from r3_scheme import fitted_tail_state_dict
+
+    torch.manual_seed(0)
+    torch.use_deterministic_algorithms(True)
+    cfg = default_config()
+    model = PGTFormer(**cfg)
+    model.eval()
+    model.load_state_dict(fitted_tail_state_dict(generate_state_dict(pgtformer_manifest(cfg), cfg, seed=0)), strict=True)
+    full = {}
+    for seed in SWEEP_CLIPS:
+        lq_u8, gt = make_clip(8, 512, seed=seed)
+        for i in SWEEP_WINDOWS:
+            x = torch.from_numpy(window_from_clip(lq_u8, i).astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+            g = torch.from_numpy(gt[i]).permute(2, 0, 1)
+            t0 = time.time()
+            with torch.no_grad():
+                out, logits, _ = model(x.clone(), w=1.0)
+            lg = logits.reshape(-1, logits.shape[-1])
+            top2 = lg.topk(2, dim=-1).values
+            tag = f"c{seed}w{i}"
+            print(f"{tag}: middle frame range [{out[1].min().item():.3f}, {out[1].max().item():.3f}], PSNR(ref, GT) {psnr(out[1], g):.3f} dB, "
+                  f"smallest top-2 margin {float((top2[:, 0] - top2[:, 1]).min()):.2e}  ({time.time() - t0:.0f} s)", flush=True)
+            full[f"{tag}.out_mid_rows"] = out[1, :, ::8, :].numpy()
+            full[f"{tag}.codes"] = lg.argmax(-1).numpy().astype(np.int16)
+            full[f"{tag}.top2_margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float32)
+            full[f"{tag}.psnr_ref_vs_gt_db"] = np.array([psnr(out[1], g)])
+    np.savez_compressed(os.path.join(HERE, "r4_golden_sweep.npz"), **full)
+    print("r4_golden_sweep.npz", os.path.getsize(os.path.join(HERE, "r4_golden_sweep.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    more_windows() if "--more" in sys.argv else main()
+    sweep_windows() if "--sweep" in sys.argv else more_windows() if "--more" in sys.argv else main()

@@ -674,3 +674,37 @@ def test_cli_streams_a_raw_clip_end_to_end(models, tmp_path):
         _LOG[f"cli_stream/{prec}"] = {"max_u8_diff": int(d.max()), "equal_fraction": float((d == 0).mean()),
                                       "two_processes_bit_equal": True}
         assert d.max() <= 1 and (d == 0).mean() > 0.99, _LOG[f"cli_stream/{prec}"]
+
+
+def test_range_telemetry_reports_saturated_half_stores(tail_models):
+    """The IEEE-half modes clamp at +-65504 instead of producing inf: PGTFormer.check_range counts, per
+    operator, the half outputs that sit at the limit.  On the operating-point windows NOTHING saturates (asserted: the PSNR
+    contract figures above are not figures of a clamped decoder); a decoder whose conv_in weights are scaled by 1e5 is reported,
+    and the driver refuses to run it."""
+    from pgtformer_amd import hip
+    from pgtformer_amd.driver import WindowRunner
+    from pgtformer_amd.synth import make_clip
+
+    m = tail_models["x3f16"]
+    lq_u8, _ = make_clip(4, 512, seed=1234)
+    fr = torch.from_numpy(lq_u8).to(DEV)
+    bad = m.check_range(fr, w=1.0, win=m.window_index(2, 3, DEV))
+    _LOG["range_telemetry/x3f16"] = {"tensors_checked": m.last_range_launches, "saturating": [list(map(str, b)) for b in bad]}
+    assert m.last_range_launches > 300 and bad == [], bad
+    # a deliberately out-of-range decoder
+    conv = m.decoder.conv_in
+    keep = conv.weight.detach().clone()
+    try:
+        with torch.no_grad():
+            conv.weight.mul_(1e5)
+        conv._pack(m.dev, conv.dt)
+        bad = m.check_range(fr, w=1.0, win=m.window_index(2, 3, DEV))
+        assert bad and all(c > 0 for _, _, c in bad), bad
+        runner = WindowRunner(m, use_graph=False, batch=2, check_range=True)
+        with pytest.raises(hip.PgtError, match="half range"):
+            runner.run(fr)
+    finally:
+        with torch.no_grad():
+            conv.weight.copy_(keep)
+        conv._pack(m.dev, conv.dt)
+    assert m.check_range(fr, w=1.0, win=m.window_index(2, 3, DEV)) == []

@@ -170,3 +170,80 @@ def test_block_fused_equals_layer_by_layer():
         b.fused = False
     y_u = layer(x).float().cpu()
     check("block_fused_vs_unfused", y_f, y_u, 4e-3)
+
+
+# ---- split-half forms (encoder-side blocks): against the fp32 emulation on the same split inputs, merged outputs, 2e-5 relative
+#      (tests/test_gpu_x3.py: 22 significand bits on two half planes, three MFMA products, fp32 accumulation)
+def _x3w(w):
+    return E.pack_conv_weight(w, "f16x3")
+
+
+@pytest.mark.parametrize("case", ["rows128", "ragged", "cout256", "big_r2", "big_r1"])
+def test_ln_linear_x3(case, monkeypatch):
+    ops = O()
+    rows, cout = 128, 768
+    if case == "ragged":
+        rows = 1000 + 13
+    elif case == "cout256":
+        rows, cout = 384, 256
+    elif case in ("big_r2", "big_r1"):
+        rows = 131072
+        monkeypatch.setenv("PGT_RC_LNX3", "r2" if case == "big_r2" else "r1")
+    x = E.to_x3(rnd((rows, 256), 61) * 1.3 + 0.2)
+    w = rnd((cout, 256), 62, scale=0.06)
+    w[:, 0] += torch.arange(cout, dtype=torch.float32) * 0.002
+    w[0, :] += torch.arange(256, dtype=torch.float32) * 0.001
+    wp = _x3w(w)
+    bias = rnd((cout,), 63)
+    want = E.from_x3(E.ln_linear(x, wp, bias, x3=True))
+    got = ops.ln_linear(x.to(DEV), wp.to(DEV), bias.to(DEV), x3=True)
+    check(f"ln_linear_x3_{case}", ops.from_x3(got), want, 2e-5)
+    # against the two launches it replaces
+    ln = ops.layernorm(x.to(DEV), torch.ones(256, device=DEV), torch.zeros(256, device=DEV), x3=True)
+    ref = ops.linear(ln, wp.to(DEV), bias.to(DEV), x3=True)
+    check(f"ln_linear_x3_{case}_vs_unfused", ops.from_x3(got), ops.from_x3(ref), 2e-5)
+
+
+@pytest.mark.parametrize("case", ["rows128", "ragged", "big"])
+def test_ln_mlp_x3(case):
+    ops = O()
+    rows = {"rows128": 128, "ragged": 2048 + 77, "big": 98304}[case]
+    c = 256
+    x = E.to_x3(rnd((rows, c), 71) * 1.2)
+    w1, w2 = rnd((c, c), 72, scale=0.06), rnd((c, c), 73, scale=0.06)
+    w1[:, 0] += torch.arange(c, dtype=torch.float32) * 0.002
+    w2[0, :] += torch.arange(c, dtype=torch.float32) * 0.001
+    wp = torch.cat([_x3w(w1), _x3w(w2)], 0).contiguous()
+    b1, b2 = rnd((c,), 74), rnd((c,), 75)
+    want = E.from_x3(E.ln_mlp(x, wp, b1, b2))
+    got = ops.ln_mlp(x.to(DEV), wp.to(DEV), b1.to(DEV), b2.to(DEV))
+    check(f"ln_mlp_x3_{case}", ops.from_x3(got), want, 2e-5)
+    xg = x.to(DEV)
+    ln = ops.layernorm(xg, torch.ones(c, device=DEV), torch.zeros(c, device=DEV), x3=True)
+    h = ops.linear(ln, wp[:c].contiguous().to(DEV), b1.to(DEV), act=E.ACT_GELU, x3=True)
+    ref = ops.linear(h, wp[c:].contiguous().to(DEV), b2.to(DEV), res=xg, x3=True)
+    check(f"ln_mlp_x3_{case}_vs_unfused", ops.from_x3(got), ops.from_x3(ref), 2e-5)
+    assert torch.equal(ops.ln_mlp(xg, wp.to(DEV), b1.to(DEV), b2.to(DEV)), got)
+
+
+def test_block_fused_equals_layer_by_layer_x3():
+    from pgtformer_amd.modules.rstt_layers import EncoderLayer
+    from pgtformer_amd.ops import X3
+    torch.manual_seed(1)
+    layer = EncoderLayer(256, 2, 8, 3, window_size=(4, 4), mlp_ratio=1.0)
+    with torch.no_grad():
+        for n_, p_ in layer.named_parameters():
+            if p_.dim() == 2 and "relative_position" not in n_:
+                p_.normal_(0, 0.06)
+            elif "norm" in n_ and n_.endswith("weight"):
+                p_.copy_(1 + 0.1 * torch.randn_like(p_))
+            elif p_.dim() == 1:
+                p_.normal_(0, 0.1)
+    layer.prepare(DEV, X3)
+    assert all(b.fused for b in layer.blocks)
+    x = O().to_x3((rnd((6, 32, 32, 256), 9) * 1.2).to(DEV))
+    y_f = O().from_x3(layer(x)).cpu()
+    for b in layer.blocks:
+        b.fused = False
+    y_u = O().from_x3(layer(x)).cpu()
+    check("block_fused_vs_unfused_x3", y_f, y_u, 2e-5)
