@@ -73,9 +73,9 @@ typedef struct pgt_conv_desc {
     int32_t out_f32;            /* 1: store y as fp32 even when dtype is bf16 (logits, distances) */
     int32_t force_bm, force_bn; /* 0 = heuristic; 64|128 pins the workgroup tile (tests, tuning)  */
     int32_t scalar_epilogue;    /* 1: force the element-wise epilogue (A/B tests); 0 = 16-byte path when legal */
-    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 3 = large-tile v3; 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-input-channel 3x3 with the weights in registers (bf16 / half; split-half: Cout % 16 == 0); 7 = streaming linear for Cin == 256, Cout % 256 == 0 (bf16 / half, plain epilogue, 16-bit output): weights in registers, rows through LDS */
+    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-input-channel 3x3 with the weights in registers (bf16 / half; split-half: Cout % 16 == 0); 7 = streaming linear for Cin == 256, Cout % 256 == 0 (bf16 / half, plain epilogue, 16-bit output): weights in registers, rows through LDS */
     int32_t splitk;             /* 0 = auto (needs a workspace); 1 = never; 2..16 = that many K slices           */
-    int32_t stages;             /* LDS pipeline depth for kernel = 3 (0 = default)                             */
+    int32_t stages;             /* unused (was the LDS pipeline depth of the removed kernel = 3)               */
     /* output placement: row index of output pixel m = orow_mul*m + orow_xmul*(m % Wo) + orow_off (orow_mul = 0: dense,
      * row m).  (4, -2, py*2*Wo + px) writes parity (py, px) of a 2x larger map: the four 2x2 sub-pixel convolutions
      * that replace nearest-x2 up-sampling + conv3x3 (archs/tdcrqvae3_arch.py:34-52).  Plain epilogue only (no
@@ -167,6 +167,13 @@ int pgt_sampled_channel_mean(int32_t dtype, const void* x, int32_t ldx, int32_t 
 int pgt_sampled_pixel(int32_t HW, int32_t i);
 int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* bias, int32_t R, int32_t K, int32_t Cout,
                         float* out, pgt_stream_t stream);
+/* pgt_weight_defect: the (K x Cout) fp32 operand `defect_t` of pgt_mean_field_bias for a layer, from its fp32 reference weight
+ * (Cout, Cin, KH, KW) (x out_scale[o] where given, e.g. the BatchNorm fold) and the packed 16-bit operand pgt_pack_conv_weight
+ * wrote for it: defect_t[k][o] = sum over taps of (w * scale - packed)[o][k][tap], K = Cin_pad; sum_taps = 0 keeps one row per
+ * (tap, k) (K = KH*KW*Cin_pad: a conv whose taps read different frames).  PGT_F16 / PGT_BF16.  With this a non-Python host
+ * reaches the default precision mode's compensated layers from the header alone. */
+int pgt_weight_defect(int32_t dtype, const float* w_oihw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t Cin_pad,
+                      const float* out_scale, const void* packed, int32_t sum_taps, float* defect_t, pgt_stream_t stream);
 /* The sampled mean for a layer that reads NORMALISED rows (pgt_ln_linear below): mean[n][c] over frame n's sample of
  * half((x[p][c] - mu_p) * rstd_p), mu_p / rstd_p = the LayerNorm statistics of row p over its C channels (C = 256 or 512;
  * PGT_F16 / PGT_BF16). */

@@ -572,7 +572,6 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     // v3 (large tiles, 8-16 waves): additionally stride 1, no up-sampling, <= 32 taps, 32-bit byte offsets
     const bool v3_legal = v2_legal && !placed && d->stride == 1 && d->ups == 0 && d->KH * d->KW <= 32 &&
                           (long)d->N * d->H * d->W * d->ldx * 2 < (1L << 31);
-    PGT_CHECK(d->kernel != 3 || v3_legal, "pgt_conv2d: kernel=3 needs bf16, stride 1, no up-sampling, Cin %% 64 == 0");
     // auto: 256x256 tiles (16 waves, 2 LDS stages) win on the Cout >= 256 convs once the grid covers the chip at
     // least twice (profiles/r1_igemm_shapes_v7.txt: 256->256 3x3 @ 12x128x128 363 -> 300 us)
     if (d->kernel == 0 && v3_legal && d->force_bm == 0 && d->force_bn == 0 && d->Cout % 256 == 0 && p.K >= 1024 &&
@@ -614,12 +613,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
         PGT_CHECK(rc != 1, "pgt_conv2d: kernel=4 has no %d-column tile (128, 256)", d->force_bn);
         return rc;
     }
-    if (d->kernel == 3) {
-        const int rc = pgt_igemm3_launch(&p, d->force_bm ? d->force_bm : 256, d->force_bn ? d->force_bn : 128,
-                                         d->stages ? d->stages : 3, st);
-        PGT_CHECK(rc != 1, "pgt_conv2d: kernel=3 tile %dx%d with %d stages is not built", d->force_bm, d->force_bn, d->stages);
-        return rc;
-    }
+    PGT_CHECK(d->kernel != 3, "pgt_conv2d: kernel=3 (the large-tile LDS-DMA variant of rounds 1-2) was removed; use 0, 1, 2, 4, 5, 6, 7");
     if (v2_legal && !placed && d->kernel != 1 && !p.gn_part && !f16) {
         const int bn = (d->force_bn == 64 || (d->force_bn == 0 && d->Cout <= 64)) ? 64 : 128;
         const long blocks = (long)((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);

@@ -715,6 +715,48 @@ extern "C" int pgt_zero2d(void* dst, int64_t ldd_bytes, int64_t rows, int32_t ro
     return 0;
 }
 
+// ---- rounding defect of a packed 16-bit weight (the operand of pgt_mean_field_bias) -------------------
+// defect_t[k][o] = sum over the filter taps of (w[o][k][tap] * scale[o] - packed[o][tap * Cin_pad + k])  (sum_taps), or one row
+// per (tap, k) (taps reading different frames: the composed temporal mix).  Sums in double, one thread per (k, o).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void weight_defect_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int Cin_pad,
+                                                            const float* __restrict__ scale, const T* __restrict__ packed,
+                                                            int sum_taps, float* __restrict__ defect_t) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long K = sum_taps ? Cin_pad : (long)taps * Cin_pad;
+    if (i >= K * Cout) return;
+    const int o = (int)(i % Cout);
+    const long kk = i / Cout;
+    const float sc = scale ? scale[o] : 1.f;
+    double acc = 0.0;
+    const int t0 = sum_taps ? 0 : (int)(kk / Cin_pad), t1 = sum_taps ? taps : t0 + 1;
+    const int k = (int)(kk % Cin_pad);
+    for (int t = t0; t < t1; ++t) {
+        const double ref = k < Cin ? (double)(w[((long)o * Cin + k) * taps + t] * sc) : 0.0;
+        acc += ref - (double)ldf(packed + (long)o * taps * Cin_pad + (long)t * Cin_pad + k);
+    }
+    defect_t[kk * Cout + o] = (float)acc;
+}
+}  // namespace
+
+extern "C" int pgt_weight_defect(int32_t dtype, const float* w_oihw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t Cin_pad,
+                                 const float* out_scale, const void* packed, int32_t sum_taps, float* defect_t, pgt_stream_t stream) {
+    PGT_CHECK(w_oihw && packed && defect_t && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && Cin_pad >= Cin, "weight_defect: bad argument");
+    PGT_CHECK(dtype == PGT_BF16 || dtype == PGT_F16, "weight_defect: dtype %d (single-plane 16-bit weights only)", dtype);
+    const int taps = KH * KW;
+    const long total = (long)(sum_taps ? Cin_pad : (long)taps * Cin_pad) * Cout;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PGT_F16)
+        hipLaunchKernelGGL(weight_defect_kernel<half_t>, grid1d(total), dim3(256), 0, st, w_oihw, Cout, Cin, taps, Cin_pad, out_scale,
+                           (const half_t*)packed, sum_taps, defect_t);
+    else
+        hipLaunchKernelGGL(weight_defect_kernel<bf16_t>, grid1d(total), dim3(256), 0, st, w_oihw, Cout, Cin, taps, Cin_pad, out_scale,
+                           (const bf16_t*)packed, sum_taps, defect_t);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- range telemetry of the IEEE-half tensors (PGT_F16 / the hi plane of PGT_F16X3) ---------------------------------------
 // fp32 -> half stores of the kernels SATURATE at +-65504 instead of producing inf (common.h sat_half): a tensor that hits the
 // limit is silently clamped.  This pass counts the elements of a (rows x cols, row stride ld) half matrix that sit at the

@@ -17,8 +17,6 @@ int pgt_window_attn_mfma(int mode, const void* qkv, int ldqkv, void* out, int ld
                          int W, int C, int heads, int wd, int wh, int ww, int sd, int sh, int sw, hipStream_t st,
                          int qlo = 0, int olo = 0);
 
-// igemm3.hip: large-tile LDS-DMA implicit GEMM (bf16, stride 1, no up-sampling, Cin % 64 == 0); 1 = combination not built
-int pgt_igemm3_launch(const void* conv_p, int bm, int bn, int stages, hipStream_t st);
 // igemm4.hip: phase-interleaved 8-wave schedule; bn = 256 -> 256x256 tiles, bn = 128 -> 512x128 tiles; 1 = tile not built
 int pgt_igemm4_launch(const void* conv_p, int bn, hipStream_t st);
 // igemm5.hip: igemm4's 256x256 schedule with one LDS input image shared by the three horizontal taps (3-wide filters)

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pgt_adain_affine": [vp, vp, vp, vp, f32, vp, vp, i32, vp],
     "pgt_sampled_channel_mean": [i32, vp, i32, i32, i32, i32, vp, vp],
     "pgt_sampled_pixel": [i32, i32],
+    "pgt_weight_defect": [i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "pgt_sampled_rownorm_mean": [i32, vp, i32, i32, i32, i32, f32, vp, vp],
     "pgt_fold_layernorm": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
     "pgt_ln_linear": [i32, vp, i32, i32, i32, f32, vp, vp, i32, i32, vp, i32, vp],

@@ -74,17 +74,7 @@ def _defect_t(w, pw, scale=None, sum_taps=True):
     whose taps read different frames).  w: the fp32 reference weight (Cout, Cin[, KH, KW]); pw = _pack_matrix(w, ...) of it.
     DESIGN.md section 2.2: y = W x + b run with W16 leaves (W - W16) x, whose frame-constant part (W - W16) mean(x) is
     put back as a per-frame bias."""
-    w32 = w.detach().to(device=pw.device, dtype=torch.float32)
-    cout, cin = w32.shape[0], w32.shape[1]
-    if scale is not None:
-        w32 = w32 * scale.view(-1, *([1] * (w32.dim() - 1)))
-    taps = w32.shape[2] * w32.shape[3] if w32.dim() == 4 else 1
-    cp = pw.shape[1] // taps
-    assert pw.shape == (cout, taps * cp) and cp >= cin, (pw.shape, w32.shape)
-    d = torch.zeros((cout, taps, cp), dtype=torch.float64, device=pw.device)
-    d[:, :, :cin] = w32.reshape(cout, cin, taps).permute(0, 2, 1).double() - pw.view(cout, taps, cp)[:, :, :cin].double()
-    d = d.sum(1) if sum_taps else d.reshape(cout, taps * cp)
-    return d.float().t().contiguous()
+    return ops.weight_defect(w.detach().to(device=pw.device, dtype=torch.float32), pw, scale=scale, sum_taps=sum_taps)   # pgt_weight_defect
 
 
 def _frame_bias(x, pdef, pb, frames=None):

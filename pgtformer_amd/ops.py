@@ -256,7 +256,7 @@ def _ld_rows(x):
 # heuristic stays one of the candidates, so tuning never loses to it.  fp32 (parity) launches are never tuned.
 AUTOTUNE = None
 _TUNE_CANDIDATES = ((0, (0, 0), 0), (1, (64, 64), 0), (1, (64, 128), 0), (1, (128, 64), 0), (1, (128, 128), 0),
-                    (3, (256, 256), 2), (4, (0, 256), 0), (4, (0, 128), 0), (5, (0, 0), 0), (6, (0, 0), 0))
+                    (4, (0, 256), 0), (4, (0, 128), 0), (5, (0, 0), 0), (6, (0, 0), 0))
 
 
 def enable_autotune(flag=True):
@@ -297,7 +297,7 @@ def _tune_conv(d, args, device, iters=4, gn_ws=None):
     L = hip.lib()
     best, best_t = _TUNE_CANDIDATES[0], None
     for cand in _TUNE_CANDIDATES:
-        if gn_ws is not None and cand[0] in (2, 3, 5, 6):
+        if gn_ws is not None and cand[0] in (2, 5, 6):
             continue       # statistics epilogue: kernels 1 and 4 (the heuristic picks among them)
         d.kernel, (d.force_bm, d.force_bn), d.stages = cand
         ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
@@ -704,6 +704,21 @@ def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
         prof.append({"kernel": "igemm", "flops": 6.0 * rows * c * c, "bytes": float(_nb(ao, shortcut, out, w3)),
                      "shape": (1, 1, rows, c, 3 * c, 1, 1, 0), "events": (e0, e1), "cfg": ("proj_mlp", 0, 0), "x3": False,
                      "dt": "float16", "chain": "proj_mlp"})
+    return out
+
+
+def weight_defect(w, packed, scale=None, sum_taps=True):
+    """(K, Cout) fp32 rounding defect of a packed 16-bit weight - the operand of mean_field_bias (pgt_weight_defect): w fp32
+    (Cout, Cin[, KH, KW]) on the device, packed = pack_conv_weight(w, half / bf16, ...) of it (Cin possibly zero-padded)."""
+    assert w.dtype == torch.float32 and w.dim() in (2, 4) and packed.dim() == 2 and packed.is_contiguous()
+    w = w.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    cp = packed.shape[1] // (kh * kw)
+    assert packed.shape == (cout, kh * kw * cp) and cp >= cin, (packed.shape, w.shape)
+    out = torch.empty((cp if sum_taps else kh * kw * cp, cout), dtype=torch.float32, device=w.device)
+    hip.check(hip.lib().pgt_weight_defect(_dt(packed), _p(w), cout, cin, kh, kw, cp, _p(scale), _p(packed), int(bool(sum_taps)),
+                                          _p(out), _stream()), "pgt_weight_defect")
     return out
 
 

@@ -299,6 +299,20 @@ def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
     return linear(h, w3[2 * c:], b_fc2, res=x1, out=out)
 
 
+def weight_defect(w, packed, scale=None, sum_taps=True):
+    w32 = w.float()
+    cout, cin = w32.shape[0], w32.shape[1]
+    if scale is not None:
+        w32 = w32 * scale.view(-1, *([1] * (w32.dim() - 1)))
+    taps = w32.shape[2] * w32.shape[3] if w32.dim() == 4 else 1
+    cp = packed.shape[1] // taps
+    d = torch.zeros((cout, taps, cp), dtype=torch.float64)
+    d[:, :, :cin] = w32.reshape(cout, cin, taps).permute(0, 2, 1).double() - packed.view(cout, taps, cp)[:, :, :cin].double()
+    d[:, :, cin:] = -packed.view(cout, taps, cp)[:, :, cin:].double()
+    d = d.sum(1) if sum_taps else d.reshape(cout, taps * cp)
+    return d.float().t().contiguous()
+
+
 def adain_affine(mean_c, var_c, mean_s, var_s, eps=1e-5):
     scale = (var_s + eps).sqrt() / (var_c + eps).sqrt()
     return scale, mean_s - mean_c * scale
@@ -535,7 +549,7 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "sample_rows", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
        "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update", "sampled_channel_mean", "mean_field_bias",
-       "sampled_rownorm_mean", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp"]
+       "sampled_rownorm_mean", "weight_defect", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp"]
 
 
 def install(monkeypatch):

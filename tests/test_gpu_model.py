@@ -328,40 +328,51 @@ def test_psnr_contract_on_windows_of_other_clips(tail_models, tag):
     assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_build_vs_ref_unclamped_db"] >= 70.0, rec
 
 
-def test_psnr_contract_sweep_against_the_fp32_build(tail_models):
-    """Regression guard for the sweep of profiles/r3_psnr_sweep.md at a size that runs in seconds: 12 windows of two more clips
-    through the benchmarked path, default mode against the fp32 build (which is pinned to the reference at 134 dB / < 1e-6 dB
-    by the tests above and so stands in for it where no reference fixture exists).  On every window whose codes all equal the
-    fp32 build's: |dPSNR vs GT| <= 1e-3 dB and PSNR(build, fp32 build) >= 75 dB; windows with a flipped code (near-ties at the
-    level of the fp32 build's own logit error) are counted and reported, and must stay the exception."""
+def test_psnr_contract_sweep_against_reference_fixtures(tail_models):
+    """The 12 windows of the regression sweep (windows 1..6 of the 8-frame clips 4077 and 5077) through the benchmarked path,
+    default mode, against REFERENCE fixtures (tests/golden/r4_golden_sweep.npz, make_golden_r3.py --sweep: the reference's codes,
+    its own top-2 logit margins and every 8th fp32 row of the middle frame).  Gate:
+      * every code equals the reference's, except at tokens where the REFERENCE's top-2 margin is below 1e-4 - a near-tie the
+        reference itself resolves only up to its fp32 summation order (its logit noise is ~5e-6; the build's 1.25e-5);
+      * on every window without a differing token: |PSNR(build, GT) - PSNR(reference, GT)| <= 1e-3 dB on the fixture rows and
+        PSNR(build, reference) >= 75 dB.
+    Round 3 compared with the fp32 BUILD here and tolerated one differing window without knowing who was right: on that
+    window (clip 4077, window 6) the reference's margin at the token is 1.4e-6."""
     from pgtformer_amd.synth import make_clip
 
-    recs, flips = [], 0
+    g = np.load(os.path.join(GOLD, "r4_golden_sweep.npz"))
+    m = tail_models["x3f16"]
+    recs, near_ties = [], 0
     for seed in (4077, 5077):
         lq_u8, gt = make_clip(8, 512, seed=seed)
         fr = torch.from_numpy(lq_u8).to(DEV)
-        outs, codes = {}, {}
-        for prec in ("fp32", "x3f16"):
-            m = tail_models[prec]
-            o, c = [], []
-            for s0 in range(0, 6, 2):                       # two windows per forward
-                y, _, _ = m.forward_nhwc(fr[s0:s0 + 4], w=1.0, win=m.window_index(2, 3, DEV), middle_only=True)
-                o.append(y.float().cpu())
-                c.append(m.last_codes.cpu().clone().reshape(2, -1))
-            outs[prec], codes[prec] = torch.cat(o, 0), torch.cat(c, 0)
+        outs, codes = [], []
+        for s0 in range(0, 6, 2):                       # two windows per forward
+            y, _, _ = m.forward_nhwc(fr[s0:s0 + 4], w=1.0, win=m.window_index(2, 3, DEV), middle_only=True)
+            outs.append(y.float().cpu())
+            codes.append(m.last_codes.cpu().clone().reshape(2, -1))
+        outs, codes = torch.cat(outs, 0), torch.cat(codes, 0)
         for j in range(6):
-            g = torch.from_numpy(gt[j + 1])
-            same = bool((codes["x3f16"][j] == codes["fp32"][j]).all())
-            rec = {"clip_seed": seed, "window": j + 1, "codes_equal": same, "psnr_fp32_vs_gt_db": psnr(outs["fp32"][j], g),
-                   "dpsnr_db": psnr(outs["x3f16"][j], g) - psnr(outs["fp32"][j], g),
-                   "psnr_vs_fp32_db": psnr(outs["x3f16"][j], outs["fp32"][j])}
+            tag = f"c{seed}w{j + 1}"
+            ref_codes = torch.from_numpy(g[f"{tag}.codes"].astype(np.int64)).reshape(-1)
+            margin = torch.from_numpy(g[f"{tag}.top2_margin"]).reshape(-1)
+            diff = (codes[j].long() != ref_codes).nonzero().reshape(-1)
+            ref_rows = torch.from_numpy(g[f"{tag}.out_mid_rows"]).double()
+            rows = outs[j].permute(2, 0, 1)[:, ::8, :].double()
+            gt_rows = torch.from_numpy(gt[j + 1]).permute(2, 0, 1)[:, ::8, :].double()
+            rec = {"clip_seed": seed, "window": j + 1, "differing_tokens": int(diff.numel()),
+                   "reference_margin_at_differing_tokens": [float(margin[i]) for i in diff],
+                   "smallest_reference_margin": float(margin.min()), "psnr_ref_vs_gt_db": psnr(ref_rows, gt_rows),
+                   "dpsnr_db": psnr(rows, gt_rows) - psnr(ref_rows, gt_rows), "psnr_build_vs_ref_db": psnr(rows, ref_rows)}
             recs.append(rec)
-            flips += not same
-            if same:
-                assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_vs_fp32_db"] >= 75.0, rec
-            assert rec["psnr_fp32_vs_gt_db"] >= 25.0, rec
-    _LOG["operating_point_sweep/x3f16_vs_fp32_build"] = {"windows": recs, "windows_with_a_flipped_code": flips}
-    assert flips <= 1, recs        # (two bf16 planes: 3 of these 12 windows; two half planes: 1, clip 4077 window 6)
+            assert all(mg < 1e-4 for mg in rec["reference_margin_at_differing_tokens"]), rec     # only the reference's near-ties
+            assert rec["psnr_ref_vs_gt_db"] >= 25.0, rec
+            if diff.numel() == 0:
+                assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_build_vs_ref_db"] >= 75.0, rec
+            else:
+                near_ties += 1
+    _LOG["operating_point_sweep/x3f16_vs_reference"] = {"windows": recs, "windows_with_a_near_tie_resolved_differently": near_ties}
+    assert near_ties <= 2, recs
 
 
 def test_whole_model_pure_bf16_report(models, golden_window):

@@ -384,33 +384,6 @@ def test_window_attention_f32_rejects_large_windows():
 
 
 V3_SHAPES = [("v3_c3x3", 2, 20, 24, 64, 128, 3), ("v3_lin_ragged", 1, 1, 333, 256, 72, 1), ("v3_c3x3_wide", 3, 16, 16, 128, 264, 3)]
-V3_TILES = [(256, 128, 2), (256, 128, 3), (256, 256, 2), (128, 256, 2), (128, 256, 3)]
-
-
-@pytest.mark.parametrize("tile", V3_TILES)
-@pytest.mark.parametrize("shape", V3_SHAPES, ids=[s[0] for s in V3_SHAPES])
-def test_conv2d_large_tile_kernel(shape, tile):
-    """igemm3 (256-row / 256-column workgroup tiles, 8-16 waves, LDS-DMA) against the emulation and v1."""
-    name, n, h, w_, cin, cout, k = shape
-    bm, bn, nst = tile
-    dtype = torch.bfloat16
-    x = rnd((n, h, w_, cin), 210, dtype)
-    wt = rnd((cout, k * k * cin), 211, dtype, 1.0 / np.sqrt(k * k * cin))
-    wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
-    b = rnd((cout,), 212, torch.float32, 0.1)
-    kw = dict(kh=k, kw=k, pad=(k // 2,) * 4)
-    v3 = dict(kernel=3, tile=(bm, bn), stages=nst)
-    want = E.conv2d(x, wt, b, act=E.ACT_SILU, **kw)
-    check(f"{name}_{tile}", ops().conv2d(g(x), g(wt), g(b), act=E.ACT_SILU, **v3, **kw), want, dtype)
-    res = rnd(tuple(want.shape), 213, dtype)
-    got = ops().conv2d(g(x), g(wt), g(b), res=g(res), post_relu=True, **v3, **kw)
-    check(f"{name}_{tile}_res", got, E.conv2d(x, wt, b, res=res, post_relu=True, **kw), dtype)
-    v1 = ops().conv2d(g(x), g(wt), g(b), res=g(res), post_relu=True, kernel=1, **kw)
-    check(f"{name}_{tile}_v1", got, v1, dtype, 0.2)
-    dec, shf = rnd(tuple(want.shape), 214, dtype), rnd(tuple(want.shape), 215, dtype)
-    check(f"{name}_{tile}_sft", ops().conv2d(g(x), g(wt), g(b), sft=(g(dec), g(shf), 0.6), **v3, **kw),
-          E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)
-
 
 V4_SHAPES = [(n, a, b, c, d, e, f, 1, False) for (n, a, b, c, d, e, f) in V3_SHAPES] + [
     ("v4_1tile_k64", 1, 8, 8, 64, 64, 1, 1, False), ("v4_odd_ktiles", 1, 24, 40, 192, 320, 3, 1, False),
@@ -882,3 +855,18 @@ def test_linear_k256_streaming_kernel(dtype, case):
         if kern == 7:
             ref7 = got.clone()
     assert torch.equal(got.reshape(rows, cout), ref7.reshape(rows, cout)) or rows < 65536     # kernel 0 == kernel 7 from 65 536 rows
+
+
+@pytest.mark.parametrize("dtype", H16, ids=["bf16", "f16"])
+def test_weight_defect_behind_the_abi(dtype):
+    """pgt_weight_defect (the D operand of the mean-field compensation) against the host restatement: a 3x3 conv with a
+    BatchNorm-style output scale and padded input channels, a Linear, and the one-row-per-tap form."""
+    O = ops()
+    for (cout, cin, k, cp, scaled, sum_taps) in [(64, 57, 3, 64, True, True), (256, 256, 1, 256, False, True), (32, 192, 3, 192, False, False)]:
+        w = rnd((cout, cin, k, k), 90 + cout, torch.float32, 0.05) if k > 1 else rnd((cout, cin), 90 + cout, torch.float32, 0.05)
+        scale = (1 + 0.2 * rnd((cout,), 91)) if scaled else None
+        pw = E.pack_conv_weight(w, dtype, cin_pad=cp, scale=scale)
+        want = E.weight_defect(w, pw, scale=scale, sum_taps=sum_taps)
+        got = O.weight_defect(g(w), g(pw), scale=g(scale), sum_taps=sum_taps)
+        check(f"weight_defect_{cout}x{cin}x{k}", got, want, torch.float32, tol_scale=1e-3)
+        assert want.abs().max() > 0

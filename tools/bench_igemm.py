@@ -94,11 +94,6 @@ def main():
                     v2 += f" v2/{bn}s{nst}={t2:6.1f}"
         cells.append(v2)
         v3 = ""
-        if dt == torch.bfloat16 and cin % 64 == 0 and cout % 8 == 0 and stride == 1 and not ups:
-            for bm, bn, nst in ((256, 256, 2),):
-                t3 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, res=res, kernel=3, tile=(bm, bn), stages=nst), args.iters)
-                best = min(best, t3)
-                v3 += f" v3/{bm}x{bn}s{nst}={t3:6.1f}"
         if dt == torch.bfloat16 and cin % 64 == 0 and cout % 8 == 0:
             for bn in (256, 128):
                 t4 = timeit(lambda: ops.conv2d(x, wt, b, kh=k, kw=k, stride=stride, pad=pad, ups=bool(ups), res=res, kernel=4, tile=(0, bn)), args.iters)
