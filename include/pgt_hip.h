@@ -198,17 +198,28 @@ int pgt_adain_affine(const float* mean_c, const float* var_c, const float* mean_
  * bias_rows consecutive rows (a multiple of 256 that divides rows), the form pgt_mean_field_bias produces from
  * pgt_sampled_rownorm_mean.  Replaces norm1 + q / kv Linear (:298, :195-213).
  * pgt_attn_proj_mlp: x1 = attn Wproj^T + b_proj + shortcut (rounded to half);  y = x1 + fc2(GELU(fc1(LN2(x1)))) with
- * w3 = [Wproj; Wfc1 diag(gamma2); Wfc2] stacked (768, 256) K-major half rows, b_fc1 carrying W1 beta2 (pgt_fold_layernorm),
- * b_proj optionally per frame (b_proj_rows as bias_rows above, a multiple of 128).  Replaces proj + shortcut add (:230-232,
- * :329), norm2, Mlp (:126-132, mlp_ratio = 1: archs/tdcrqvae3_arch.py:499) and the residual add (:335-337).  GELU is the
- * exact-erf form (erf to 1.5e-7).  y may alias neither input. */
+ * w3 = [Wproj; Wfc1 diag(gamma2); Wfc2] stacked (768, 256) K-major half rows, b_fc1 carrying W1 beta2 (pgt_fold_layernorm).
+ * bias_rows = 0: the three biases are 256-vectors; > 0: each is a (rows / bias_rows, 256) matrix - one vector per bias_rows
+ * consecutive rows (a multiple of 128 that divides rows: a frame), the form pgt_mean_field_bias produces.  Replaces proj +
+ * shortcut add (:230-232, :329), norm2, Mlp (:126-132, mlp_ratio = 1: archs/tdcrqvae3_arch.py:499) and the residual add
+ * (:335-337).  GELU is the exact-erf form (erf to 1.5e-7).  y may alias neither input.
+ * pgt_attn_proj_mlp_sample: the operands of fc1 and fc2 never reach HBM in that launch, so the per-frame channel means their
+ * weight-rounding compensation needs (pgt_mean_field_bias) are taken by running the chain up to the hidden row on the fixed
+ * pixel sample of every frame (pgt_sampled_pixel; frames of HW rows): mean_ln[f][c] = mean of half(xhat) (fc1's operand),
+ * mean_hid[f][c] = mean of half(GELU(fc1(xhat) + b_fc1)) (fc2's operand; fc1 with its plain bias), both (frames, 256) fp32.
+ * b_proj: 256 values, or (frames, 256) with b_proj_per_frame.  workspace: pgt_attn_proj_mlp_sample_workspace_bytes bytes. */
 int pgt_fold_layernorm(const float* w, const float* gamma, const float* beta, const float* bias, int32_t Cout, int32_t Cin,
                        float* w_out, float* bias_out, pgt_stream_t stream);
 int pgt_ln_linear(int32_t dtype, const void* x, int32_t ldx, int32_t rows, int32_t Cin, float eps, const void* w,
                   const float* bias, int32_t bias_rows, int32_t Cout, void* y, int32_t ldy, pgt_stream_t stream);
 int pgt_attn_proj_mlp(int32_t dtype, const void* attn, int32_t lda, const void* shortcut, int32_t lds, int32_t rows, int32_t C,
-                      const void* w3, const float* b_proj, int32_t b_proj_rows, const float* b_fc1, const float* b_fc2,
+                      const void* w3, const float* b_proj, const float* b_fc1, const float* b_fc2, int32_t bias_rows,
                       float eps, void* y, int32_t ldy, pgt_stream_t stream);
+size_t pgt_attn_proj_mlp_sample_workspace_bytes(int32_t frames, int32_t HW);
+int pgt_attn_proj_mlp_sample(int32_t dtype, const void* attn, int32_t lda, const void* shortcut, int32_t lds, int32_t frames,
+                             int32_t HW, int32_t C, const void* w3, const float* b_proj, int32_t b_proj_per_frame,
+                             const float* b_fc1, float eps, void* workspace, float* mean_ln, float* mean_hid,
+                             pgt_stream_t stream);
 
 /* Split-half (PGT_F16X3) forms of the chains, for the encoder-side blocks: x / y split rows (lo planes x_lo / y_lo elements
  * after the hi planes), every product x_lo w_hi + x_hi w_lo + x_hi w_hi on the f16 MFMA, fp32 statistics; w in the

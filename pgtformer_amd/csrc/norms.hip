@@ -1,6 +1,7 @@
 // Normalisation kernels (K6, K7, K11 of SURVEY.md §2.3): HBM-bound, 16-byte vector accesses,
 // every thread keeps a fixed channel chunk so per-channel coefficients live in registers.
 #include "common.h"
+#include "pgt_sample.h"
 #include "pgt_internal.h"
 
 namespace {
@@ -455,20 +456,6 @@ __global__ __launch_bounds__(kStatSlots * 64) void channel_stats_kernel(const T*
 // (W - W16)[o][k][tap].  mean_n is taken over a fixed sample of <= 1024 pixels of the frame (an estimate good to 1-2 % of a
 // term that is itself 2^-12 of the output): kSampleRun consecutive pixels from each of up to kSampleCells equal cells.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSampleRun = 16, kSampleCells = 64;
-__host__ __device__ inline void mean_sample_geometry(int HW, int* run, int* cells, int* cell) {
-    *run = HW < kSampleRun ? HW : kSampleRun;
-    int r = HW / *run;
-    *cells = r < kSampleCells ? r : kSampleCells;
-    *cell = HW / *cells;
-}
-// i-th sampled pixel: pixel i % run of the run of cell i / run, which starts at a hashed offset inside the cell (so that the
-// runs do not line up in columns of the image)
-__host__ __device__ inline int mean_sample_pixel(int i, int cell, int run) {
-    const int j = i / run;
-    return j * cell + (int)(((unsigned)j * 40503u) % (unsigned)(cell - run + 1)) + i % run;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void sampled_mean_kernel(const T* __restrict__ x, int ldx, int HW, int C, float* __restrict__ mean) {
     __shared__ float sm[32][64 + 1];

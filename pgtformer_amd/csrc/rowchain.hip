@@ -35,6 +35,7 @@
 #include "common.h"
 #include "pgt_internal.h"
 #include "igemm_common.h"
+#include "pgt_sample.h"
 
 // Probe hooks (tools/rowchain_probe.py compiles this file with -DRC_PROBE=<bits>; the library build has none):
 //   1 no MFMAs   2 no A-fragment reads   4 no weight DMA   8 GELU -> identity   16 no normalisation   32 no output stores
@@ -79,6 +80,8 @@ struct RowChainP {
     int ldx, ldr, ldy;    // row strides in elements
     int M, ncol, b0_rows;
     float eps;
+    int HW;               // chain 3 (sampled pass): rows per frame; M = frames * HW
+    float* stats;         // chain 3: partial column sums [frame][128-row sample tile][wave][2][256]
 };
 
 constexpr int kRcNS = 4;                        // ring slots
@@ -137,6 +140,8 @@ __device__ __forceinline__ void rc_normalize(uint4 (&b)[8], float eps) {
 template <int MODE, int RT, int NW>
 __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntiles) {
     static_assert(MODE == 0 || RT == 1, "the three-GEMM chain keeps one row tile per wave");
+    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "chain 0: LN -> Linear; 1: proj -> Mlp; 3: chain 1 on the sampled rows, statistics only");
+    constexpr bool CHAIN = MODE != 0;
     static_assert(NW == 4 || NW == 8 || NW == 16, "16 DMA pieces per chunk are dealt to 4, 8 or 16 waves");
     constexpr int kRcWaves = NW;
     constexpr int kRcPPC = 16 / NW;                     // DMA pieces (1 KiB) per wave and chunk
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
 #if RC_PROBE & 256
     const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_readcyclecounter();
 #endif
-    const int NQ = MODE == 0 ? p.ncol / 32 : 24;        // chunks per tile
+    const int NQ = MODE == 0 ? p.ncol / 32 : MODE == 1 ? 24 : 16;        // chunks per tile (sampled pass: proj and fc1 only)
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total = my_tiles * NQ;                    // chunks this workgroup consumes
     const unsigned lds0 = lds_addr(smem);
@@ -176,17 +181,14 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
     };
     for (int i = 0; i < kRcNS - 1 && i < total && !(RC_PROBE & 4); ++i) issue();
 
-    // ---- static operands into LDS (visible after the first chunk barrier)
-    if (MODE == 1) {
-        for (int i = tid; i < 512; i += 64 * kRcWaves) {
-            const float v = i < 256 ? p.b1[i] : p.b2[i - 256];
-            bias_l[256 + i] = v;
-            bias_l[kRcMaxCol + 256 + i] = v;
-        }
-    }
-    const int nb0 = MODE == 0 ? p.ncol : 256;
+    // ---- static operands into LDS (visible after the first chunk barrier).  Chain 1: [b_proj | b_fc1 | b_fc2], all three one
+    //      vector per frame when b0_rows > 0; the sampled pass: b_proj per frame when b0_rows > 0, b_fc1 always a vector
+    const int nb0 = MODE == 0 ? p.ncol : MODE == 1 ? 768 : 256;
+    if (MODE == 3)
+        for (int i = tid; i < 256; i += 64 * kRcWaves) bias_l[256 + i] = bias_l[kRcMaxCol + 256 + i] = p.b1[i];
     if (p.b0_rows == 0)
-        for (int i = tid; i < nb0; i += 64 * kRcWaves) bias_l[i] = p.b0 ? p.b0[i] : 0.f;
+        for (int i = tid; i < nb0; i += 64 * kRcWaves)
+            bias_l[i] = !CHAIN ? (p.b0 ? p.b0[i] : 0.f) : i < 256 ? p.b0[i] : i < 512 ? p.b1[i - 256] : p.b2[i - 512];
     int cur_frame = -1, cur_buf = 0;
 
     // A fragment of (16-column tile t, k-step ks) of a slot: lane (g, m = n) reads chunk row 8 (m >> 2) + 4 t + (m & 3), 16-byte
@@ -266,18 +268,26 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
         for (int ks = 0; ks < 8; ++ks) dst[ks] = (RC_PROBE & 64) ? make_uint4(0x3c003800u + lane, 0x38003c00u, tile, ks) : xp[4 * ks];
     };
 
-    uint4 nb[MODE == 1 ? 8 : 1], nsc[MODE == 1 ? 8 : 1];      // chain 1: the next tile's rows, requested during this tile's last GEMM
+    uint4 nb[MODE != 0 ? 8 : 1], nsc[MODE != 0 ? 8 : 1];      // chain 1: the next tile's rows, requested during this tile's last GEMM
     uint4 nb0r[MODE == 0 ? RT : 1][8];                         // chain 0: the same, requested kRcNS - 1 chunks before the tile ends
     bool have_next = false;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = (long)tile * TR;
-        // ---- per-frame bias of the first GEMM: refreshed into the other LDS buffer when the tile enters a new frame
+        // ---- per-frame biases: refreshed into the other LDS buffer when the tile enters a new frame
+        int s_run = 1, s_cells = 1, s_cell = 1, tpf = 1;           // sampled pass: sample geometry, 128-row sample tiles per frame
+        if (MODE == 3) {
+            mean_sample_geometry(p.HW, &s_run, &s_cells, &s_cell);
+            tpf = (s_cells * s_run + TR - 1) / TR;
+        }
         if (p.b0_rows > 0) {
-            const int frame = (int)(row0 / p.b0_rows);
+            const int frame = MODE == 3 ? tile / tpf : (int)(row0 / p.b0_rows);
             if (frame != cur_frame) {
                 cur_frame = frame;
                 cur_buf ^= 1;
-                for (int i = tid; i < nb0; i += 64 * kRcWaves) bias_l[cur_buf * kRcMaxCol + i] = p.b0[(long)frame * nb0 + i];
+                for (int i = tid; i < nb0; i += 64 * kRcWaves) {
+                    const float* src = !CHAIN ? p.b0 + (long)frame * nb0 : i < 256 ? p.b0 + (long)frame * 256 : i < 512 ? p.b1 + (long)frame * 256 - 256 : p.b2 + (long)frame * 256 - 512;
+                    bias_l[cur_buf * kRcMaxCol + i] = src[i];
+                }
             }
         }
         const float* bl = bias_l + cur_buf * kRcMaxCol;
@@ -286,6 +296,32 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
         uint4 b[RT][8];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) rows[rt] = row0 + (wave * RT + rt) * 16 + n;
+        bool valid = true;                              // sampled pass: this lane's row is one of the frame's sample
+        if (MODE == 3) {
+            const int f = tile / tpf, i = (tile - f * tpf) * TR + wave * 16 + n, S = s_cells * s_run;
+            valid = i < S;
+            rows[0] = (long)f * p.HW + mean_sample_pixel(valid ? i : S - 1, s_cell, s_run);
+        }
+        // sampled pass: column sums of this wave's (valid) rows, into stats[tile][wave][which][256]
+        auto column_sums = [&](const uint4 (&t8)[8], int which) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float v[8];
+                Vec16<half_t>::unpack(t8[ks], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = valid ? v[e] : 0.f;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) x += __shfl_xor(x, o, 64);
+                    v[e] = x;
+                }
+                if (n == 0) {
+                    float* dst = p.stats + (((long)tile * kRcWaves + wave) * 2 + which) * 256 + 32 * ks + 8 * g;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+        };
         if constexpr (MODE == 0) {
             if (have_next) {
 #pragma unroll
@@ -390,9 +426,14 @@ __global__ __launch_bounds__(64 * NW) void rowchain_kernel(RowChainP p, int ntil
 #pragma unroll
             for (int q = 0; q < 8; ++q) b[0][q] = x1[0][q];
             if (!(RC_PROBE & 16)) rc_normalize(b[0], p.eps);
+            if (MODE == 3) column_sums(b[0], 0);
             gemm(b, epi1);
+            if (MODE == 3) {
+                column_sums(hid[0], 1);
+                continue;
+            }
             // ---- the next tile's rows are requested here: they have the whole last GEMM to arrive
-            have_next = RC_PREFETCH && tile + (int)gridDim.x < ntiles;
+            have_next = RC_PREFETCH && MODE == 1 && tile + (int)gridDim.x < ntiles;
             if (have_next) {
                 const long nrow = (long)(tile + gridDim.x) * TR + wave * 16 + n;
                 load_rows(nb, p.x, p.ldx, nrow, tile);
@@ -614,9 +655,9 @@ __global__ __launch_bounds__(512) void rowchain_x3_kernel(RowChainP p, int ntile
 
 int rc_cus();
 
-template <int MODE, int RT, int NW> int rc_launch(const RowChainP& p, hipStream_t st) {
+template <int MODE, int RT, int NW> int rc_launch(const RowChainP& p, hipStream_t st, int ntiles_override = 0) {
     constexpr int TR = NW * 16 * RT;
-    const int ntiles = (p.M + TR - 1) / TR;
+    const int ntiles = ntiles_override ? ntiles_override : (p.M + TR - 1) / TR;
     static std::atomic<unsigned long long> attr_set{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -765,20 +806,67 @@ extern "C" int pgt_ln_mlp_x3(const void* x, int32_t ldx, int32_t x_lo, int32_t r
     return rc_launch_x3<2, 1>(p, x_lo, y_lo, (hipStream_t)stream);
 }
 
+namespace {
+// mean[which][f][c] = (sum over the frame's sample tiles and their 8 waves, in that order) / S   (the sampled pass's partial sums)
+__global__ __launch_bounds__(512) void sample_partial_mean_kernel(const float* __restrict__ stats, int tpf, int frames, int S,
+                                                                  float* __restrict__ mean_ln, float* __restrict__ mean_hid) {
+    const int f = blockIdx.x, which = threadIdx.x >> 8, c = threadIdx.x & 255;
+    float t = 0.f;
+    for (int k = 0; k < tpf * 8; ++k) t += stats[(((long)f * tpf * 8 + k) * 2 + which) * 256 + c];
+    (which ? mean_hid : mean_ln)[(long)f * 256 + c] = t / (float)S;
+}
+}  // namespace
+
+// The sampled pass of pgt_attn_proj_mlp, for the weight-rounding compensation of fc1 / fc2: the inputs of
+// those two layers never reach HBM in the fused launch, so their per-frame channel means are taken here, by running the chain
+// up to the hidden row on the library's pixel sample of every frame (pgt_sampled_pixel: <= 1024 rows of each HW-row frame).
+//   mean_ln [f][c]  = mean over the sample of half(xhat)        (the operand of fc1: the normalised x1, x1 = proj + shortcut)
+//   mean_hid[f][c]  = mean over the sample of half(GELU(fc1))   (the operand of fc2; fc1 with the PLAIN bias b_fc1)
+// b_proj: (256) or, with b_proj_per_frame, (frames, 256).  workspace: pgt_attn_proj_mlp_sample_workspace_bytes(frames, HW).
+extern "C" size_t pgt_attn_proj_mlp_sample_workspace_bytes(int32_t frames, int32_t HW) {
+    int run, cells, cell;
+    if (frames < 1 || HW < 1) return 0;
+    mean_sample_geometry(HW, &run, &cells, &cell);
+    return (size_t)frames * ((cells * run + 127) / 128) * 8 * 2 * 256 * sizeof(float);
+}
+
+extern "C" int pgt_attn_proj_mlp_sample(int32_t dtype, const void* attn, int32_t lda, const void* shortcut, int32_t lds, int32_t frames,
+                                        int32_t HW, int32_t C, const void* w3, const float* b_proj, int32_t b_proj_per_frame,
+                                        const float* b_fc1, float eps, void* workspace, float* mean_ln, float* mean_hid,
+                                        pgt_stream_t stream) {
+    PGT_CHECK(dtype == PGT_F16 && C == 256, "attn_proj_mlp_sample: PGT_F16, C = 256 (dtype %d, C %d)", dtype, C);
+    PGT_CHECK(attn && shortcut && w3 && b_proj && b_fc1 && workspace && mean_ln && mean_hid && frames >= 1 && HW >= 1, "attn_proj_mlp_sample: null argument");
+    PGT_CHECK(lda % 8 == 0 && lds % 8 == 0 && lda >= C && lds >= C && (((uintptr_t)attn | (uintptr_t)shortcut | (uintptr_t)w3 | (uintptr_t)workspace) & 15) == 0,
+              "attn_proj_mlp_sample: misaligned argument");
+    int run, cells, cell;
+    mean_sample_geometry(HW, &run, &cells, &cell);
+    const int S = cells * run, tpf = (S + 127) / 128;
+    RowChainP p{};
+    p.x = (const char*)attn; p.res = (const char*)shortcut; p.w = (const char*)w3;
+    p.b0 = b_proj; p.b0_rows = b_proj_per_frame ? 1 : 0; p.b1 = b_fc1; p.eps = eps;
+    p.ldx = lda; p.ldr = lds; p.M = (int)((long)frames * HW); p.ncol = 512; p.HW = HW; p.stats = (float*)workspace;
+    PGT_CHECK((long)frames * HW < (1L << 31), "attn_proj_mlp_sample: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = rc_launch<3, 1, 8>(p, st, frames * tpf)) return rc;
+    hipLaunchKernelGGL(sample_partial_mean_kernel, dim3(frames), dim3(512), 0, st, (const float*)workspace, tpf, frames, S, mean_ln, mean_hid);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
 // The tail of a window-attention block in one launch: x1 = attn Wproj^T + b_proj + shortcut; y = x1 + fc2(GELU(fc1(LN2(x1))))
 // (modules/rstt_layers.py:230-232 proj, :329 shortcut add, :335-337 norm2 + Mlp + residual; Mlp :126-132 with mlp_ratio = 1,
 // archs/tdcrqvae3_arch.py:499).  w3 = the three (256, 256) weights stacked [Wproj; Wfc1'; Wfc2], K-major half rows, Wfc1' / b_fc1
 // carrying norm2's gamma / beta (pgt_fold_layernorm).
 extern "C" int pgt_attn_proj_mlp(int32_t dtype, const void* attn, int32_t lda, const void* shortcut, int32_t lds, int32_t rows,
-                                 int32_t C, const void* w3, const float* b_proj, int32_t b_proj_rows, const float* b_fc1,
-                                 const float* b_fc2, float eps, void* y, int32_t ldy, pgt_stream_t stream) {
+                                 int32_t C, const void* w3, const float* b_proj, const float* b_fc1, const float* b_fc2,
+                                 int32_t bias_rows, float eps, void* y, int32_t ldy, pgt_stream_t stream) {
     PGT_CHECK(dtype == PGT_F16, "attn_proj_mlp: dtype %d (PGT_F16 only)", dtype);
     PGT_CHECK(C == 256, "attn_proj_mlp: C=%d (256)", C);
     PGT_CHECK(shortcut && b_fc1 && b_fc2 && lds % 8 == 0 && ((uintptr_t)shortcut & 15) == 0 && lds >= C && lda >= C && ldy >= C,
               "attn_proj_mlp: null / misaligned argument");
     RowChainP p{};
     p.x = (const char*)attn; p.res = (const char*)shortcut; p.y = (char*)y; p.w = (const char*)w3;
-    p.b0 = b_proj; p.b0_rows = b_proj_rows; p.b1 = b_fc1; p.b2 = b_fc2; p.eps = eps;
+    p.b0 = b_proj; p.b0_rows = bias_rows; p.b1 = b_fc1; p.b2 = b_fc2; p.eps = eps;
     p.ldx = lda; p.ldr = lds; p.ldy = ldy; p.M = rows; p.ncol = 768;
     const char* e = getenv("PGT_RC_MLP");              // w8 | w4 pins the variant (tuning)
     const bool w4 = e && !strcmp(e, "w4");

@@ -25,6 +25,7 @@ USE_X3_C64 = os.environ.get("PGT_X3_C64", "1") != "0"     # A/B switch of the re
 
 USE_WCOMP = os.environ.get("PGT_WCOMP", "1") != "0"       # A/B switch of the mean-field weight-rounding compensation
 USE_WCOMP_LINEAR = os.environ.get("PGT_WCOMP_LINEAR", "1") != "0"   # ... of the token-row linears (window-attention blocks)
+USE_WCOMP_MLP = os.environ.get("PGT_WCOMP_MLP", "1") != "0"         # ... of fc1 / fc2 only (layer-by-layer path; the fused chains cannot)
 USE_ROWCHAIN = os.environ.get("PGT_ROWCHAIN", "1") != "0"           # A/B switch of the fused token-row chains (rowchain.hip)
 USE_ROWCHAIN_X3 = os.environ.get("PGT_ROWCHAIN_X3", "1") != "0"     # ... of their split-half forms (encoder-side blocks)
 
@@ -291,7 +292,12 @@ class VSTSREncoderTransformerBlock(HipModule):
             self.f_w3 = torch.cat([_pack_matrix(f32(a.proj.weight), device, dtype), _pack_matrix(w1, device, dtype),
                                    _pack_matrix(f32(m.fc2.weight), device, dtype)], 0).contiguous()
             self.f_bp = f32(a.proj.bias)
-            self.f_dproj = _defect_t(a.proj.weight, self.f_w3[:self.dim]) if _wants_wcomp(dtype) else None
+            self.f_dproj = self.f_dfc1 = self.f_dfc2 = None
+            if _wants_wcomp(dtype):
+                d = self.dim
+                self.f_dproj = _defect_t(a.proj.weight, self.f_w3[:d])
+                self.f_dfc1 = _defect_t(w1, self.f_w3[d:2 * d])
+                self.f_dfc2 = _defect_t(m.fc2.weight, self.f_w3[2 * d:])
             self.fused = True
         elif _is_x3(dtype) and USE_ROWCHAIN_X3:
             # split blocks (encoder side): LN1 -> q|k|v and LN2 -> Mlp -> residual fused; proj + shortcut stays a linear launch
@@ -321,14 +327,20 @@ class VSTSREncoderTransformerBlock(HipModule):
                 bq = ops.mean_field_bias(ops.sampled_rownorm_mean(x3d, self.norm1.eps), self.f_dqkv, self.f_bqkv)
             qkv = ops.ln_linear(xt, self.f_wqkv, bq, self.norm1.eps)
             ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift)
-            return ops.attn_proj_mlp(ao, xt, self.f_w3, _frame_bias(ao, self.f_dproj, self.f_bp, nf), self.f_b1, self.f_b2,
-                                     self.norm2.eps, out=out)
+            bp, b1, b2 = _frame_bias(ao, self.f_dproj, self.f_bp, nf), self.f_b1, self.f_b2
+            if bp.dim() == 2:
+                # fc1 / fc2 read rows that never reach HBM: the per-frame means of their operands come from a sampled pass of
+                # the same chain (ops.attn_proj_mlp_sample, <= 1024 rows per frame)
+                m_ln, m_hid = ops.attn_proj_mlp_sample(ao, xt, self.f_w3, bp, self.f_b1, nf, self.norm2.eps)
+                b1, b2 = ops.mean_field_bias(m_ln, self.f_dfc1, self.f_b1), ops.mean_field_bias(m_hid, self.f_dfc2, self.f_b2)
+            return ops.attn_proj_mlp(ao, xt, self.f_w3, bp, b1, b2, self.norm2.eps, out=out)
         ln = self.norm1.run(xt)
         qkv = ops.linear(ln, self.attn.w_qkv, _frame_bias(ln, self.attn.d_qkv, self.attn.b_qkv, nf), x3=x3)
         ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift, x3=x3)
         x1 = self.attn.proj.run(ao, frames=nf, res=xt)
-        m = self.mlp.fc1.run(self.norm2.run(x1), frames=nf, act=ACT_GELU)
-        return self.mlp.fc2.run(m, frames=nf, res=x1, out=out, gn=None if gn_images is None else (32, gn_images))
+        nfm = nf if USE_WCOMP_MLP else None
+        m = self.mlp.fc1.run(self.norm2.run(x1), frames=nfm, act=ACT_GELU)
+        return self.mlp.fc2.run(m, frames=nfm, res=x1, out=out, gn=None if gn_images is None else (32, gn_images))
 
 
 class EncoderLayer(HipModule):

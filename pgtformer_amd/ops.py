@@ -681,7 +681,8 @@ def ln_mlp(x, w2, b_fc1, b_fc2, eps=1e-5, out=None, x3=True):
 
 def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
     """The tail of a window-attention block in one launch: x1 = ao @ Wproj.T + b_proj + shortcut; y = x1 + fc2(GELU(fc1(LN(x1)))).
-    w3 = [Wproj; Wfc1 diag(gamma2); Wfc2] (768, 256) packed half; b_proj (256,) or per frame (frames, 256)."""
+    w3 = [Wproj; Wfc1 diag(gamma2); Wfc2] (768, 256) packed half; the three biases are (256,) vectors, or all three per frame
+    (frames, 256) - the compensated form (mean_field_bias)."""
     rows, c = ao.shape
     assert ao.dtype == torch.float16 and shortcut.dtype == torch.float16 and tuple(shortcut.shape) == (rows, c)
     assert w3.dtype == torch.float16 and tuple(w3.shape) == (3 * c, c) and w3.is_contiguous()
@@ -689,15 +690,17 @@ def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
         out = torch.empty((rows, c), device=ao.device, dtype=ao.dtype)
     assert out.data_ptr() != ao.data_ptr() and out.data_ptr() != shortcut.data_ptr()
     brows = 0
-    if b_proj is not None and b_proj.dim() == 2:
-        assert b_proj.shape[1] == c and b_proj.is_contiguous() and rows % b_proj.shape[0] == 0
+    if b_proj.dim() == 2:
+        assert all(b.dim() == 2 and b.shape == b_proj.shape and b.is_contiguous() for b in (b_proj, b_fc1, b_fc2)) and rows % b_proj.shape[0] == 0
         brows = rows // b_proj.shape[0]
+    else:
+        assert b_fc1.dim() == 1 and b_fc2.dim() == 1
     prof = PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     hip.check(hip.lib().pgt_attn_proj_mlp(_dt(ao), _p(ao), _ld_rows(ao), _p(shortcut), _ld_rows(shortcut), rows, c, _p(w3),
-                                          _p(b_proj), brows, _p(b_fc1), _p(b_fc2), float(eps), _p(out), _ld_rows(out), _stream()),
+                                          _p(b_proj), _p(b_fc1), _p(b_fc2), brows, float(eps), _p(out), _ld_rows(out), _stream()),
               "pgt_attn_proj_mlp")
     if prof is not None:
         e1.record()
@@ -705,6 +708,23 @@ def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
                      "shape": (1, 1, rows, c, 3 * c, 1, 1, 0), "events": (e0, e1), "cfg": ("proj_mlp", 0, 0), "x3": False,
                      "dt": "float16", "chain": "proj_mlp"})
     return out
+
+
+def attn_proj_mlp_sample(ao, shortcut, w3, b_proj, b_fc1, frames, eps=1e-5):
+    """The sampled pass of attn_proj_mlp (pgt_attn_proj_mlp_sample): per frame, the channel means of fc1's operand (the normalised
+    x1) and of fc2's operand (the GELU'd hidden row) over the library's pixel sample -> (mean_ln, mean_hid), fp32 (frames, 256).
+    ao / shortcut: (frames * HW, 256) rows; b_proj (256,) or (frames, 256)."""
+    rows, c = ao.shape
+    hw = rows // frames
+    assert rows == frames * hw and ao.dtype == torch.float16 and shortcut.dtype == torch.float16
+    L = hip.lib()
+    ws = torch.empty(L.pgt_attn_proj_mlp_sample_workspace_bytes(frames, hw) // 4, dtype=torch.float32, device=ao.device)
+    means = torch.empty((2, frames, c), dtype=torch.float32, device=ao.device)
+    with _Prof("mean_field", 4.0 * frames * min(hw, 1024) * c * c, float(2 * frames * min(hw, 1024) * c * 2 + w3.numel() * 2)):
+        hip.check(L.pgt_attn_proj_mlp_sample(_dt(ao), _p(ao), _ld_rows(ao), _p(shortcut), _ld_rows(shortcut), frames, hw, c, _p(w3),
+                                             _p(b_proj), int(b_proj.dim() == 2), _p(b_fc1), float(eps), _p(ws), _p(means[0]), _p(means[1]),
+                                             _stream()), "pgt_attn_proj_mlp_sample")
+    return means[0], means[1]
 
 
 def weight_defect(w, packed, scale=None, sum_taps=True):

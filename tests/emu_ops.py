@@ -299,6 +299,18 @@ def attn_proj_mlp(ao, shortcut, w3, b_proj, b_fc1, b_fc2, eps=1e-5, out=None):
     return linear(h, w3[2 * c:], b_fc2, res=x1, out=out)
 
 
+def attn_proj_mlp_sample(ao, shortcut, w3, b_proj, b_fc1, frames, eps=1e-5):
+    rows, c = ao.shape
+    hw = rows // frames
+    idx = sampled_pixels(hw)
+    a3, s3 = ao.reshape(frames, hw, c)[:, idx, :], shortcut.reshape(frames, hw, c)[:, idx, :]
+    ns = len(idx)
+    x1 = linear(a3.reshape(-1, c), w3[:c], b_proj, res=s3.reshape(-1, c))
+    xh = _rownorm(x1, eps)
+    h = linear(xh, w3[c:2 * c], b_fc1, act=ACT_GELU)
+    return xh.float().reshape(frames, ns, c).mean(1), h.float().reshape(frames, ns, c).mean(1)
+
+
 def weight_defect(w, packed, scale=None, sum_taps=True):
     w32 = w.float()
     cout, cin = w32.shape[0], w32.shape[1]
@@ -549,7 +561,7 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "sample_rows", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
        "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update", "sampled_channel_mean", "mean_field_bias",
-       "sampled_rownorm_mean", "weight_defect", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp"]
+       "sampled_rownorm_mean", "weight_defect", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp", "attn_proj_mlp_sample"]
 
 
 def install(monkeypatch):

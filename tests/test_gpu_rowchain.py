@@ -124,8 +124,8 @@ def test_attn_proj_mlp(case):
     w3 = rnd((3 * c, c), 43, H, 0.06)
     w3[:, 0] += (torch.arange(3 * c, dtype=torch.float32) * 0.001).to(H)
     w3[0, :] += (torch.arange(c, dtype=torch.float32) * 0.001).to(H)
-    bp = rnd((frames, c), 44) if frames else rnd((c,), 44)
-    b1, b2 = rnd((c,), 45), rnd((c,), 46)
+    bp = rnd((frames, c), 44) if frames else rnd((c,), 44)          # the three biases: vectors, or all three per frame
+    b1, b2 = (rnd((frames, c), 45), rnd((frames, c), 46)) if frames else (rnd((c,), 45), rnd((c,), 46))
     want = E.attn_proj_mlp(ao, sc, w3, bp, b1, b2)
     scg = scw.to(DEV)[:, c:] if case == "views_frames" else sc.to(DEV)
     out = None
@@ -146,6 +146,25 @@ def test_attn_proj_mlp(case):
     # bit-reproducible
     again = ops.attn_proj_mlp(ao.to(DEV), scg, w3g, bp.to(DEV), b1.to(DEV), b2.to(DEV))
     assert torch.equal(again, got if out is None else out)
+
+
+@pytest.mark.parametrize("case", ["hw4096_frames", "hw16384", "hw200"])
+def test_attn_proj_mlp_sample(case):
+    """The sampled pass of the fused block tail: per-frame channel means of fc1's operand (normalised x1) and fc2's operand
+    (GELU'd hidden row) over the library's pixel sample, against the emulation of the same chain on the same sample."""
+    ops = O()
+    frames, hw, per_frame = {"hw4096_frames": (5, 4096, True), "hw16384": (2, 16384, False), "hw200": (3, 200, False)}[case]
+    c, rows = 256, frames * hw
+    ao, sc = rnd((rows, c), 81, H), rnd((rows, c), 82, H)
+    w3 = rnd((3 * c, c), 83, H, 0.06)
+    bp = rnd((frames, c), 84) if per_frame else rnd((c,), 84)
+    b1 = rnd((c,), 85)
+    want_ln, want_hid = E.attn_proj_mlp_sample(ao, sc, w3, bp, b1, frames)
+    got_ln, got_hid = ops.attn_proj_mlp_sample(ao.to(DEV), sc.to(DEV), w3.to(DEV), bp.to(DEV), b1.to(DEV), frames)
+    check(f"sample_mean_ln_{case}", got_ln, want_ln, 1e-3)          # means of half-rounded values: a few half ulps / sqrt(rows)
+    check(f"sample_mean_hid_{case}", got_hid, want_hid, 1e-3)
+    again = ops.attn_proj_mlp_sample(ao.to(DEV), sc.to(DEV), w3.to(DEV), bp.to(DEV), b1.to(DEV), frames)
+    assert torch.equal(again[0], got_ln) and torch.equal(again[1], got_hid)
 
 
 def test_block_fused_equals_layer_by_layer():
