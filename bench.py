@@ -412,17 +412,21 @@ def main():
                                           "(configs[1]: u8 on host; H2D / D2H double-buffered inside the timed region) is "
                                           "value_from_pinned_host",
                       "parallelism": f"frame-range shard x{world}, 1 all_gather of boundary frames"}}
-    if world > 1:
+    if world > 1 and os.environ.get("PGT_BENCH_CONFIGS2", "1") != "0":
         # BASELINE.json configs[2] as named, in the same run (so that a multi-GPU scaling run records it without extra flags):
-        # ONE 256-frame clip sharded by output-frame range, halo all_gather, restored frames gathered to rank 0
+        # ONE 256-frame clip sharded by output-frame range, halo all_gather, restored frames gathered to rank 0.  The headline
+        # fields above are already final; a failure of this extra pass is recorded, not raised.
         import copy
         a2 = copy.copy(args)
         a2.clip_frames, a2.steps, a2.warmup = 256, 2, 1
         del runner
         torch.cuda.empty_cache()
-        c2 = clip_mode(a2, model, dev, rank, world)
-        res["configs2_clip256"] = {"value": c2["value"], "unit": c2["unit"], "ms_per_pass": c2["ms_per_step"], "scaling": "strong",
-                                   "workload": c2["config"]["workload"]}
+        try:
+            c2 = clip_mode(a2, model, dev, rank, world)
+            res["configs2_clip256"] = {"value": c2["value"], "unit": c2["unit"], "ms_per_pass": c2["ms_per_step"], "scaling": "strong",
+                                       "workload": c2["config"]["workload"]}
+        except Exception as e:      # noqa: BLE001
+            res["configs2_clip256"] = {"error": repr(e)[:300]}
     if host_rate is not None:
         res["value_from_pinned_host"] = host_rate      # same job with H2D / D2H of the uint8 frames inside the timed region
     if rank == 0:

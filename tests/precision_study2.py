@@ -9,6 +9,9 @@ group (512x512 level, 256->512 up-sampling, 256x256 level + fusion, the rest).
   groups        22-bit weights in one decoder level at a time / in all but one: whose weight rounding carries the systematic error
   compensation  half everywhere + the mean-field compensation of the weight rounding (what the product does: per-frame bias
                 (W - W16) mean(x) from the library's pixel sample), for the residual-block / fusion convs only and for every layer
+  products      TWO MFMA products instead of three in one sub-network of the code-prediction branch at a time (VERDICT round 3,
+                item 4): single-plane WEIGHTS (x_hi w_hi + x_lo w_hi) or single-plane ACTIVATIONS (x_hi w_hi + x_hi w_lo), the rest
+                of the branch on two half planes; logit error and flipped codes against the exact oracle
   planes        the code-prediction branch on two bf16 planes (the split type of rounds 2-3a) against two half planes (the product's): logit error
                 and flipped codes against the exact oracle
 Results: profiles/r3_psnr_sweep.md.
@@ -219,6 +222,45 @@ def run_planes(seed, i):
                   f"flipped codes {int((lg.argmax(-1) != ref.argmax(-1)).sum())}/{ref.argmax(-1).numel()}", flush=True)
 
 
+def run_products(seed, i):
+    """one sub-network of the code branch with a single-plane operand (two products instead of three), everything else split"""
+    lq_u8, _ = make_clip(i + 2, 512, seed=seed)
+    x = torch.from_numpy(window_from_clip(lq_u8, i).astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    oc, ol, og, oln = O._conv, O._lin, O._gn, O._ln
+
+    def run(part, qa_part, qw_part):
+        """layers of `part`: activation operand qa_part, weight operand qw_part; all other layers and all stored tensors: h2"""
+        def conv(sd_, p, xx, stride=1, padding=0):
+            qa, qw = (qa_part, qw_part) if part(p) else (q_h2, q_h2)
+            return q_h2(F.conv2d(qa(xx), qw(sd_[p + ".weight"]), sd_.get(p + ".bias"), stride=stride, padding=padding))
+        def lin(sd_, p, xx):
+            qa, qw = (qa_part, qw_part) if part(p) else (q_h2, q_h2)
+            return q_h2(F.linear(qa(xx), qw(sd_[p + ".weight"]), sd_.get(p + ".bias")))
+        O._conv, O._lin = conv, lin
+        O._gn = lambda sd_, p, xx, eps=1e-6: q_h2(og(sd_, p, xx, eps))
+        O._ln = lambda sd_, p, xx, eps=1e-5: q_h2(oln(sd_, p, xx, eps))
+        try:
+            return O.pgtformer_forward(sd, cfg, x, w=1.0, code_only=True)[0]
+        finally:
+            O._conv, O._lin, O._gn, O._ln = oc, ol, og, oln
+    ref = O.pgtformer_forward(sd, cfg, x, w=1.0, code_only=True)[0]
+    top2 = ref.topk(2, -1).values
+    gap = top2[..., 0] - top2[..., 1]
+    print(f"== clip {seed} window {i}: smallest top-2 logit gap of the exact oracle {float(gap.min()):.2e}, gaps < 1e-4: {int((gap < 1e-4).sum())}", flush=True)
+    parts = {"none (three products everywhere)": lambda p: False,
+             "BiSeNet + convpos": lambda p: p.startswith("conditionnet") or p.startswith("convpos"),
+             "encoder levels 0-1 (per-frame front)": lambda p: p.startswith("encoder.conv_in") or p.startswith("encoder.down.0") or p.startswith("encoder.down.1"),
+             "encoder (all)": lambda p: p.startswith("encoder") or p.startswith("quant_conv"),
+             "feat_emb + transformer + head": lambda p: p.startswith("feat_emb") or p.startswith("ft_layers") or p.startswith("idx_pred")}
+    for pname, part in parts.items():
+        for name, qa, qw in (("single-plane weights", q_h2, q_f16), ("single-plane activations", q_f16, q_h2)):
+            lg = run(part, qa, qw)
+            print(f"  {pname:40s} {name:26s} logits: max err {float((lg - ref).abs().max()):.2e}  rms {float((lg - ref).pow(2).mean().sqrt()):.2e}   "
+                  f"flipped codes {int((lg.argmax(-1) != ref.argmax(-1)).sum())}/{ref.argmax(-1).numel()}", flush=True)
+            if pname.startswith("none"):
+                break
+
+
 def report(name, out, c):
     ref, gt = c["ref"][1], c["gt"]
     e, r = (out - ref).double(), (ref - gt).double()
@@ -230,10 +272,10 @@ if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 and ":" not in sys.argv[1] else "levels"
     sys.argv = [a for a in sys.argv if a != mode]
     wins = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(1234, 1), (1077, 4), (2077, 1)]
-    if mode == "planes":
+    if mode in ("planes", "products"):
         torch.set_num_threads(8)
         for seed, i in wins:
-            run_planes(seed, i)
+            (run_planes if mode == "planes" else run_products)(seed, i)
         sys.exit(0)
     if mode in ("groups", "compensation"):
         torch.set_num_threads(8)
