@@ -176,9 +176,10 @@ int pgt_weight_defect(int32_t dtype, const float* w_oihw, int32_t Cout, int32_t 
                       const float* out_scale, const void* packed, int32_t sum_taps, float* defect_t, pgt_stream_t stream);
 /* The sampled mean for a layer that reads NORMALISED rows (pgt_ln_linear below): mean[n][c] over frame n's sample of
  * half((x[p][c] - mu_p) * rstd_p), mu_p / rstd_p = the LayerNorm statistics of row p over its C channels (C = 256 or 512;
- * PGT_F16 / PGT_BF16). */
+ * PGT_F16 / PGT_BF16).  workspace: pgt_sampled_rownorm_workspace_bytes bytes (partial sums of 128-row sample slices, summed in order). */
+size_t pgt_sampled_rownorm_workspace_bytes(int32_t N, int32_t HW, int32_t C);
 int pgt_sampled_rownorm_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C, float eps,
-                             float* mean, pgt_stream_t stream);
+                             float* mean, void* workspace, pgt_stream_t stream);
 /* AdaIN coefficients: scale = sqrt(var_s+eps)/sqrt(var_c+eps), shift = mean_s - mean_c*scale
  * (adaptive_instance_normalization, codeformer_arch.py:32-46); n = N*C entries */
 int pgt_adain_affine(const float* mean_c, const float* var_c, const float* mean_s, const float* var_s,

@@ -374,16 +374,26 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restric
     }
     const float total = __shfl(incl, 63, 64);
     const float target = u[row] * total;
-    const float excl = incl - mine;
+    // the exclusive sum is the PREVIOUS lane's inclusive sum, bit for bit (incl - mine would differ from it in the last place and
+    // could put the walk's running sum above the target before an entry with probability > 0 is reached)
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.f;
     // the owning lane: the first one whose inclusive sum exceeds the target (the last non-empty lane if rounding leaves none)
     const unsigned long long hit = __ballot(incl > target && j0 < K);
     const int owner = hit ? __ffsll((long long)hit) - 1 : min(63, (K - 1) / per);
     if (lane == owner) {
+        // torch.multinomial never returns a category of probability zero: only entries with pr[j] > 0 are accepted, and the
+        // fall-back (rounding left no entry above the target) is the last such entry of the row
         float c = excl;
-        int pick = j1 - 1;
+        int pick = -1;
         for (int j = j0; j < j1; ++j) {
             c += pr[j];
-            if (c > target) { pick = j; break; }
+            if (c > target && pr[j] > 0.f) { pick = j; break; }
+        }
+        if (pick < 0) {
+            for (int j = K - 1; j >= 0; --j)
+                if (pr[j] > 0.f) { pick = j; break; }
+            if (pick < 0) pick = j1 - 1;
         }
         codes[row] = pick;
     }

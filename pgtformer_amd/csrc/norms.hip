@@ -492,14 +492,16 @@ __global__ __launch_bounds__(256) void sampled_mean_kernel(const T* __restrict__
 
 // The same mean for a layer that reads the NORMALISED rows of x (pgt_ln_linear: the LayerNorm's affine part lives in its
 // weights): mean[n][c] over the frame's sample of half((x[p][c] - mu_p) * rstd_p), mu_p / rstd_p the LayerNorm statistics of
-// row p over its C channels.  One workgroup per frame, one wavefront per sampled row at a time, partial sums combined in
-// wave order (deterministic).
+// row p over its C channels.  Stage 1: a workgroup (4 waves) per (frame, slice of 128 sample rows), a wavefront per row, eight
+// rows' loads in flight at a time (one row per iteration is a chain of dependent HBM round trips); partial sums per slice.
+// Stage 2: the slices summed in order (deterministic).
+constexpr int kRnSlice = 128;
 template <typename T, int EPL>
-__global__ __launch_bounds__(1024) void sampled_rownorm_mean_kernel(const T* __restrict__ x, int ldx, int HW, int C, float eps,
-                                                                    float* __restrict__ mean) {
-    __shared__ float part[16][64 * EPL];
+__global__ __launch_bounds__(256) void sampled_rownorm_partial_kernel(const T* __restrict__ x, int ldx, int HW, int C, float eps,
+                                                                      float* __restrict__ part) {
+    __shared__ float red[4][64 * EPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x;
+    const int n = blockIdx.y, slice = blockIdx.x;
     int run, cells, cell;
     mean_sample_geometry(HW, &run, &cells, &cell);
     const int S = cells * run;
@@ -507,14 +509,12 @@ __global__ __launch_bounds__(1024) void sampled_rownorm_mean_kernel(const T* __r
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     const T* base = x + (long)n * HW * ldx + lane * EPL;
-    // rows wave, wave + 16, ...: eight at a time, all of their loads issued before the first reduction (one row per iteration
-    // is a chain of dependent HBM round trips: 82 us per launch, measured)
     constexpr int NB = 8;
-    for (int i0 = wave; i0 < S; i0 += 16 * NB) {
+    for (int i0 = slice * kRnSlice + wave; i0 < (slice + 1) * kRnSlice && i0 < S; i0 += 4 * NB) {
         float v[NB][EPL];
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int i = i0 + 16 * u;
+            const int i = i0 + 4 * u;
             RowIO<T, EPL, true>::ld(base + (long)mean_sample_pixel(i < S ? i : i0, cell, run) * ldx, v[u]);
         }
 #pragma unroll
@@ -527,7 +527,8 @@ __global__ __launch_bounds__(1024) void sampled_rownorm_mean_kernel(const T* __r
 #pragma unroll
             for (int e = 0; e < EPL; ++e) { v[u][e] -= mu; ss += v[u][e] * v[u][e]; }
             const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
-            if (i0 + 16 * u < S) {
+            const int i = i0 + 4 * u;
+            if (i < S && i < (slice + 1) * kRnSlice) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     T r;
@@ -538,13 +539,19 @@ __global__ __launch_bounds__(1024) void sampled_rownorm_mean_kernel(const T* __r
         }
     }
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) part[wave][lane * EPL + e] = acc[e];
+    for (int e = 0; e < EPL; ++e) red[wave][lane * EPL + e] = acc[e];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 1024) {
-        float tot = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tot += part[k][c];
-        mean[(long)n * C + c] = tot / (float)S;
+    for (int c = threadIdx.x; c < C; c += 256)
+        part[((long)n * gridDim.x + slice) * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+__global__ __launch_bounds__(256) void sampled_rownorm_finish_kernel(const float* __restrict__ part, int nslice, int C, int S,
+                                                                     float* __restrict__ mean) {
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int k = 0; k < nslice; ++k) t += part[((long)n * nslice + k) * C + c];
+        mean[(long)n * C + c] = t / (float)S;
     }
 }
 
@@ -795,16 +802,29 @@ extern "C" int pgt_sampled_channel_mean(int32_t dtype, const void* x, int32_t ld
     return 0;
 }
 
+extern "C" size_t pgt_sampled_rownorm_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
+    int run, cells, cell;
+    if (N < 1 || HW < 1 || C < 1) return 0;
+    mean_sample_geometry(HW, &run, &cells, &cell);
+    return (size_t)N * ((cells * run + kRnSlice - 1) / kRnSlice) * C * sizeof(float);
+}
+
 extern "C" int pgt_sampled_rownorm_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t C, float eps,
-                                        float* mean, pgt_stream_t stream) {
-    PGT_CHECK(x && mean && N >= 1 && HW >= 1, "sampled_rownorm_mean: null argument");
+                                        float* mean, void* workspace, pgt_stream_t stream) {
+    PGT_CHECK(x && mean && workspace && N >= 1 && HW >= 1, "sampled_rownorm_mean: null argument");
     PGT_CHECK((C == 256 || C == 512) && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "sampled_rownorm_mean: C=%d (256 or 512), ldx=%d (multiple of 8)", C, ldx);
+    int run, cells, cell;
+    mean_sample_geometry(HW, &run, &cells, &cell);
+    const int S = cells * run, nslice = (S + kRnSlice - 1) / kRnSlice;
     hipStream_t st = (hipStream_t)stream;
-#define SRM(T_, E_) hipLaunchKernelGGL((sampled_rownorm_mean_kernel<T_, E_>), dim3(N), dim3(1024), 0, st, (const T_*)x, ldx, HW, C, eps, mean)
+    float* part = (float*)workspace;
+#define SRM(T_, E_) hipLaunchKernelGGL((sampled_rownorm_partial_kernel<T_, E_>), dim3(nslice, N), dim3(256), 0, st, (const T_*)x, ldx, HW, C, eps, part)
     if (dtype == PGT_BF16) { if (C == 256) SRM(bf16_t, 4); else SRM(bf16_t, 8); }
     else if (dtype == PGT_F16) { if (C == 256) SRM(half_t, 4); else SRM(half_t, 8); }
     else PGT_CHECK(false, "sampled_rownorm_mean: bad dtype %d", dtype);
 #undef SRM
+    PGT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sampled_rownorm_finish_kernel, dim3(N), dim3(256), 0, st, part, nslice, C, S, mean);
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -45,7 +45,8 @@ SIGNATURES = {
     "pgt_sampled_channel_mean": [i32, vp, i32, i32, i32, i32, vp, vp],
     "pgt_sampled_pixel": [i32, i32],
     "pgt_weight_defect": [i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
-    "pgt_sampled_rownorm_mean": [i32, vp, i32, i32, i32, i32, f32, vp, vp],
+    "pgt_sampled_rownorm_workspace_bytes": [i32, i32, i32],
+    "pgt_sampled_rownorm_mean": [i32, vp, i32, i32, i32, i32, f32, vp, vp, vp],
     "pgt_fold_layernorm": [vp, vp, vp, vp, i32, i32, vp, vp, vp],
     "pgt_ln_linear": [i32, vp, i32, i32, i32, f32, vp, vp, i32, i32, vp, i32, vp],
     "pgt_ln_linear_x3": [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, i32, vp],
@@ -93,7 +94,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz,
              "pgt_commit_loss_workspace_bytes": sz, "pgt_conv_gn_workspace_bytes": sz,
-             "pgt_conv2d_workspace_bytes": sz, "pgt_packed_weight_bytes": sz, "pgt_attn_proj_mlp_sample_workspace_bytes": sz}
+             "pgt_conv2d_workspace_bytes": sz, "pgt_packed_weight_bytes": sz, "pgt_attn_proj_mlp_sample_workspace_bytes": sz, "pgt_sampled_rownorm_workspace_bytes": sz}
 
 
 class PgtError(RuntimeError):

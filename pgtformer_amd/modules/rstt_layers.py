@@ -82,7 +82,7 @@ def _frame_bias(x, pdef, pb, frames=None):
     """bias operand of a layer: the (frames, Cout) per-frame bias of a compensated layer - x (N,H,W,C) image batch, or
     (rows, C) tokens of `frames` frames - or the plain (Cout,) bias `pb` when the layer is not compensated or its frames are
     not whole 512-row tiles (pgt_conv_desc::bias_rows)"""
-    if pdef is None:
+    if pdef is None or pdef.shape[0] > 3840:      # (pgt_mean_field_bias holds K <= 3840 means in LDS: wider layers keep the plain bias)
         return pb
     if x.dim() == 2:
         if not USE_WCOMP_LINEAR:

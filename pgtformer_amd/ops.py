@@ -433,7 +433,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     if (AUTOTUNE is not None and kernel == 0 and tile == (0, 0) and splitk == 0 and not scalar_epi
             and x.dtype == torch.bfloat16 and not x3):
         key = (n, h, wd, cin, d.ldx, d.ups, kh, kw, stride, tuple(pad), cout, d.ldy, act, d.post_relu, d.ldr, d.epi,
-               d.ld_dec, d.ld_shift, d.out_f32, bias is None, d.orow_mul, d.orow_xmul, d.orow_off, d.gn_groups)
+               d.ld_dec, d.ld_shift, d.out_f32, bias is None, d.orow_mul, d.orow_xmul, d.orow_off, d.gn_groups, d.bias_rows)
         cfg = AUTOTUNE.get(key)
         if cfg is None and not torch.cuda.is_current_stream_capturing():
             if L.pgt_conv2d_workspace_bytes(C.byref(d)):
@@ -607,8 +607,9 @@ def sampled_rownorm_mean(x, eps=1e-5):
     mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
     ld = x.stride(1) if hw > 1 else c
     assert x.stride(2) == 1 and (n == 1 or x.stride(0) == hw * ld)
+    ws = torch.empty(max(4, hip.lib().pgt_sampled_rownorm_workspace_bytes(n, hw, c) // 4), dtype=torch.float32, device=x.device)
     with _Prof("mean_field", 0, float(n * min(hw, 1024) * c * x.element_size())):
-        hip.check(hip.lib().pgt_sampled_rownorm_mean(_dt(x), _p(x), ld, n, hw, c, float(eps), _p(mean), _stream()), "pgt_sampled_rownorm_mean")
+        hip.check(hip.lib().pgt_sampled_rownorm_mean(_dt(x), _p(x), ld, n, hw, c, float(eps), _p(mean), _p(ws), _stream()), "pgt_sampled_rownorm_mean")
     return mean
 
 
