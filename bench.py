@@ -311,11 +311,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("PGT_DIST_BACKEND", "nccl")      # "gloo": several ranks on ONE GPU (a test rig for the N > 1 control flow)
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

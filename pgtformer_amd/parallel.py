@@ -10,6 +10,12 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t, group):
+    """gloo moves host tensors only: on a single-GPU test rig (several ranks on one device, backend gloo) device tensors are
+    staged through host memory for the collective; on RCCL (`nccl`) they go as they are."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def frame_range(n_frames, rank, world):
     """Contiguous, balanced output-frame range [start, end) of `rank` (ranges differ by at most 1)."""
     base, rem = divmod(n_frames, world)
@@ -42,8 +48,13 @@ def exchange_halo(local_frames, rank, world, group=None):
         mine[:fbytes] = local_frames[0].reshape(-1)
         mine[fbytes:2 * fbytes] = local_frames[-1].reshape(-1)
     mine[2 * fbytes:] = torch.tensor([n_local], dtype=torch.int64).view(torch.uint8).to(local_frames.device)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
+    if _staged(mine, group):
+        host = [torch.empty_like(mine, device="cpu") for _ in range(world)]
+        dist.all_gather(host, mine.cpu(), group=group)
+        gathered = [h.to(mine.device) for h in host]
+    else:
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
     if n_local == 0:
         return None, None
     counts = torch.stack([g[2 * fbytes:] for g in gathered]).cpu().view(torch.int64).reshape(-1).tolist()
@@ -76,8 +87,13 @@ def gather_outputs(local_out, n_frames, rank, world, dst=0, group=None):
     maxn = max(e - s for s, e in sizes)
     pad = torch.zeros((maxn,) + tuple(local_out.shape[1:]), dtype=local_out.dtype, device=local_out.device)
     pad[:local_out.shape[0]] = local_out
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst, group=group)
+    if _staged(pad, group):
+        host = [torch.empty_like(pad, device="cpu") for _ in range(world)] if rank == dst else None
+        dist.gather(pad.cpu(), host, dst=dst, group=group)
+        bufs = [h.to(pad.device) for h in host] if rank == dst else None
+    else:
+        bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, bufs, dst=dst, group=group)
     if rank != dst:
         return None
     return torch.cat([bufs[r][: sizes[r][1] - sizes[r][0]] for r in range(world)], 0)
