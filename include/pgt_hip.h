@@ -107,6 +107,10 @@ typedef struct pgt_conv_desc {
                                  * vector per bias_rows consecutive output pixels - a bias per frame (bias_rows = Ho*Wo; for
                                  * token rows: tokens per frame), the form pgt_mean_field_bias produces.  A multiple of 512
                                  * that divides N*Ho*Wo; single-plane dtypes; kernels 0, 1, 4, 5, 6, 7.                       */
+    int32_t out_split;          /* dtype == PGT_F32 only: store y as split-half planes [hi | lo] (lo plane y_lo elements after
+                                 * the hi plane, ldy in 16-bit elements) instead of fp32 - the exact-fp32 first conv of the encoder
+                                 * (3 input channels) feeding the split-half levels without a conversion pass
+                                 * (archs/tdcrqvae3_arch.py:540-546).  16-byte epilogue only (Cout % 8 == 0), no split-K.        */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,

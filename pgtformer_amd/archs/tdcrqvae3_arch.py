@@ -290,6 +290,9 @@ class RQBottleneck(HipModule):
         return out.reshape(b, h, w, -1)
 
 
+USE_CONV_IN_SPLIT = os.environ.get("PGT_CONV_IN_SPLIT", "1") != "0"     # A/B switch: split planes straight from the fp32 first conv
+
+
 class Encoder(HipModule):
     def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), depths, num_res_blocks, num_heads, num_frames,
                  window_sizes, attn_resolutions, dropout=0.0, resamp_with_conv=True, in_channels, resolution,
@@ -366,7 +369,13 @@ class Encoder(HipModule):
         feats = []
         cur = self.conv_in.dt
         # (the level-0 block starts with a GroupNorm: statistics from conv_in's epilogue unless a dtype conversion intervenes)
-        h = self.conv_in.run(x, gn=32 if self.down[0].block[0].dt == cur else None)
+        if cur == torch.float32 and _is_x3(self.down[0].block[0].dt) and USE_CONV_IN_SPLIT:
+            # exact-fp32 conv_in feeding a split-half level: the kernel stores the split planes itself (pgt_conv_desc::out_split)
+            # - no fp32 tensor, no conversion pass over the largest activation of the model - and leaves the statistics too
+            h = self.conv_in.run(x, gn=32, out_x3=True)
+            cur = X3
+        else:
+            h = self.conv_in.run(x, gn=32 if self.down[0].block[0].dt == cur else None)
         per_frame = win is not None
         for i_level in range(self.num_resolutions):
             lvl = self.down[i_level]

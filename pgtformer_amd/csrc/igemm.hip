@@ -274,7 +274,13 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gs[8 + e] += v[e] * v[e]; }
                 }
-                if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + out_row(p, m) * p.ldy + n, v);
+                if (p.out_split) {      // (fp32 launches only) split-half planes straight from the fp32 values
+                    uint4 hi, lo;
+                    split8(v, hi, lo);
+                    half_t* yh = reinterpret_cast<half_t*>(p.y) + out_row(p, m) * p.ldy + n;
+                    *reinterpret_cast<uint4*>(yh) = hi;
+                    *reinterpret_cast<uint4*>(yh + p.ylo) = lo;
+                } else if (p.out_f32) store8<float>(reinterpret_cast<float*>(p.y) + out_row(p, m) * p.ldy + n, v);
                 else store8<T>(reinterpret_cast<T*>(p.y) + out_row(p, m) * p.ldy + n, v);
             }
             __syncthreads();
@@ -407,7 +413,7 @@ template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm,
 
 // number of K slices pgt_conv2d_ws would use for this layer (1 = single pass)
 static int planned_splitk(const pgt_conv_desc* d) {
-    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_F16X3 || d->gn_groups > 0) return 1;
+    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_F16X3 || d->gn_groups > 0 || d->out_split) return 1;
     const long M = (long)d->N * d->Ho * d->Wo;
     const int K = d->KH * d->KW * d->Cin;
     const int bk = d->dtype == PGT_F32 ? 32 : 64;
@@ -438,7 +444,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     PGT_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "pgt_conv2d: x and w must be 16-byte aligned");
     PGT_CHECK(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->Cout >= 1 && d->N >= 1, "pgt_conv2d: bad geometry");
     PGT_CHECK(d->ups == 0 || d->ups == 1, "pgt_conv2d: ups must be 0 or 1");
-    PGT_CHECK(d->ldy >= d->Cout, "pgt_conv2d: ldy < Cout");
+    PGT_CHECK(d->ldy >= d->Cout && (!d->out_split || d->ldy >= (d->y_lo ? d->y_lo : d->Cout) + d->Cout), "pgt_conv2d: ldy < Cout");
     // the gather offsets of every kernel are 32-bit byte offsets
     PGT_CHECK((long)d->N * d->H * d->W * d->ldx * es < (1L << 31), "pgt_conv2d: the input tensor must be smaller than 2 GiB "
               "(N=%d H=%d W=%d ldx=%d): split the batch", d->N, d->H, d->W, d->ldx);
@@ -477,6 +483,10 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.slo = d->shift_lo ? d->shift_lo : d->Cout;
     p.nw = (x3 && d->x3_fold) ? 128 : d->Cout;
     p.bias_rows = d->bias_rows;
+    p.out_split = d->out_split ? 1 : 0;
+    PGT_CHECK(!d->out_split || (d->dtype == PGT_F32 && d->Cout % 8 == 0 && !d->scalar_epilogue && d->epi == 0 && !d->out_f32 && d->orow_mul == 0 &&
+                                d->splitk <= 1 && d->ldy % 8 == 0 && (((uintptr_t)y) & 15) == 0),
+              "pgt_conv2d: out_split needs dtype PGT_F32, Cout %% 8 == 0, the plain 16-byte epilogue, no split-K, 16-byte aligned rows");
     PGT_CHECK(d->bias_rows == 0 || (bias && d->bias_rows > 0 && d->bias_rows % 512 == 0 && p.M % d->bias_rows == 0 && !x3 &&
                                     d->kernel != 2 && d->kernel != 3),
               "pgt_conv2d: bias_rows=%d (a bias vector per frame) needs a bias, a multiple of 512 rows that divides M=%d, a single-plane dtype and kernel 0, 1, 4, 5 or 6", d->bias_rows, p.M);

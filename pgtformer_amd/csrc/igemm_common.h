@@ -49,6 +49,7 @@ struct ConvP {
     int f16;                    // 16-bit operands are IEEE half (PGT_F16) instead of bf16
     int dlo, slo;               // x3 with the SFT epilogue: element offsets of the lo planes of dec / shift
     int bias_rows;              // > 0: bias is a (M / bias_rows, Cout) matrix - one vector per bias_rows consecutive output pixels (a frame)
+    int out_split;              // fp32 kernel: y is stored as split-half planes [hi | lo] (lo plane ylo elements further)
     int nw;                     // rows of the weight matrix = GEMM columns (Cout; 128 for the folded 64-channel x3 form, x3 == 2)
     // GroupNorm statistics of the OUTPUT from the epilogue (gn_part != nullptr): every workgroup tile writes the sum and
     // sum of squares of its outputs per channel group to gn_part[((img * gn_maxblk + k) * gn_G + g) * 2 + {0, 1}], k = the

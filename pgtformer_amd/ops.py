@@ -322,7 +322,7 @@ def _tune_conv(d, args, device, iters=4, gn_ws=None):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False):
+           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False, out_x3=False):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout).
     out_parity=(py, px): write the (N,Ho,Wo,Cout) result to out[:, py::2, px::2, :] of a required (N,2Ho,2Wo,Cout) `out`
@@ -331,9 +331,12 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     (any (..., Cout) view; its pixel stride is the row pitch).
     gn: None, or a number of groups: the epilogue also reduces the GroupNorm statistics of the output, attached to the
     returned tensor as `._pgt_gn` (ops.GnStats) for the GroupNorm that follows; or (GnStats, sub) when several launches
-    write one tensor (the caller binds the statistics to the tensor after the last launch)."""
+    write one tensor (the caller binds the statistics to the tensor after the last launch).
+    out_x3: fp32 x / w, result stored as split-half planes (N,Ho,Wo,2*Cout) (pgt_conv_desc::out_split)."""
     n, h, wd, cin = x.shape
     cout = w.shape[0]
+    if out_x3:
+        assert x.dtype == torch.float32 and not x3 and not out_f32 and sft is None and out_rows is None and out_parity is None and res is None
     if x3:   # split-half operands: x (N,H,W,2*Cin) = [hi | lo], w (Cout, kh*kw*3*Cin), y (N,Ho,Wo,2*Cout) unless out_f32
         assert x.dtype == X3_PLANE and cin % 2 == 0 and sft is None and not ups and out_rows is None and out_parity is None
         cin //= 2
@@ -345,14 +348,14 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     else:
         assert w.shape[1] == kh * kw * cin, (w.shape, kh, kw, cin)
     assert w.dtype == x.dtype and w.is_contiguous()
-    cst = cout if (out_f32 or not x3) else 2 * cout      # stored output channels
+    cst = 2 * cout if (out_x3 or (x3 and not out_f32)) else cout      # stored output channels
     if n > 1 and n * h * wd * _ld_img(x) * x.element_size() >= (1 << 31) and out_rows is None and out_parity is None:
         # the kernels take 32-bit byte offsets: run a >= 2 GiB input as frame chunks (frames are independent)
         hv0, wv0 = (h * 2, wd * 2) if ups else (h, wd)
         ho0 = (hv0 + pad[0] + pad[1] - kh) // stride + 1
         wo0 = (wv0 + pad[2] + pad[3] - kw) // stride + 1
         if out is None:
-            out = torch.empty((n, ho0, wo0, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+            out = torch.empty((n, ho0, wo0, cst), device=x.device, dtype=torch.float32 if out_f32 else (X3_PLANE if out_x3 else x.dtype))
         per = max(1, ((1 << 31) - 1) // (h * wd * _ld_img(x) * x.element_size()))
         st = None
         if gn is not None and not isinstance(gn, tuple) and USE_EPILOGUE_GN and gn_ok(n, ho0 * wo0, cout, gn, cin, kh):
@@ -371,7 +374,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                    res=None if res is None else res[sl], post_relu=post_relu,
                    sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
                    tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3,
-                   gn=None if st is None else (st, 0, i), x3_fold=x3_fold)
+                   gn=None if st is None else (st, 0, i), x3_fold=x3_fold, out_x3=out_x3)
         return out if st is None else st.bind(out, cst)
     hv, wv = (h * 2, wd * 2) if ups else (h, wd)
     ho = (hv + pad[0] + pad[1] - kh) // stride + 1
@@ -383,7 +386,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         assert out is not None and out.shape[-1] == cout and res is None and sft is None
     else:
         if out is None:
-            out = torch.empty((n, ho, wo, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+            out = torch.empty((n, ho, wo, cst), device=x.device, dtype=torch.float32 if out_f32 else (X3_PLANE if out_x3 else x.dtype))
         assert tuple(out.shape) == (n, ho, wo, cst), (out.shape, (n, ho, wo, cst))
     d = hip.ConvDesc()
     d.dtype = PGT_F16X3 if x3 else _dt(x)
@@ -399,6 +402,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.splitk = int(splitk)
     d.stages = int(stages)
     d.x3_fold = int(bool(x3_fold))
+    d.out_split = int(bool(out_x3))
     if bias is not None and bias.dim() == 2:      # one bias vector per frame (mean_field_bias): (frames, Cout) fp32
         assert bias.shape[1] == cout and bias.is_contiguous() and (n * ho * wo) % bias.shape[0] == 0 and bias.shape[0] % n == 0, (bias.shape, n, cout)
         d.bias_rows = (n * ho * wo) // bias.shape[0]

@@ -120,7 +120,7 @@ def _store(val, out, dtype):
 
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
-           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
+           post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0, out_x3=False,
            out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False):
     n, h, wd, cin = x.shape
     cout = w.shape[0]
@@ -168,7 +168,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         flat = out.as_strided((int(rows.max()) + 1, cout), (out.stride(-2), 1))
         flat[rows] = y.reshape(-1, cout).to(out.dtype)
         return out
-    if x3 and not out_f32:
+    if out_x3 or (x3 and not out_f32):
         return _store_x3(y, out)
     return _store(y, out, torch.float32 if out_f32 else x.dtype)
 

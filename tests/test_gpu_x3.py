@@ -322,3 +322,24 @@ def test_split_planes_saturate_instead_of_overflowing():
     big = ops().to_x3(g(torch.full((1, 1, 512, 64), 100.0)))
     y = ops().from_x3(ops().conv2d(big, w, None, x3=True))
     assert torch.isfinite(y).all() and float(y.max()) == 65504.0
+
+
+def test_fp32_conv_with_split_output():
+    """pgt_conv_desc::out_split: the exact-fp32 kernel (the encoder's 3-input-channel first conv) stores split-half planes itself:
+    bit-equal to the fp32 result split afterwards (to_x3), with and without the epilogue GroupNorm statistics."""
+    O = ops()
+    x = rnd((3, 32, 32, 8), 301)
+    w = rnd((64, 9 * 8), 302, 0.2)
+    b = rnd((64,), 303)
+    y32 = O.conv2d(g(x), g(w), g(b), kh=3, kw=3, pad=(1, 1, 1, 1))
+    want = O.to_x3(y32)
+    got = O.conv2d(g(x), g(w), g(b), kh=3, kw=3, pad=(1, 1, 1, 1), out_x3=True)
+    assert got.dtype == torch.float16 and got.shape == (3, 32, 32, 128) and torch.equal(got, want)
+    got_gn = O.conv2d(g(x), g(w), g(b), kh=3, kw=3, pad=(1, 1, 1, 1), out_x3=True, gn=32)
+    assert torch.equal(got_gn, want) and getattr(got_gn, "_pgt_gn", None) is not None
+    gm, bt = 1 + 0.1 * rnd((64,), 304), 0.1 * rnd((64,), 305)
+    s1, t1 = O.groupnorm_affine(got_gn, g(gm), g(bt), x3=True)          # from the epilogue statistics
+    s2, t2 = O.groupnorm_affine(want, g(gm), g(bt), x3=True)            # from the statistics pass
+    check("out_split_gn_scale", s1, s2, 2e-5)
+    check("out_split_gn_shift", t1, t2, 2e-5)
+    check("out_split_vs_emulation", O.from_x3(got), E.from_x3(E.conv2d(x, w, b, kh=3, kw=3, pad=(1, 1, 1, 1), out_x3=True)), 2e-4)
