@@ -25,9 +25,18 @@
 //   * one barrier per chunk (DMA of chunk c + NS - 1 is issued right after the barrier that retires chunk c - 1); counted
 //     s_waitcnt vmcnt so that NS - 2 chunks stay in flight across the barrier.
 //   * persistent workgroups (8 waves = 128 RT rows per tile), one per CU.
-// Numerics are those of the unfused launches: x1, LN outputs and the hidden row are rounded to half exactly where the
-// layer-by-layer path stores them; accumulation and statistics are fp32.  GELU is the exact-erf form with erf from
-// Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the half rounding that follows it).
+// Numerics are those of the unfused launches: x1, the normalised rows and the hidden row are rounded to half exactly where the
+// layer-by-layer path stores them; accumulation and statistics are fp32.  Two differences, both at load time: the LayerNorm's
+// affine part is folded into the following Linear (pgt_fold_layernorm: W diag(gamma), b + W beta), so the kernels normalise
+// without per-channel operands; GELU is the exact-erf form with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three
+// orders below the half rounding that follows it).
+//   chain 3  the sampled pass of chain 1 (pgt_attn_proj_mlp_sample): the same code on the <= 1024 sampled rows of every frame,
+//            up to the hidden row, leaving column sums - the per-frame means the weight-rounding compensation of fc1 / fc2
+//            needs for operands that never reach HBM.
+//   split-half forms (rowchain_x3_kernel, further down): LN -> Linear and LN -> Mlp -> residual on two half planes.
+// What bounds these kernels (tools/rowchain_probe.py): the chip's power limit - switching work off
+// shortens them whatever the work is, re-scheduling the same work (pipelined epilogues, prefetched rows, 4 / 8 / 16 waves, two
+// workgroups per CU) changes their cycle count and clock in opposite directions and leaves the time where it was.
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
