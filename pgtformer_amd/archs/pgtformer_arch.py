@@ -565,7 +565,9 @@ class PGTFormer(TDCRQVAE3):
         operator counts the elements of its IEEE-half outputs that sit at the saturation limit +-65504 or are not finite
         (ops.RANGE_CHECK, pgt_count_saturated).  Returns the list of (operator, shape, count) with count > 0 - empty when the
         checkpoint's activations fit the half range.  The half decoder of the default mode clamps silently otherwise:
-        callers fall back to prepare(device, "bf16x3") (bf16 decoder: no range limit)."""
+        callers fall back to prepare(device, "bf16x3") (bf16 decoder: no range limit).  Rows that stay on chip inside the fused
+        token-row chains (x1 and the hidden row of a block tail; the normalised rows are bounded by 16) are not tensors and
+        are not counted: a block whose x1 saturated shows up in its output and in the layers that follow."""
         recs, hooks = [], []
         for name, mod in self.named_modules():          # records carry the innermost module whose forward() is running
             hooks.append(mod.register_forward_pre_hook(lambda m, a, n=name: ops.RANGE_CTX.append(n)))
