@@ -55,7 +55,7 @@ template <bool F16> struct El {
 // Windows are (wd, wh, ww) blocks of the (D, H, W) token grid with a cyclic shift (sd, sh, sw) and the 27-region mask of
 // modules/swin.py:311-323; the PGTFormer layers use wd = D, sd = 0 (all frames of a spatial window in one group).
 template <int HD, int NW, bool X3 = false, bool F16 = false>
-__global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_t* __restrict__ qkv, int ldqkv,
+__global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 1) ? 4 : 1) void window_attn_mfma_kernel(const uint16_t* __restrict__ qkv, int ldqkv,
                                                                    uint16_t* __restrict__ out, int ldo,
                                                                    const float* __restrict__ bias, int T_, int H, int W,
                                                                    int C, int heads, int wh, int ww, int sh, int sw,
@@ -105,6 +105,30 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
         reg[i] = (rd * 3 + rh) * 3 + rw;
     }
     __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, col = lane & 15;
+    const float scale = X3 ? 1.0f / sqrtf((float)HD) : rsqrtf((float)HD);
+    // Q^T fragments of this wave's 3 query tiles and the K fragments of the first 48-key group: requested BEFORE the V^T staging
+    // below, so that the three operands travel together - the kernel is a chain of dependent HBM round trips otherwise (V rows ->
+    // LDS -> barrier -> Q -> K: measured 3.3 TB/s at 16 waves per CU, round 4)
+    uint4 qf[3][KS], ql[X3 ? 3 : 1][KS];
+    uint4 kf0[3][KS], kl0[X3 ? 3 : 1][KS];
+    int qidx[3], rq[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+        qidx[qt] = wave * 48 + qt * 16 + col;
+        rq[qt] = reg[qidx[qt]];
+        const uint16_t* qrow = qkv + (long)tok[qidx[qt]] * ldqkv + head * HD + g * 8;
+        const uint16_t* krow = qkv + (long)tok[qt * 16 + col] * ldqkv + C + head * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[qt][ks] = *reinterpret_cast<const uint4*>(qrow + ks * 32);
+            kf0[qt][ks] = *reinterpret_cast<const uint4*>(krow + ks * 32);
+            if constexpr (X3) {
+                ql[qt][ks] = *reinterpret_cast<const uint4*>(qrow + qlo + ks * 32);
+                kl0[qt][ks] = *reinterpret_cast<const uint4*>(krow + qlo + ks * 32);
+            }
+        }
+    }
     // ---- V^T image: work item = (key pair, 8-channel chunk); dword = {V[2kp][d], V[2kp+1][d]}
     for (int it = tid; it < NP * (N / 2) * (HD / 8); it += 64 * NW) {
         const int pl = it / ((N / 2) * (HD / 8)), it2 = it % ((N / 2) * (HD / 8));   // plane (0 = hi, 1 = lo)
@@ -123,22 +147,6 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
     }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, col = lane & 15;
-    const float scale = X3 ? 1.0f / sqrtf((float)HD) : rsqrtf((float)HD);
-    // Q^T fragments of this wave's 3 query tiles
-    uint4 qf[3][KS], ql[X3 ? 3 : 1][KS];
-    int qidx[3], rq[3];
-#pragma unroll
-    for (int qt = 0; qt < 3; ++qt) {
-        qidx[qt] = wave * 48 + qt * 16 + col;
-        rq[qt] = reg[qidx[qt]];
-        const uint16_t* qrow = qkv + (long)tok[qidx[qt]] * ldqkv + head * HD + g * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[qt][ks] = *reinterpret_cast<const uint4*>(qrow + ks * 32);
-            if constexpr (X3) ql[qt][ks] = *reinterpret_cast<const uint4*>(qrow + qlo + ks * 32);
-        }
-    }
     float m[3], l[3];
     f32x4 o[3][DT];
 #pragma unroll
@@ -156,8 +164,13 @@ __global__ __launch_bounds__(64 * NW) void window_attn_mfma_kernel(const uint16_
             const uint16_t* krow = qkv + (long)tok[kg * 48 + kt * 16 + col] * ldqkv + C + head * HD + g * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                kf[kt][ks] = *reinterpret_cast<const uint4*>(krow + ks * 32);
-                if constexpr (X3) kl[kt][ks] = *reinterpret_cast<const uint4*>(krow + qlo + ks * 32);
+                if (kg == 0) {                       // (requested before the V^T staging)
+                    kf[kt][ks] = kf0[kt][ks];
+                    if constexpr (X3) kl[kt][ks] = kl0[kt][ks];
+                } else {
+                    kf[kt][ks] = *reinterpret_cast<const uint4*>(krow + ks * 32);
+                    if constexpr (X3) kl[kt][ks] = *reinterpret_cast<const uint4*>(krow + qlo + ks * 32);
+                }
             }
         }
         int rk[3][4];

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpgt_hip.so")
+# PGT_LIB_PATH: load another build of the library (same-box A/B of two builds: tools/gpu/ab_env.sh "" "PGT_LIB_PATH=..." "")
+LIB_PATH = os.environ.get("PGT_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpgt_hip.so")
 
 PGT_F32, PGT_BF16, PGT_F16X3, PGT_F16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_LEAKY02, ACT_SIGMOID = range(6)
