@@ -54,12 +54,17 @@ template <bool F16> struct El {
 // product is taken as hi*hi + lo*hi + hi*lo (S^T from q, k; O^T from P, V with P split in registers after the exp).
 // Windows are (wd, wh, ww) blocks of the (D, H, W) token grid with a cyclic shift (sd, sh, sw) and the 27-region mask of
 // modules/swin.py:311-323; the PGTFormer layers use wd = D, sd = 0 (all frames of a spatial window in one group).
-template <int HD, int NW, bool X3 = false, bool F16 = false>
-__global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 1) ? 4 : 1) void window_attn_mfma_kernel(const uint16_t* __restrict__ qkv, int ldqkv,
+#ifndef PGT_WATTN_OCC
+#define PGT_WATTN_OCC 4      // waves per SIMD asked of the compiler for the 48-token, 32-wide-head form (tools/bench_wattn.py A/Bs)
+#endif
+// HPW heads of one window per workgroup (each on its own NW waves): the workgroup then asks for HPW adjacent 64 / 128-byte
+// slices of every token row at the same moment instead of leaving them to HPW workgroups that run whenever they are scheduled.
+template <int HD, int NW, bool X3 = false, bool F16 = false, int HPW = 1>
+__global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? PGT_WATTN_OCC : 1) void window_attn_mfma_kernel(const uint16_t* __restrict__ qkv, int ldqkv,
                                                                    uint16_t* __restrict__ out, int ldo,
                                                                    const float* __restrict__ bias, int T_, int H, int W,
                                                                    int C, int heads, int wh, int ww, int sh, int sw,
-                                                                   int qlo, int olo, int wd, int sd) {
+                                                                   int qlo, int olo, int wd, int sd, int p2) {
     static_assert(!(X3 && F16), "X3 selects the split rows (half planes), F16 plain half rows");
     typedef El<F16 || X3> EL;
     constexpr int N = 48 * NW;
@@ -68,13 +73,13 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 1) ? 4 : 1) void window
     constexpr int DT = HD / 16;       // 16-wide head-dim tiles of O^T
     constexpr int NP = X3 ? 2 : 1;    // operand planes
     constexpr float LOG2E = 1.44269504088896340736f;
-    __shared__ __attribute__((aligned(16))) char vt_all[NP * HD * VSTR];
-    char* const vt = vt_all;
+    __shared__ __attribute__((aligned(16))) char vt_all[HPW * NP * HD * VSTR];
     __shared__ int tok[N];
     __shared__ int reg[N];
 
-    const int tid = threadIdx.x;
-    const int nwx = W / ww, nwy = H / wh;
+    const int hsub = HPW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x / (64 * NW)) : 0;   // which of the workgroup's heads
+    const int tid = HPW > 1 ? threadIdx.x - hsub * (64 * NW) : threadIdx.x;                   // thread within that head's waves
+    char* const vt = vt_all + hsub * (NP * HD * VSTR);
     // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), but the heads of one
     // window read ADJACENT 64 / 128-byte slices of the same token rows - give every XCD a contiguous run of (window, head)
     // ids so that those slices meet in one L2 (bijective for any grid size, as in the conv kernels)
@@ -83,20 +88,39 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 1) ? 4 : 1) void window
         const int nblk = gridDim.x, b0 = blockIdx.x, xcd = b0 & 7, q8 = nblk >> 3, r8 = nblk & 7;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b0 >> 3);
     }
-    const int head = bid % heads; bid /= heads;
-    const int wx = bid % nwx; bid /= nwx;
-    const int wy = bid % nwy; bid /= nwy;
-    const int nwz = T_ / wd;
-    const int wz = bid % nwz;
-    const int b = bid / nwz;
+    // p2 (host: pgt_window_attn_mfma): ww, wh, W/ww, H/wh and heads are powers of two and wd == D - bit 30 set, their log2 in
+    // 5-bit fields.  The index arithmetic is then shifts and masks: with one wave per workgroup and ~1100 instructions per
+    // window the dozen integer divisions of the general form were a third of the kernel's issue slots (round 4).
+    const bool fast = (p2 >> 30) & 1;
+    const int l_ww = p2 & 31, l_wh = (p2 >> 5) & 31, l_nwx = (p2 >> 10) & 31, l_nwy = (p2 >> 15) & 31, l_hd = (p2 >> 20) & 31;
+    int head, wx, wy, wz, b;
+    const int hgroups = heads / HPW;      // (host: heads % HPW == 0; fast => a power of two)
+    if (fast) {
+        head = (bid & (hgroups - 1)) * HPW + hsub; bid >>= l_hd;
+        wx = bid & ((1 << l_nwx) - 1); bid >>= l_nwx;
+        wy = bid & ((1 << l_nwy) - 1); bid >>= l_nwy;
+        wz = 0; b = bid;
+    } else {
+        const int nwx = W / ww, nwy = H / wh;
+        head = (bid % hgroups) * HPW + hsub; bid /= hgroups;
+        wx = bid % nwx; bid /= nwx;
+        wy = bid % nwy; bid /= nwy;
+        const int nwz = T_ / wd;
+        wz = bid % nwz;
+        b = bid / nwz;
+    }
     const bool shifted = (sh > 0) || (sw > 0) || (sd > 0);
 
-    for (int i = tid; i < N; i += 64 * NW) {
-        const int s = i % ww;
-        const int r = (i / ww) % wh;
-        const int dd = i / (ww * wh);
+    for (int i = threadIdx.x; i < N; i += 64 * NW * HPW) {
+        int s, r, dd;
+        if (fast) {
+            s = i & (ww - 1); r = (i >> l_ww) & (wh - 1); dd = i >> (l_ww + l_wh);
+        } else {
+            s = i % ww; r = (i / ww) % wh; dd = i / (ww * wh);
+        }
         const int ds = wz * wd + dd, ys = wy * wh + r, xs = wx * ww + s;      // coordinates in the rolled volume
-        const int d = (ds + sd) % T_, y = (ys + sh) % H, x = (xs + sw) % W;   // source token (roll by -shift)
+        int d = ds + sd, y = ys + sh, x = xs + sw;                            // source token (roll by -shift; shifts < sizes)
+        d = d >= T_ ? d - T_ : d; y = y >= H ? y - H : y; x = x >= W ? x - W : x;
         tok[i] = ((b * T_ + d) * H + y) * W + x;
         // img_mask regions (rstt_layers.py:552-563; swin.py:313-318): only equality inside one window matters
         const int rd = ds < T_ - wd ? 0 : (ds < T_ - sd ? 1 : 2);
@@ -268,6 +292,8 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 1) ? 4 : 1) void window
     }
 }
 
+constexpr int kDefaultHpw = 8;      // measured on MI355X: 1 -> 8 heads per workgroup -5 ... -8 % (profiles/r4_g_window_attention_hpw.jsonl)
+
 }  // namespace
 
 // mode 0: bf16, 1: split-half (lo planes qlo / olo elements after the hi planes), 2: fp16.  Windows (wd, wh, ww) with shift
@@ -280,13 +306,28 @@ int pgt_window_attn_mfma(int mode, const void* qkv, int ldqkv, void* out, int ld
     if (N % 48 != 0 || N > 192 || (hd != 32 && hd != 64) || wd <= 0 || D % wd != 0) return 1;
     if (ldqkv % 8 != 0 || ldo % 4 != 0 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7) || ((uintptr_t)bias & 15)) return 1;
     if (mode == 1 && (qlo % 8 != 0 || olo % 4 != 0)) return 1;
-    const int grid = B * (D / wd) * (H / wh) * (W / ww) * heads;
     const int nw = N / 48;
+    // heads per workgroup (48-token windows of 32-wide heads: the model's layers): PGT_WATTN_HPW = 1 | 2 | 4 | 8 for A/Bs
+    static const int env_hpw = [] { const char* e = getenv("PGT_WATTN_HPW"); return e ? atoi(e) : 0; }();
+    int hpw = env_hpw > 0 ? env_hpw : kDefaultHpw;
+    if (nw != 1 || hd != 32 || (hpw != 2 && hpw != 4 && hpw != 8) || heads % hpw != 0) hpw = 1;
+    const int grid = B * (D / wd) * (H / wh) * (W / ww) * (heads / hpw);
+    sd %= D; sh %= H; sw %= W;      // (the kernel rolls by one conditional subtraction)
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    int p2 = 0;
+    if (lg(ww) >= 0 && lg(wh) >= 0 && lg(W / ww) >= 0 && lg(H / wh) >= 0 && lg(heads) >= 0 && wd == D)
+        p2 = (1 << 30) | lg(ww) | (lg(wh) << 5) | (lg(W / ww) << 10) | (lg(H / wh) << 15) | (lg(heads / hpw) << 20);
 #define WAM(HD_, NW_, X3_, F16_)                                                                                              \
     hipLaunchKernelGGL((window_attn_mfma_kernel<HD_, NW_, X3_, F16_>), dim3(grid), dim3(64 * NW_), 0, st, (const uint16_t*)qkv, \
-                       ldqkv, (uint16_t*)out, ldo, bias, D, H, W, C, heads, wh, ww, sh, sw, qlo, olo, wd, sd)
+                       ldqkv, (uint16_t*)out, ldo, bias, D, H, W, C, heads, wh, ww, sh, sw, qlo, olo, wd, sd, p2)
+#define WAMH(X3_, F16_, HPW_)                                                                                                 \
+    hipLaunchKernelGGL((window_attn_mfma_kernel<32, 1, X3_, F16_, HPW_>), dim3(grid), dim3(64 * HPW_), 0, st, (const uint16_t*)qkv, \
+                       ldqkv, (uint16_t*)out, ldo, bias, D, H, W, C, heads, wh, ww, sh, sw, qlo, olo, wd, sd, p2)
 #define WAM_ALL(X3_, F16_)                                                                                                    \
     do {                                                                                                                      \
+        if (hpw == 2) { WAMH(X3_, F16_, 2); break; }                                                                           \
+        if (hpw == 4) { WAMH(X3_, F16_, 4); break; }                                                                           \
+        if (hpw == 8) { WAMH(X3_, F16_, 8); break; }                                                                           \
         if (hd == 32) {                                                                                                       \
             switch (nw) { case 1: WAM(32, 1, X3_, F16_); break; case 2: WAM(32, 2, X3_, F16_); break;                          \
                           case 3: WAM(32, 3, X3_, F16_); break; default: WAM(32, 4, X3_, F16_); }                              \
@@ -299,6 +340,7 @@ int pgt_window_attn_mfma(int mode, const void* qkv, int ldqkv, void* out, int ld
     else if (mode == 2) WAM_ALL(false, true);
     else WAM_ALL(false, false);
 #undef WAM_ALL
+#undef WAMH
 #undef WAM
     PGT_LAUNCH_CHECK();
     return 0;

@@ -196,6 +196,23 @@ def get_window_size(x_size, window_size, shift_size=None):
     return tuple(use_w) if use_s is None else (tuple(use_w), tuple(use_s))
 
 
+# Residual blocks over frame groups whose maps stay in the Infinity Cache (TDResnetBlock._forward_chunked): group size in MiB
+# of the block's widest map (0 = whole tensors, as up to round 3)
+BLOCK_GROUP_MIB = float(os.environ.get("PGT_BLOCK_GROUP_MIB", "0"))
+
+
+def _chunk_frames(x, c_stored):
+    """frames per group for an (N,H,W,.) map with c_stored 16-bit channels per pixel, or None when the map is run whole"""
+    if BLOCK_GROUP_MIB <= 0 or x.dim() != 4:
+        return None
+    n, h, w = x.shape[:3]
+    per = int(BLOCK_GROUP_MIB * (1 << 20) // max(1, h * w * c_stored * x.element_size()))
+    if per < 1 or per >= n:
+        return None if per >= n else 1
+    groups = -(-n // per)
+    return -(-n // groups)
+
+
 class TDResnetBlock(HipModule):
     """GN-SiLU-conv3x3-GN-SiLU-conv3x3 + (identity | 1x1 nin_shortcut) (reference: rstt_layers.py:835-904).
     x: (N,H,W,Cin) -> (N,H,W,Cout); the residual add is the second conv's epilogue."""
@@ -217,10 +234,43 @@ class TDResnetBlock(HipModule):
         """out: optional (N,H,W,Cout) view (e.g. a channel slice of a concat buffer) that receives the result.
         gn_next: a GroupNorm follows this block - its statistics come out of conv2's epilogue (as norm2's come out of
         conv1's: SURVEY K1/K7 "statistics from the producer")."""
+        per = _chunk_frames(x, max(self.in_channels, self.out_channels) * (2 if _is_x3(self.dt) else 1))
+        if per is not None:
+            return self._forward_chunked(x, per, out, gn_next)
         h = self.conv1.run(self.norm1.run(x, ACT_SILU), gn=self.norm2.num_groups)
         h = self.norm2.run(h, ACT_SILU)
         sc = self.nin_shortcut.run(x) if self.in_channels != self.out_channels else x
         return self.conv2.run(h, res=sc, out=out, gn=32 if gn_next else None)
+
+    def _forward_chunked(self, x, per, out, gn_next):
+        """The same block over groups of `per` frames (every operation of it is per frame): the three intermediate maps are
+        group-sized buffers that are rewritten for every group, so the passes between the two convs find their operands in the
+        256 MiB Infinity Cache instead of HBM.  norm1's statistics are those of the whole x (its
+        producer's epilogue left them); the statistics a following GroupNorm wants come out of the groups' conv2 launches into
+        one workspace (pgt_conv_desc::gn_img0)."""
+        n, hh, ww, _ = x.shape
+        x3 = _is_x3(self.dt)
+        cs = (2 if x3 else 1)
+        co = self.out_channels
+        if out is None:
+            out = torch.empty((n, hh, ww, co * cs), device=x.device, dtype=x.dtype)
+        scale, shift = ops.groupnorm_affine(x, self.norm1.pg, self.norm1.pbeta, self.norm1.num_groups, self.norm1.eps, x3=x3)
+        t1 = torch.empty((per, hh, ww, self.in_channels * cs), device=x.device, dtype=x.dtype)
+        t2 = torch.empty((per, hh, ww, co * cs), device=x.device, dtype=x.dtype)
+        t3 = torch.empty((per, hh, ww, co * cs), device=x.device, dtype=x.dtype)
+        st = None
+        if gn_next and ops.USE_EPILOGUE_GN and ops.gn_ok(n, hh * ww, co, 32, co, 3):
+            st = ops.GnStats(n, 1, hh * ww, co, 32, x.device)
+        for f0 in range(0, n, per):
+            f1 = min(n, f0 + per)
+            m = f1 - f0
+            xs = x[f0:f1]
+            a = ops.affine_act(xs, scale[f0:f1], shift[f0:f1], ACT_SILU, out=t1[:m], x3=x3)
+            h = self.conv1.run(a, gn=self.norm2.num_groups, out=t2[:m])
+            h = self.norm2.run(h, ACT_SILU, out=t3[:m])
+            sc = self.nin_shortcut.run(xs) if self.in_channels != self.out_channels else xs
+            self.conv2.run(h, res=sc, out=out[f0:f1], gn=(st, 0, f0) if st is not None else None)
+        return out if st is None else st.bind(out, co * cs)
 
 
 class Mlp(HipModule):

@@ -270,6 +270,57 @@ def test_window_attention(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_copy_into_channel_slices_vector_and_element_paths(dtype):
+    """pgt_copy2d: the 16-byte-chunk kernel (same type, widths / pitches / addresses multiples of 16 bytes) and the element
+    kernel (everything else, incl. conversions) write exactly the source values, into channel slices of wider buffers, and
+    nothing outside them."""
+    O = ops()
+    for rows, c, cw, off in ((3 * 16 * 16, 64, 160, 0), (2 * 8 * 8, 64, 160, 64), (5 * 4 * 4, 24, 56, 8), (77, 20, 36, 3), (4, 8, 8, 0)):
+        src = rnd((rows, c + 8), 70 + c, dtype)[:, :c] if off != 3 else rnd((rows, c), 70 + c, dtype)
+        dst = torch.full((rows, cw), -7.0, dtype=dtype)
+        want = dst.clone()
+        want[:, off:off + c] = src
+        d = g(dst)
+        O.copy_into(g(src) if off == 3 else g(rnd((rows, c + 8), 70 + c, dtype))[:, :c], d[:, off:off + c])
+        assert torch.equal(d.cpu(), want), (rows, c, cw, off, dtype)
+    x = rnd((2, 8, 8, 32), 79, dtype)
+    for to in DTYPES:      # conversions stay on the element kernel
+        got = O.cast(g(x), to)
+        assert got.dtype == to and torch.equal(got.cpu(), x.to(to))
+
+
+def test_window_attention_heads_per_workgroup_variants():
+    """The 48-token / 32-wide-head form runs 8 heads of a window per workgroup (window_attn_mfma.hip: HPW); the 1-, 2- and
+    4-head forms (PGT_WATTN_HPW, read once per process: separate interpreters) store the same bits - every head's arithmetic is
+    the same instruction sequence on its own waves - on power-of-two and other grids, shifted and not, half and split rows."""
+    import subprocess
+    import sys
+    import tempfile
+    prog = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import pgtformer_amd.ops as O\n"
+        "g = torch.Generator(device='cuda').manual_seed(3)\n"
+        "outs = []\n"
+        "for (b, h, w, shift, x3) in ((2, 16, 16, (2, 2), False), (1, 8, 12, (0, 0), False), (1, 8, 12, (2, 2), True), (2, 16, 8, (0, 0), True)):\n"
+        "    qkv = torch.randn((b * 3 * h * w, 768 * (2 if x3 else 1)), device='cuda', dtype=torch.float16, generator=g)\n"
+        "    if x3: qkv[:, 768:] *= 2.0 ** -11\n"
+        "    bias = 0.5 * torch.randn((8, 48, 48), device='cuda', generator=g)\n"
+        "    outs.append(O.window_attention(qkv, bias, b, 3, h, w, 256, 8, (4, 4), shift, x3=x3).cpu())\n"
+        "torch.save(outs, sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for hpw in ("8", "1", "2", "4"):
+            f = os.path.join(d, f"o{hpw}.pt")
+            subprocess.run([sys.executable, "-c", prog, f], check=True, env=dict(os.environ, PGT_WATTN_HPW=hpw), timeout=300)
+            res[hpw] = torch.load(f)
+    for hpw in ("1", "2", "4"):
+        for a, b_ in zip(res["8"], res[hpw]):
+            assert torch.equal(a, b_), hpw
+    _LOG.append({"name": "window_attention_heads_per_workgroup_1_2_4_8", "bit_equal": True, "cases": len(res["8"])})
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("L", [192, 200, 640, 777])
 def test_mha(dtype, L):
     b, heads, hd = 2, 8, 64
@@ -705,6 +756,38 @@ def test_model_with_and_without_epilogue_statistics(monkeypatch):
         monkeypatch.setattr(O, "USE_EPILOGUE_GN", True)
         assert getattr(off, "_pgt_gn", None) is None
         check(f"block_gn_on_vs_off_{dtype}", on, off, dtype, 0.5)
+
+
+def test_residual_block_over_frame_groups_is_bit_equal(monkeypatch):
+    """TDResnetBlock over groups of frames (PGT_BLOCK_GROUP_MIB) against the whole-tensor block: the
+    same tiles, the same per-frame biases, the same statistics partials - every stored value equal, for the half / bf16 layers
+    and the split-half ones, with the statistics of the NEXT GroupNorm coming out of the groups' conv2 launches."""
+    import pgtformer_amd.ops as O
+    from pgtformer_amd.modules import rstt_layers as RL
+    torch.manual_seed(11)
+    for cin, cout, hw in ((128, 256, 32), (128, 128, 64)):
+        blk = RL.TDResnetBlock(in_channels=cin, out_channels=cout)
+        nxt = RL.Normalize(cout)
+        for p_ in list(blk.parameters()) + list(nxt.parameters()):
+            torch.nn.init.normal_(p_, std=0.05)
+        x = rnd((7, hw, hw, cin), 231)
+        for dtype in (torch.float16, torch.bfloat16, O.X3):
+            blk.prepare(DEV, dtype)
+            nxt.prepare(DEV, dtype)
+            xd = O.to_x3(g(x)) if dtype == O.X3 else g(x.to(dtype))
+            monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", 0.0)
+            want = blk(xd, gn_next=True)
+            want_n = nxt.run(want)
+            frame_mib = hw * hw * max(cin, cout) * (4 if dtype == O.X3 else 2) / (1 << 20)
+            for per in (1, 3, 4):
+                monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", per * frame_mib)
+                got = blk(xd, gn_next=True)
+                assert (getattr(got, "_pgt_gn", None) is None) == (getattr(want, "_pgt_gn", None) is None)
+                assert torch.equal(got, want), (cin, cout, dtype, per, float((got.float() - want.float()).abs().max()))
+                got_n = nxt.run(got)
+                err = float((got_n.float() - want_n.float()).abs().max())
+                _LOG.append({"name": f"block_groups_{cin}_{cout}_{hw}_{dtype}_per{per}", "max_abs_err_next_groupnorm": err})
+                assert err <= 2e-2 * max(1.0, float(want_n.float().abs().max())), err
 
 
 # ------------------------------------------------------------------------------------------------

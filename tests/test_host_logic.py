@@ -272,3 +272,31 @@ def test_weight_rounding_compensation_host_logic(monkeypatch):
         other = R.Linear(64, 64)
         R.prepare_tree(other, torch.device("cpu"), dt)
         assert other.pdef is None
+
+
+def test_residual_block_over_frame_groups_matches_whole_tensor(monkeypatch):
+    """TDResnetBlock._forward_chunked (PGT_BLOCK_GROUP_MIB: the block over groups of frames whose maps stay in the Infinity
+    Cache) is the same function as the whole-tensor block: every operation of it is per frame (reference:
+    rstt_layers.py:835-904).  Checked through the CPU emulation of the ops, group sizes that do and do not divide N."""
+    import torch
+    from pgtformer_amd.modules import rstt_layers as RL
+    emu_ops.install(monkeypatch)
+    torch.manual_seed(5)
+    for cin, cout in ((64, 64), (32, 64)):
+        blk = RL.TDResnetBlock(in_channels=cin, out_channels=cout)
+        for p_ in blk.parameters():
+            torch.nn.init.normal_(p_, std=0.05)
+        RL.prepare_tree(blk, "cpu", torch.float32)
+        x = torch.randn(7, 8, 16, cin)
+        monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", 0.0)
+        want = blk(x, gn_next=True)
+        frame_mib = 8 * 16 * max(cin, cout) * 4 / (1 << 20)
+        for per in (1, 2, 3, 7):
+            monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", per * frame_mib)
+            assert RL._chunk_frames(x, max(cin, cout)) == (None if per >= 7 else -(-7 // -(-7 // per)))
+            got = blk(x, gn_next=True)
+            assert torch.allclose(got, want, atol=1e-5, rtol=1e-5), (per, float((got - want).abs().max()))
+        dst = torch.zeros(7, 8, 16, cout + 8)
+        monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", 2 * frame_mib)
+        blk(x, out=dst[..., :cout])
+        assert torch.allclose(dst[..., :cout], want, atol=1e-5, rtol=1e-5) and float(dst[..., cout:].abs().max()) == 0.0
