@@ -12,8 +12,6 @@
 // Roll / partition / reverse are address arithmetic (tok[]), the relative-position bias is a dense
 // (heads,N,N) fp32 table read as float4, the 9-region mask is two region-id compares.  Online softmax over
 // 48-key groups (one cross-lane-group max per group), exp2 domain.
-#include <atomic>
-
 #include "common.h"
 #include "pgt_internal.h"
 
@@ -294,225 +292,6 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
     }
 }
 
-// ---- persistent form of the model's case (48-token windows, 8 heads of 32 channels, power-of-two window grid, wd == D) ----
-// One 8-wave workgroup per CU for the whole launch; wave h is head h and walks the windows blockIdx.x, + gridDim.x, ...  A wave
-// shares nothing with the others (its token / region table, its V^T image and its head's bias rows are wave-private LDS), so
-// there is no barrier; while it multiplies window i its loads of window i + 1 (Q, K and the V rows, held in registers until
-// the V^T image is free) are in flight - the per-window kernel above spends half of a wave's life waiting for exactly those
-// (SQ_WAIT_INST_ANY 10 k of 27 k cycles per wave, profiles/r4_window_attention_sq_counters.json).  The bias table of the head
-// is read from HBM / L2 once per wave instead of once per window.  Same arithmetic, instruction for instruction, as the
-// per-window kernel: outputs are bit-equal (tests/test_gpu_ops.py).
-struct WapGeo {
-    int T_, H, W, C, wh, ww, sh, sw, qlo, olo, nwin;
-    int l_ww, l_wh, l_nwx, l_nwy;
-};
-
-template <bool X3, bool F16>
-__global__ __launch_bounds__(512, 1) void window_attn_persist_kernel(const uint16_t* __restrict__ qkv, int ldqkv,
-                                                                     uint16_t* __restrict__ out, int ldo,
-                                                                     const float* __restrict__ bias, WapGeo ge) {
-    typedef El<F16 || X3> EL;
-    constexpr int HD = 32, N = 48, VSTR = N * 2 + 8, DT = HD / 16, NP = X3 ? 2 : 1;
-    constexpr int BST = 52;                               // bias row pitch in LDS (floats): 16 rows x 16 bytes hit 64 banks
-    constexpr int VWORK = NP * (N / 2) * (HD / 8);         // V staging work items of a head: 96 (192 split)
-    constexpr int VIT = (VWORK + 63) / 64;
-    constexpr float LOG2E = 1.44269504088896340736f;
-    extern __shared__ __attribute__((aligned(16))) char wap_smem[];
-    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, col = lane & 15;
-    float* const bl = reinterpret_cast<float*>(wap_smem) + head * (N * BST);
-    char* const vt = wap_smem + 8 * N * BST * 4 + head * (NP * HD * VSTR);
-    int* const tr = reinterpret_cast<int*>(wap_smem + 8 * N * BST * 4 + 8 * NP * HD * VSTR) + head * (4 * N);   // [2][tok | region]
-    const bool shifted = (ge.sh > 0) || (ge.sw > 0);
-    const float scale = X3 ? 1.0f / sqrtf((float)HD) : rsqrtf((float)HD);
-
-    for (int i = lane; i < N * (N / 4); i += 64) {         // this head's (N, N) bias rows, once
-        const int row = i / (N / 4), c4 = i % (N / 4);
-        *reinterpret_cast<float4*>(bl + row * BST + c4 * 4) = *reinterpret_cast<const float4*>(bias + ((long)head * N + row) * N + c4 * 4);
-    }
-
-    uint4 q[3], k[3], ql[X3 ? 3 : 1], kl[X3 ? 3 : 1], v[VIT][2];
-    int tq[3];
-    // token / region table of window w into buffer `buf`, then the loads of that window into the registers above
-    auto request = [&](int w, int buf) {
-        int* const tk = tr + buf * (2 * N);
-        if (lane < N) {
-            const int wx = w & ((1 << ge.l_nwx) - 1), wy = (w >> ge.l_nwx) & ((1 << ge.l_nwy) - 1), b = w >> (ge.l_nwx + ge.l_nwy);
-            const int s = lane & (ge.ww - 1), r = (lane >> ge.l_ww) & (ge.wh - 1), d = lane >> (ge.l_ww + ge.l_wh);
-            const int ys = wy * ge.wh + r, xs = wx * ge.ww + s;
-            int y = ys + ge.sh, x = xs + ge.sw;
-            y = y >= ge.H ? y - ge.H : y; x = x >= ge.W ? x - ge.W : x;
-            const int rh = ys < ge.H - ge.wh ? 0 : (ys < ge.H - ge.sh ? 1 : 2);
-            const int rw = xs < ge.W - ge.ww ? 0 : (xs < ge.W - ge.sw ? 1 : 2);
-            tk[lane] = ((b * ge.T_ + d) * ge.H + y) * ge.W + x;
-            tk[N + lane] = rh * 3 + rw;
-        }
-#pragma unroll
-        for (int qt = 0; qt < 3; ++qt) {
-            tq[qt] = tk[qt * 16 + col];
-            const uint16_t* qrow = qkv + (long)tq[qt] * ldqkv + head * HD + g * 8;
-            q[qt] = *reinterpret_cast<const uint4*>(qrow);
-            k[qt] = *reinterpret_cast<const uint4*>(qrow + ge.C);
-            if constexpr (X3) {
-                ql[qt] = *reinterpret_cast<const uint4*>(qrow + ge.qlo);
-                kl[qt] = *reinterpret_cast<const uint4*>(qrow + ge.C + ge.qlo);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < VIT; ++j) {
-            const int it = lane + 64 * j;
-            if (VWORK % 64 == 0 || it < VWORK) {
-                const int pl = it / ((N / 2) * (HD / 8)), it2 = it % ((N / 2) * (HD / 8));
-                const int kp = it2 / (HD / 8), c = it2 % (HD / 8);
-                const uint16_t* vb = qkv + pl * ge.qlo + 2 * ge.C + head * HD + c * 8;
-                v[j][0] = *reinterpret_cast<const uint4*>(vb + (long)tk[2 * kp] * ldqkv);
-                v[j][1] = *reinterpret_cast<const uint4*>(vb + (long)tk[2 * kp + 1] * ldqkv);
-            }
-        }
-    };
-
-    int w = blockIdx.x, buf = 0;
-    if (w < ge.nwin) request(w, 0);
-    for (; w < ge.nwin; w += gridDim.x, buf ^= 1) {
-        // ---- V^T image of this window from the registers (dword = {V[2kp][d], V[2kp+1][d]})
-#pragma unroll
-        for (int j = 0; j < VIT; ++j) {
-            const int it = lane + 64 * j;
-            if (VWORK % 64 == 0 || it < VWORK) {
-                const int pl = it / ((N / 2) * (HD / 8)), it2 = it % ((N / 2) * (HD / 8));
-                const int kp = it2 / (HD / 8), c = it2 % (HD / 8);
-                const uint32_t a[4] = {v[j][0].x, v[j][0].y, v[j][0].z, v[j][0].w};
-                const uint32_t bb[4] = {v[j][1].x, v[j][1].y, v[j][1].z, v[j][1].w};
-                char* vp = vt + pl * HD * VSTR;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    *reinterpret_cast<uint32_t*>(vp + (c * 8 + 2 * jj) * VSTR + kp * 4) = (a[jj] & 0xffffu) | (bb[jj] << 16);
-                    *reinterpret_cast<uint32_t*>(vp + (c * 8 + 2 * jj + 1) * VSTR + kp * 4) = (a[jj] >> 16) | (bb[jj] & 0xffff0000u);
-                }
-            }
-        }
-        // ---- this window's operands into their own registers, then the next window's loads take the others' place
-        uint4 qf[3], kf[3], qlf[X3 ? 3 : 1], klf[X3 ? 3 : 1];
-        int tqc[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            qf[t] = q[t]; kf[t] = k[t]; tqc[t] = tq[t];
-            if constexpr (X3) { qlf[t] = ql[t]; klf[t] = kl[t]; }
-        }
-        const int* const rg = tr + buf * (2 * N) + N;
-        int rq[3], rk[3][4];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            rq[t] = rg[t * 16 + col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rk[t][r] = rg[t * 16 + 4 * g + r];
-        }
-        if (w + (int)gridDim.x < ge.nwin) request(w + gridDim.x, buf ^ 1);
-
-#pragma unroll
-        for (int qt = 0; qt < 3; ++qt) {
-            f32x4 sc[3];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt) {
-                sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (X3) {   // small terms first
-                    sc[kt] = EL::mma32(klf[kt], qf[qt], sc[kt]);
-                    sc[kt] = EL::mma32(kf[kt], qlf[qt], sc[kt]);
-                }
-                sc[kt] = EL::mma32(kf[kt], qf[qt], sc[kt]);
-                const float4 bv = *reinterpret_cast<const float4*>(bl + (qt * 16 + col) * BST + kt * 16 + 4 * g);
-                const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float val = sc[kt][r] * scale + bvv[r];
-                    if (shifted && rk[kt][r] != rq[qt]) val += -100.0f;
-                    val *= LOG2E;
-                    sc[kt][r] = val;
-                    mx = fmaxf(mx, val);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // (the per-window kernel's online-softmax step with m = -inf, l = 0, o = 0: alpha = exp2(-inf) = 0)
-            const float mnew = fmaxf(-INFINITY, mx);
-            float lsum = 0.f;
-            uint2 pf[3], pl2[X3 ? 3 : 1];
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt) {
-                float pr[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pr[r] = __builtin_amdgcn_exp2f(sc[kt][r] - mnew);
-                    lsum += pr[r];
-                }
-                pf[kt] = make_uint2(EL::pack2(pr[0], pr[1]), EL::pack2(pr[2], pr[3]));
-                if constexpr (X3) {
-                    x3_opaque(pf[kt].x);
-                    x3_opaque(pf[kt].y);
-                    const float r0 = pr[0] - EL::lo_of(pf[kt].x), r1 = pr[1] - EL::hi_of(pf[kt].x);
-                    const float r2 = pr[2] - EL::lo_of(pf[kt].y), r3 = pr[3] - EL::hi_of(pf[kt].y);
-                    pl2[kt] = make_uint2(EL::pack2(r0, r1), EL::pack2(r2, r3));
-                }
-            }
-            float lt = 0.f * 0.f + lsum;
-            lt += __shfl_xor(lt, 16, 64);
-            lt += __shfl_xor(lt, 32, 64);
-            const float inv = 1.0f / lt;
-            uint16_t* orow = out + (long)tqc[qt] * ldo + head * HD + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt) {
-                    const uint2 a = *reinterpret_cast<const uint2*>(vt + (dt * 16 + col) * VSTR + (kt * 16 + 4 * g) * 2);
-                    if constexpr (X3) {
-                        const uint2 al = *reinterpret_cast<const uint2*>(vt + HD * VSTR + (dt * 16 + col) * VSTR + (kt * 16 + 4 * g) * 2);
-                        o = EL::mma16(al, pf[kt], o);
-                        o = EL::mma16(a, pl2[kt], o);
-                    }
-                    o = EL::mma16(a, pf[kt], o);
-                }
-                const float v0 = o[0] * inv, v1 = o[1] * inv, v2 = o[2] * inv, v3 = o[3] * inv;
-                uint2 w2 = make_uint2(EL::pack2(v0, v1), EL::pack2(v2, v3));
-                if constexpr (X3) { x3_opaque(w2.x); x3_opaque(w2.y); }
-                *reinterpret_cast<uint2*>(orow + dt * 16) = w2;
-                if constexpr (X3) {
-                    const uint2 wl = make_uint2(EL::pack2(v0 - EL::lo_of(w2.x), v1 - EL::hi_of(w2.x)),
-                                                EL::pack2(v2 - EL::lo_of(w2.y), v3 - EL::hi_of(w2.y)));
-                    *reinterpret_cast<uint2*>(orow + ge.olo + dt * 16) = wl;
-                }
-            }
-        }
-    }
-}
-
-constexpr int wap_lds_bytes(bool x3) { return 8 * 48 * 52 * 4 + 8 * (x3 ? 2 : 1) * 32 * (48 * 2 + 8) + 8 * 4 * 48 * 4; }
-
-template <bool X3, bool F16>
-int launch_wap(const void* qkv, int ldqkv, void* out, int ldo, const float* bias, const WapGeo& ge, hipStream_t st) {
-    constexpr int bytes = wap_lds_bytes(X3);
-    static std::atomic<unsigned long long> attr_set{0};
-    static std::atomic<int> n_cu{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_persist_kernel<X3, F16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) { pgt_set_error("window attention: cannot reserve %d B of LDS: %s", bytes, hipGetErrorString(e)); return -12; }
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { pgt_set_error("window attention: hipGetDeviceProperties failed"); return -12; }
-        n_cu.store(prop.multiProcessorCount, std::memory_order_relaxed);
-        attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
-    }
-    const int cus = n_cu.load(std::memory_order_relaxed);
-    const int grid = ge.nwin < cus ? ge.nwin : cus;
-    hipLaunchKernelGGL((window_attn_persist_kernel<X3, F16>), dim3(grid), dim3(512), bytes, st, (const uint16_t*)qkv, ldqkv,
-                       (uint16_t*)out, ldo, bias, ge);
-    PGT_LAUNCH_CHECK();
-    return 0;
-}
-
-constexpr int kDefaultPersist = 0;
 constexpr int kDefaultHpw = 8;      // measured on MI355X: 1 -> 8 heads per workgroup -5 ... -8 % (profiles/r4_g_window_attention_hpw.jsonl)
 
 }  // namespace
@@ -535,15 +314,6 @@ int pgt_window_attn_mfma(int mode, const void* qkv, int ldqkv, void* out, int ld
     const int grid = B * (D / wd) * (H / wh) * (W / ww) * (heads / hpw);
     sd %= D; sh %= H; sw %= W;      // (the kernel rolls by one conditional subtraction)
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
-    // the persistent form: the model's layers (48 tokens, 8 heads x 32, power-of-two window grid, all frames in one window)
-    static const int env_persist = [] { const char* e = getenv("PGT_WATTN_PERSIST"); return e ? atoi(e) : -1; }();
-    if ((env_persist < 0 ? kDefaultPersist : env_persist) && nw == 1 && hd == 32 && heads == 8 && wd == D && sd == 0 && lg(ww) >= 0 &&
-        lg(wh) >= 0 && lg(W / ww) >= 0 && lg(H / wh) >= 0 && (long)B * D * H * W < (1l << 31)) {
-        WapGeo ge{D, H, W, C, wh, ww, sh, sw, qlo, olo, B * (H / wh) * (W / ww), lg(ww), lg(wh), lg(W / ww), lg(H / wh)};
-        if (mode == 1) return launch_wap<true, false>(qkv, ldqkv, out, ldo, bias, ge, st);
-        if (mode == 2) return launch_wap<false, true>(qkv, ldqkv, out, ldo, bias, ge, st);
-        return launch_wap<false, false>(qkv, ldqkv, out, ldo, bias, ge, st);
-    }
     int p2 = 0;
     if (lg(ww) >= 0 && lg(wh) >= 0 && lg(W / ww) >= 0 && lg(H / wh) >= 0 && lg(heads) >= 0 && wd == D)
         p2 = (1 << 30) | lg(ww) | (lg(wh) << 5) | (lg(W / ww) << 10) | (lg(H / wh) << 15) | (lg(heads / hpw) << 20);
