@@ -202,6 +202,13 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) rk[kt][r] = reg[kg * 48 + kt * 16 + 4 * g + r];
+        float4 bvs[3][3];        // the group's bias rows requested together, ahead of the products that want them (-4 %, round 4)
+#pragma unroll
+        for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+                bvs[qt][kt] = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + kg * 48 + kt * 16 + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks every load to its use)
 #pragma unroll
         for (int qt = 0; qt < 3; ++qt) {
             f32x4 s[3];
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
                     }
                     s[kt] = EL::mma32(kf[kt][ks], qf[qt][ks], s[kt]);
                 }
-                const float4 bv = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + kg * 48 + kt * 16 + 4 * g);
+                const float4 bv = bvs[qt][kt];
                 const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
