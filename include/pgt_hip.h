@@ -73,7 +73,7 @@ typedef struct pgt_conv_desc {
     int32_t out_f32;            /* 1: store y as fp32 even when dtype is bf16 (logits, distances) */
     int32_t force_bm, force_bn; /* 0 = heuristic; 64|128 pins the workgroup tile (tests, tuning)  */
     int32_t scalar_epilogue;    /* 1: force the element-wise epilogue (A/B tests); 0 = 16-byte path when legal */
-    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-input-channel 3x3 with the weights in registers (bf16 / half; split-half: Cout % 16 == 0); 7 = streaming linear for Cin == 256, Cout % 256 == 0 (bf16 / half, plain epilogue, 16-bit output): weights in registers, rows through LDS */
+    int32_t kernel;             /* 0 = auto; 1 = register-staged v1; 2 = LDS-DMA v2 (bf16, Cin % 64 == 0); 4 = phased v4; 5 = v4 + horizontal tap reuse; 6 = 64-input-channel 3x3 with the weights in registers (bf16 / half; split-half: Cout % 16 == 0); 7 = streaming linear for Cin == 256, Cout % 256 == 0 (bf16 / half, plain epilogue, 16-bit output): weights in registers, rows through LDS; 8 = the layers of 6 at W >= 128 with a ring of row images in LDS (every input row staged once), bias (+ residual) epilogue from registers, optional fused input affine (pgt_conv2d_affine_in) */
     int32_t splitk;             /* 0 = auto (needs a workspace); 1 = never; 2..16 = that many K slices           */
     int32_t stages;             /* unused (was the LDS pipeline depth of the removed kernel = 3)               */
     /* output placement: row index of output pixel m = orow_mul*m + orow_xmul*(m % Wo) + orow_off (orow_mul = 0: dense,
@@ -110,7 +110,8 @@ typedef struct pgt_conv_desc {
     int32_t out_split;          /* dtype == PGT_F32 only: store y as split-half planes [hi | lo] (lo plane y_lo elements after
                                  * the hi plane, ldy in 16-bit elements) instead of fp32 - the exact-fp32 first conv of the encoder
                                  * (3 input channels) feeding the split-half levels without a conversion pass
-                                 * (archs/tdcrqvae3_arch.py:540-546).  16-byte epilogue only (Cout % 8 == 0), no split-K.        */
+                                 * (archs/tdcrqvae3_arch.py:540-546).  16-byte epilogue only: Cout % 8 == 0, y / ldy 16-byte aligned,
+                                 * y_lo % 8 == 0, no residual, no split-K (anything else: -22).                                     */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -131,6 +132,19 @@ size_t pgt_conv_gn_workspace_bytes(int32_t N, int32_t nsub, int32_t HWsub, int32
 int pgt_conv2d_gn(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
                   const void* residual, const void* sft_dec, const void* sft_shift, void* y,
                   float* gn_workspace, void* workspace, size_t workspace_bytes, pgt_stream_t stream);
+
+/* The conv of act(x * in_scale[n][c] + in_shift[n][c]): the GroupNorm apply + SiLU of the Normalize that PRECEDES the conv
+ * (conv1 / conv2 of TDResnetBlock, modules/rstt_layers.py:875-904 with Normalize / nonlinearity :754-758; norm_out -> conv_out,
+ * archs/tdcrqvae3_arch.py:672-707) fused into the operand load: the normalised tensor is never written.  in_scale / in_shift:
+ * fp32 (N, Cin), the output of pgt_groupnorm_affine / pgt_groupnorm_from_partials; in_act: PGT_ACT_NONE or PGT_ACT_SILU.
+ * Exists for the launches pgt_conv2d_affine_in_ok(d) accepts (returns 1): single-plane 16-bit dtypes, 3x3 stride 1 pad 1 same
+ * size, Cin == 64, Cout <= 64, W >= 128 and H >= 4 powers of two, epilogue = bias (+ residual; bias_rows allowed) without
+ * activation, 16-byte aligned rows unless Cout <= 32 - the full-resolution level, where a separate apply pass costs as much HBM
+ * traffic as the conv itself.  Results equal pgt_affine_act followed by pgt_conv2d bit for bit in the operand (same arithmetic,
+ * one rounding to the 16-bit type); the accumulation order is that of kernel 8.  Other launches: -22, run the two calls.        */
+int pgt_conv2d_affine_in_ok(const pgt_conv_desc* d);
+int pgt_conv2d_affine_in(const pgt_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, int32_t in_act,
+                         const void* w, const float* bias, const void* residual, void* y, pgt_stream_t stream);
 
 /* ---- normalisation ---------------------------------------------------------------------------
  * GroupNorm(groups, eps) statistics -> per-(n,c) affine so that GN(x) = x*scale + shift
@@ -171,6 +185,14 @@ int pgt_sampled_channel_mean(int32_t dtype, const void* x, int32_t ldx, int32_t 
 int pgt_sampled_pixel(int32_t HW, int32_t i);
 int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* bias, int32_t R, int32_t K, int32_t Cout,
                         float* out, pgt_stream_t stream);
+/* pgt_sampled_channel_mean + pgt_mean_field_bias in ONE launch (each of the two is at the launch-latency floor and sits in the
+ * dependency chain in front of a compensated layer): out[n][o] = bias[o] + sum_k defect_t[k][o] * mean_n[k], mean_n over frame
+ * n's pixel sample of x (N, HW, K; PGT_F16 / PGT_BF16) - or, with in_scale / in_shift (fp32 (N, K)), of the operand a layer
+ * fed through pgt_conv2d_affine_in multiplies: in_act(x * in_scale + in_shift) rounded to the tensor's type.  One workgroup per
+ * frame, fixed summation order (lanes, then K slices): deterministic.  K % 8 == 0, K <= 3840. */
+int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t K, const float* in_scale,
+                   const float* in_shift, int32_t in_act, const float* defect_t, const float* bias, int32_t Cout, float* out,
+                   pgt_stream_t stream);
 /* pgt_weight_defect: the (K x Cout) fp32 operand `defect_t` of pgt_mean_field_bias for a layer, from its fp32 reference weight
  * (Cout, Cin, KH, KW) (x out_scale[o] where given, e.g. the BatchNorm fold) and the packed 16-bit operand pgt_pack_conv_weight
  * wrote for it: defect_t[k][o] = sum over taps of (w * scale - packed)[o][k][tap], K = Cin_pad; sum_taps = 0 keeps one row per

@@ -499,7 +499,7 @@ class Decoder(HipModule):
             return h
         # the restored frames leave the last conv in fp32 whatever the decoder's storage type (3 channels: free), so the
         # 16-bit modes do not add an output rounding (2^-12 of [0, 1] in half) on top of their arithmetic
-        return self.conv_out.run(self.norm_out.run(h, ACT_SILU), out_f32=True)
+        return self.conv_out.run(h, affine_in=self.norm_out.coeffs(h, ACT_SILU), out_f32=True)
 
 
 class HubMixin:

@@ -14,4 +14,4 @@ void pgt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pgt_last_error(void) { return g_err; }
-extern "C" const char* pgt_version(void) { return "pgt_hip 0.1 (gfx950)"; }
+extern "C" const char* pgt_version(void) { return "pgt_hip 0.2 (gfx950)"; }

@@ -14,6 +14,8 @@
 // LDS rows are padded 128->144 B so the ds_read_b128 fragment reads and ds_write_b128 staging
 // writes are bank-conflict free.  bf16 uses v_mfma_f32_32x32x16_bf16, f32 uses the exact
 // v_mfma_f32_32x32x2_f32 (parity mode); both accumulate in fp32.
+#include <cstdlib>
+
 #include "common.h"
 #include "pgt_internal.h"
 #include "igemm_common.h"
@@ -423,6 +425,31 @@ static int planned_splitk(const pgt_conv_desc* d) {
 
 // statistics workspace of the call in flight on this thread (set by pgt_conv2d_gn around pgt_conv2d_ws)
 static thread_local float* g_gn_ws = nullptr;
+// per-(image, channel) affine + activation applied to the operand on load (set by pgt_conv2d_affine_in around pgt_conv2d_ws)
+static thread_local const float* g_in_scale = nullptr;
+static thread_local const float* g_in_shift = nullptr;
+static thread_local int g_in_act = 0;
+
+// A/B switch of the ring kernel for the 64-channel 3x3 layers at W >= 128 (igemm8.hip): PGT_C64_RING=0 keeps igemm6 on them
+static bool use_ring_kernel() {
+    static const bool on = [] {
+        const char* e = getenv("PGT_C64_RING");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// igemm8.hip covers this launch (single-plane 16-bit 3x3, Cin == 64, Cout <= 64, stride 1, same size, W >= 128, bias (+ residual)
+// epilogue); `aligned`: every epilogue operand allows 16-byte accesses (else only the <= 32-output-channel form, which stores
+// element-wise: conv_out)
+static bool ring_legal(const pgt_conv_desc* d, bool aligned, bool has_res) {
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    return (d->dtype == PGT_BF16 || d->dtype == PGT_F16) && d->orow_mul == 0 && d->Cin == 64 && d->Cout >= 1 && d->Cout <= 64 &&
+           d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ups == 0 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H &&
+           d->Wo == d->W && pow2(d->W) && pow2(d->H) && d->W >= 128 && d->H >= 4 && d->ldx % 8 == 0 && d->epi == 0 && d->act == 0 &&
+           !d->post_relu && d->gn_groups == 0 && d->splitk <= 1 && d->force_bm == 0 && d->force_bn == 0 && (aligned || d->Cout <= 32) &&
+           (!has_res || (long)d->N * d->H * d->W * d->ldr * 2 < (1L << 32));
+}
 
 extern "C" size_t pgt_conv2d_workspace_bytes(const pgt_conv_desc* d) {
     if (!d) return 0;
@@ -460,6 +487,7 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.M = d->N * d->Ho * d->Wo;
     p.K = d->KH * d->KW * d->Cin * (x3 ? (d->x3_fold ? 2 : 3) : 1);
     p.gn_part = nullptr; p.gn_hdr = nullptr; p.gn_cpg = p.gn_G = p.gn_maxblk = p.gn_hw = 0;
+    p.in_scale = g_in_scale; p.in_shift = g_in_shift; p.in_act = g_in_act;
     if (d->gn_groups > 0) {
         PGT_CHECK(g_gn_ws != nullptr, "pgt_conv2d: gn_groups set without a statistics workspace (use pgt_conv2d_gn)");
         PGT_CHECK(d->Cout % d->gn_groups == 0 && d->Cout % 8 == 0 && d->gn_nsub >= 1 && d->gn_nsub <= 8 && d->gn_sub >= 0 &&
@@ -484,9 +512,6 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.nw = (x3 && d->x3_fold) ? 128 : d->Cout;
     p.bias_rows = d->bias_rows;
     p.out_split = d->out_split ? 1 : 0;
-    PGT_CHECK(!d->out_split || (d->dtype == PGT_F32 && d->Cout % 8 == 0 && !d->scalar_epilogue && d->epi == 0 && !d->out_f32 && d->orow_mul == 0 &&
-                                d->splitk <= 1 && d->ldy % 8 == 0 && (((uintptr_t)y) & 15) == 0),
-              "pgt_conv2d: out_split needs dtype PGT_F32, Cout %% 8 == 0, the plain 16-byte epilogue, no split-K, 16-byte aligned rows");
     PGT_CHECK(d->bias_rows == 0 || (bias && d->bias_rows > 0 && d->bias_rows % 512 == 0 && p.M % d->bias_rows == 0 && !x3 &&
                                     d->kernel != 2 && d->kernel != 3),
               "pgt_conv2d: bias_rows=%d (a bias vector per frame) needs a bias, a multiple of 512 rows that divides M=%d, a single-plane dtype and kernel 0, 1, 4, 5 or 6", d->bias_rows, p.M);
@@ -507,7 +532,23 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     auto al = [](const void* ptr, int ld) { return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && ld % 8 == 0); };
     p.vec_epi = (d->Cout % 8 == 0) && al(y, d->ldy) && al(residual, d->ldr) &&
                 (d->epi == 0 || (al(sft_dec, d->ld_dec) && al(sft_shift, d->ld_shift))) && !d->scalar_epilogue;
+    // split-half planes out of the fp32 kernel exist in the 16-byte epilogue only (the element-wise epilogue would write fp32
+    // into the half buffer): checked AFTER vec_epi is known, and the lo plane must start on a 16-byte boundary
+    PGT_CHECK(!d->out_split || (d->dtype == PGT_F32 && p.vec_epi && !residual && d->epi == 0 && !d->out_f32 && d->orow_mul == 0 &&
+                                d->splitk <= 1 && p.ylo % 8 == 0),
+              "pgt_conv2d: out_split needs dtype PGT_F32, Cout %% 8 == 0, the plain 16-byte epilogue without residual, no split-K, "
+              "16-byte aligned rows and y_lo %% 8 == 0");
     hipStream_t st = (hipStream_t)stream;
+
+    // ---- the 64-channel 3x3 layers of the 512x512 level: ring of row images, optional fused input affine (igemm8.hip)
+    {
+        const bool v8 = ring_legal(d, p.vec_epi != 0, residual != nullptr);
+        PGT_CHECK(d->kernel != 8 || v8, "pgt_conv2d: kernel=8 needs a single-plane 16-bit 3x3 stride-1 same-size conv, Cin == 64, Cout <= 64, "
+                  "W >= 128 and H >= 4 powers of two, bias (+ residual) epilogue without activation, 16-byte aligned rows unless Cout <= 32");
+        PGT_CHECK(!p.in_scale || (v8 && (d->kernel == 0 || d->kernel == 8) && p.in_shift && (p.in_act == ACT_NONE || p.in_act == ACT_SILU)),
+                  "pgt_conv2d_affine_in: this launch has no fused-operand form (pgt_conv2d_affine_in_ok), or in_act is neither none nor SiLU");
+        if (v8 && (d->kernel == 8 || p.in_scale || (d->kernel == 0 && use_ring_kernel()))) return pgt_igemm8_launch(&p, st);
+    }
 
     if (x3) {   // split-half operands: the phase-interleaved LDS-DMA kernel with the three-segment K order
         PGT_CHECK(d->Cin % 64 == 0 && d->ups == 0 && d->KH * d->KW <= 30,
@@ -638,6 +679,20 @@ extern "C" int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, 
                           const void* residual, const void* sft_dec, const void* sft_shift, void* y,
                           pgt_stream_t stream) {
     return pgt_conv2d_ws(d, x, w, bias, residual, sft_dec, sft_shift, y, nullptr, 0, stream);
+}
+
+extern "C" int pgt_conv2d_affine_in_ok(const pgt_conv_desc* d) {
+    return d && ring_legal(d, true, false) ? 1 : 0;
+}
+
+extern "C" int pgt_conv2d_affine_in(const pgt_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                                    int32_t in_act, const void* w, const float* bias, const void* residual, void* y,
+                                    pgt_stream_t stream) {
+    PGT_CHECK(d && in_scale && in_shift, "pgt_conv2d_affine_in: null argument");
+    g_in_scale = in_scale; g_in_shift = in_shift; g_in_act = in_act;
+    const int rc = pgt_conv2d_ws(d, x, w, bias, residual, nullptr, nullptr, y, nullptr, 0, stream);
+    g_in_scale = g_in_shift = nullptr; g_in_act = 0;
+    return rc;
 }
 
 extern "C" size_t pgt_conv_gn_workspace_bytes(int32_t N, int32_t nsub, int32_t HWsub, int32_t groups) {

@@ -58,6 +58,11 @@ struct ConvP {
     float* gn_part;
     float* gn_hdr;
     int gn_cpg, gn_G, gn_maxblk, gn_hw;
+    // the operand is in_act(x * in_scale[n][c] + in_shift[n][c]) (fp32 (N, Cin) each): the GroupNorm apply + SiLU of the
+    // Normalize that precedes the conv, fused into the operand load (pgt_conv2d_affine_in; igemm8.hip only)
+    const float* in_scale;
+    const float* in_shift;
+    int in_act;
 };
 
 // bias vector of output pixel m: shared, or the one of m's frame (pgt_conv_desc::bias_rows; a workgroup tile never straddles

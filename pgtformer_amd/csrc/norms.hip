@@ -599,6 +599,89 @@ __global__ __launch_bounds__(256) void mean_field_bias_kernel(const float* __res
     }
 }
 
+// Sampled mean AND the matrix-vector product in ONE launch (round 5: the two launches above are each at the launch-latency
+// floor, 11-18 us, and sit in the dependency chain in front of every compensated layer): out[n][o] = bias[o] +
+// sum_k defect_t[k][o] * mean_n[k], mean_n[k] over frame n's pixel sample of the layer's operand - x itself, or
+// T(in_act(x * in_scale[n][k] + in_shift[n][k])) when the layer reads its operand through the fused GroupNorm apply
+// (pgt_conv2d_affine_in: the normalised tensor never exists).  One workgroup of 1024 threads per frame: K / 8 channel chunks
+// x PL pixel lanes (all loads of a thread are independent: up to 8 in flight), per-lane sums reduced over the lanes in lane
+// order, then Cout outputs x KS slices of K reduced in slice order: no atomics, one fixed order whatever the grid.
+template <typename T>
+__global__ __launch_bounds__(1024) void frame_bias_kernel(const T* __restrict__ x, int ldx, int HW, int K, const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift, int in_act,
+                                                          const float* __restrict__ defect_t, const float* __restrict__ bias,
+                                                          int Cout, float* __restrict__ out) {
+    extern __shared__ float fbs[];                 // [PL][K] lane sums (then [KS][Cout-slice] partial products) | mean[K]
+    const int QC = K / 8;
+    const int PL = 1024 / QC < 1 ? 1 : 1024 / QC;
+    float* mean = fbs + (size_t)PL * K;
+    const int n = blockIdx.x;
+    int run, cells, cell;
+    mean_sample_geometry(HW, &run, &cells, &cell);
+    const int S = cells * run;
+    for (int q0 = 0; q0 < QC; q0 += 1024) {        // (K > 8192: more than one chunk per thread; not a shape of this model)
+        const int q = q0 + (int)threadIdx.x % QC, pl = (int)threadIdx.x / QC;
+        if (q < QC && pl < PL) {
+            float acc[8], sc[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+            if (in_scale) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sc[e] = in_scale[(long)n * K + q * 8 + e]; sh[e] = in_shift[(long)n * K + q * 8 + e]; }
+            }
+            const T* base = x + (long)n * HW * ldx + q * 8;
+#pragma unroll 8
+            for (int i = pl; i < S; i += PL) {
+                float v[8];
+                RowIO<T, 8, sizeof(T) == 2>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
+                if (in_scale) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                    act_vec<T, 8>(v, in_act);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {      // the rounding the consuming kernel applies to its operand
+                        T r;
+                        stf(&r, v[e]);
+                        v[e] = ldf(&r);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fbs[(size_t)pl * K + q * 8 + e] = acc[e];
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 1024) {
+        float t = 0.f;
+        for (int l = 0; l < PL; ++l) t += fbs[(size_t)l * K + k];
+        mean[k] = t / (float)S;
+    }
+    __syncthreads();
+    // out: 1024 threads = OL outputs x KS slices of K
+    const int OL = Cout >= 1024 ? 1024 : (Cout >= 512 ? 512 : (Cout >= 256 ? 256 : (Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32))));
+    const int KS = 1024 / OL;
+    const int ol = threadIdx.x % OL, ks = threadIdx.x / OL;
+    const int kq = (K + KS - 1) / KS, k0 = ks * kq, k1 = k0 + kq < K ? k0 + kq : K;
+    for (int o0 = 0; o0 < Cout; o0 += OL) {
+        const int o = o0 + ol;
+        float a = 0.f;
+        if (o < Cout) {
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) a += defect_t[(long)k * Cout + o] * mean[k];
+        }
+        __syncthreads();                           // (the lane sums / the previous slice's partial products are consumed)
+        fbs[ks * OL + ol] = a;
+        __syncthreads();
+        if (ks == 0 && o < Cout) {
+            float t = bias ? bias[o] : 0.f;
+            for (int j = 0; j < KS; ++j) t += fbs[j * OL + ol];
+            out[(long)n * Cout + o] = t;
+        }
+    }
+}
+
 __global__ void adain_affine_kernel(const float* mc, const float* vc, const float* ms, const float* vs, float eps,
                                     float* scale, float* shift, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -849,6 +932,26 @@ extern "C" int pgt_mean_field_bias(const float* mean, const float* defect_t, con
     if (Cout > 32) hipLaunchKernelGGL(mean_field_bias_kernel<64>, dim3((Cout + 63) / 64, fb), dim3(256), lds, st, mean, defect_t, bias, R, K, Cout, out);
     else if (Cout > 8) hipLaunchKernelGGL(mean_field_bias_kernel<32>, dim3((Cout + 31) / 32, fb), dim3(256), lds, st, mean, defect_t, bias, R, K, Cout, out);
     else hipLaunchKernelGGL(mean_field_bias_kernel<8>, dim3((Cout + 7) / 8, fb), dim3(256), lds, st, mean, defect_t, bias, R, K, Cout, out);
+    PGT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t K, const float* in_scale,
+                              const float* in_shift, int32_t in_act, const float* defect_t, const float* bias, int32_t Cout,
+                              float* out, pgt_stream_t stream) {
+    PGT_CHECK(x && defect_t && out && N >= 1 && HW >= 1 && Cout >= 1, "frame_bias: null argument");
+    PGT_CHECK(K >= 8 && K % 8 == 0 && K <= 3840 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "frame_bias: K=%d (a multiple of 8, <= 3840) / ldx=%d / x alignment", K, ldx);
+    PGT_CHECK((in_scale == nullptr) == (in_shift == nullptr), "frame_bias: in_scale and in_shift go together");
+    const int QC = K / 8, PL = 1024 / QC < 1 ? 1 : 1024 / QC;
+    size_t lds = ((size_t)PL * K + K) * sizeof(float);
+    if (lds < (1024 + (size_t)K) * sizeof(float)) lds = (1024 + (size_t)K) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PGT_BF16)
+        hipLaunchKernelGGL((frame_bias_kernel<bf16_t>), dim3(N), dim3(1024), lds, st, (const bf16_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out);
+    else if (dtype == PGT_F16)
+        hipLaunchKernelGGL((frame_bias_kernel<half_t>), dim3(N), dim3(1024), lds, st, (const half_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out);
+    else
+        PGT_CHECK(false, "frame_bias: dtype %d (PGT_BF16 / PGT_F16: the compensated layers are the single-plane 16-bit ones)", dtype);
     PGT_LAUNCH_CHECK();
     return 0;
 }

@@ -27,3 +27,6 @@ int pgt_igemm6_launch(const void* conv_p, hipStream_t st);
 int pgt_igemm6x3_launch(const void* conv_p, hipStream_t st);
 // igemm7.hip: streaming linear for K = 256 on many rows (weights in registers, rows through LDS, two workgroups per CU)
 int pgt_igemm7_launch(const void* conv_params, hipStream_t st);
+// igemm8.hip: the same layers as igemm6 for W >= 128: a ring of row images in LDS (every input row staged once), weights as the
+// MFMA A operand, register epilogue; optionally the preceding GroupNorm apply + activation fused into the operand (ConvP::in_scale)
+int pgt_igemm8_launch(const void* conv_p, hipStream_t st);

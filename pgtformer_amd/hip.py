@@ -36,6 +36,8 @@ SIGNATURES = {
     "pgt_conv2d_ws": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
     "pgt_conv_gn_workspace_bytes": [i32, i32, i32, i32],
     "pgt_conv2d_gn": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+    "pgt_conv2d_affine_in_ok": [C.POINTER(ConvDesc)],
+    "pgt_conv2d_affine_in": [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, vp, vp, vp, vp],
     "pgt_groupnorm_from_partials": [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp],
     "pgt_groupnorm_workspace_bytes": [i32, i32, i32, i32],
     "pgt_groupnorm_affine": [i32, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp],
@@ -55,6 +57,7 @@ SIGNATURES = {
     "pgt_attn_proj_mlp": [i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, i32, vp],
     "pgt_attn_proj_mlp_sample_workspace_bytes": [i32, i32],
     "pgt_attn_proj_mlp_sample": [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp, vp, vp],
+    "pgt_frame_bias": [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp],
     "pgt_mean_field_bias": [vp, vp, vp, i32, i32, i32, vp, vp],
     "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pgt_window_attention3d": [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],

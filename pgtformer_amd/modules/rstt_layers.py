@@ -78,7 +78,7 @@ def _defect_t(w, pw, scale=None, sum_taps=True):
     return ops.weight_defect(w.detach().to(device=pw.device, dtype=torch.float32), pw, scale=scale, sum_taps=sum_taps)   # pgt_weight_defect
 
 
-def _frame_bias(x, pdef, pb, frames=None):
+def _frame_bias(x, pdef, pb, frames=None, affine_in=None):
     """bias operand of a layer: the (frames, Cout) per-frame bias of a compensated layer - x (N,H,W,C) image batch, or
     (rows, C) tokens of `frames` frames - or the plain (Cout,) bias `pb` when the layer is not compensated or its frames are
     not whole 512-row tiles (pgt_conv_desc::bias_rows)"""
@@ -92,6 +92,10 @@ def _frame_bias(x, pdef, pb, frames=None):
         x = x.as_strided((frames, x.shape[0] // frames, x.shape[1]), (x.stride(0) * (x.shape[0] // frames), x.stride(0), 1))
     elif (x.shape[1] * x.shape[2]) % 512:
         return pb
+    if ops.USE_FRAME_BIAS and x.dtype in (torch.float16, torch.bfloat16):
+        return ops.frame_bias(x, pdef, pb, affine_in=affine_in)        # one launch (pgt_frame_bias)
+    if affine_in is not None:
+        x = ops.affine_act(x, *affine_in)
     return ops.mean_field_bias(ops.sampled_channel_mean(x), pdef, pb)
 
 
@@ -142,11 +146,18 @@ class Conv2d(nn.Conv2d, HipModule):
         if fold:
             kw = dict(kw, x3_fold=True)
         if _is_x3f(self.dt):     # fp32 in / fp32 out, split-half MFMA arithmetic in between
+            assert kw.get("affine_in") is None
             return ops.conv2d(ops.to_x3(x), w, self.pb, kh=self.kernel_size[0], kw=self.kernel_size[1],
                               stride=self.stride[0], pad=self.pad4, x3=True, out_f32=True, **kw)
         b = self.pb
+        a_in = kw.get("affine_in")
+        if a_in is not None and not ops.affine_in_fuses(x, self.out_channels, self.kernel_size[0], self.kernel_size[1], self.stride[0], self.pad4,
+                                                        x3=_is_x3(self.dt), bias=b, **{k: v for k, v in kw.items() if k not in ("affine_in", "gn")}):
+            x = ops.affine_act(x, a_in[0], a_in[1], a_in[2], x3=_is_x3(self.dt))      # no fused-operand form for this launch: one apply pass
+            kw = {k: v for k, v in kw.items() if k != "affine_in"}
+            a_in = None
         if self.pdef is not None and self.stride == (1, 1) and not kw.get("ups"):     # (same-size layers: frames of H*W output pixels)
-            b = _frame_bias(x, self.pdef, self.pb)
+            b = _frame_bias(x, self.pdef, self.pb, affine_in=a_in)
         return ops.conv2d(x, w, b, kh=self.kernel_size[0], kw=self.kernel_size[1],
                           stride=self.stride[0], pad=self.pad4, x3=_is_x3(self.dt), **kw)
 
@@ -168,6 +179,12 @@ class GroupNorm(nn.GroupNorm, HipModule):
 
     def run(self, x, act=ACT_SILU, out=None):
         return ops.groupnorm_act(x, self.pg, self.pbeta, act, self.num_groups, self.eps, out=out, x3=_is_x3(self.dt))
+
+    def coeffs(self, x, act=ACT_SILU):
+        """the (scale, shift, act) of this GroupNorm + activation over x for a consumer that applies them itself
+        (Conv2d.run(..., affine_in=...)): statistics only, the normalised tensor is not written"""
+        scale, shift = ops.groupnorm_affine(x, self.pg, self.pbeta, self.num_groups, self.eps, x3=_is_x3(self.dt))
+        return scale, shift, act
 
 
 class LayerNorm(nn.LayerNorm, HipModule):
@@ -237,10 +254,11 @@ class TDResnetBlock(HipModule):
         per = _chunk_frames(x, max(self.in_channels, self.out_channels) * (2 if _is_x3(self.dt) else 1))
         if per is not None:
             return self._forward_chunked(x, per, out, gn_next)
-        h = self.conv1.run(self.norm1.run(x, ACT_SILU), gn=self.norm2.num_groups)
-        h = self.norm2.run(h, ACT_SILU)
+        # GroupNorm apply + SiLU ride in the consuming conv's operand load where the library has that form (the 64-channel
+        # 512x512 layers: Conv2d.run falls back to one apply pass elsewhere)
+        h = self.conv1.run(x, affine_in=self.norm1.coeffs(x, ACT_SILU), gn=self.norm2.num_groups)
         sc = self.nin_shortcut.run(x) if self.in_channels != self.out_channels else x
-        return self.conv2.run(h, res=sc, out=out, gn=32 if gn_next else None)
+        return self.conv2.run(h, affine_in=self.norm2.coeffs(h, ACT_SILU), res=sc, out=out, gn=32 if gn_next else None)
 
     def _forward_chunked(self, x, per, out, gn_next):
         """The same block over groups of `per` frames (every operation of it is per frame): the three intermediate maps are

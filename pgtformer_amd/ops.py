@@ -25,6 +25,11 @@ X3_PLANE = torch.float16
 # GroupNorm statistics from the producing conv's epilogue (PGT_EPILOGUE_GN=0: always the separate statistics pass)
 import os as _os
 USE_EPILOGUE_GN = _os.environ.get("PGT_EPILOGUE_GN", "1") != "0"
+# GroupNorm apply + SiLU inside the consuming conv's operand load where the library has that form (pgt_conv2d_affine_in:
+# the 64-channel 3x3 layers of the 512x512 level); PGT_FUSE_GN_APPLY=0: always the separate apply pass
+USE_FUSED_GN_APPLY = _os.environ.get("PGT_FUSE_GN_APPLY", "1") != "0"
+# sampled mean + mean-field bias in one launch (pgt_frame_bias); PGT_FRAME_BIAS=0: the two launches of round 3
+USE_FRAME_BIAS = _os.environ.get("PGT_FRAME_BIAS", "1") != "0"
 
 
 class GnStats:
@@ -322,7 +327,7 @@ def _tune_conv(d, args, device, iters=4, gn_ws=None):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False, out_x3=False):
+           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False, out_x3=False, affine_in=None):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout).
     out_parity=(py, px): write the (N,Ho,Wo,Cout) result to out[:, py::2, px::2, :] of a required (N,2Ho,2Wo,Cout) `out`
@@ -332,9 +337,17 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     gn: None, or a number of groups: the epilogue also reduces the GroupNorm statistics of the output, attached to the
     returned tensor as `._pgt_gn` (ops.GnStats) for the GroupNorm that follows; or (GnStats, sub) when several launches
     write one tensor (the caller binds the statistics to the tensor after the last launch).
-    out_x3: fp32 x / w, result stored as split-half planes (N,Ho,Wo,2*Cout) (pgt_conv_desc::out_split)."""
+    out_x3: fp32 x / w, result stored as split-half planes (N,Ho,Wo,2*Cout) (pgt_conv_desc::out_split).
+    affine_in=(scale, shift, act): the conv reads act(x * scale[n, c] + shift[n, c]) - the GroupNorm apply + SiLU of the
+    Normalize in front of it; fused into the operand load where the library has that form (affine_in_fuses), else one
+    affine_act pass."""
     n, h, wd, cin = x.shape
     cout = w.shape[0]
+    if affine_in is not None and not affine_in_fuses(x, cout, kh, kw, stride, pad, ups=ups, act=act, res=res, post_relu=post_relu, sft=sft,
+                                                    out=out, out_f32=out_f32, tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk,
+                                                    out_parity=out_parity, out_rows=out_rows, x3=x3, out_x3=out_x3, bias=bias):
+        x = affine_act(x, affine_in[0], affine_in[1], affine_in[2], x3=x3)
+        affine_in = None
     if out_x3:
         assert x.dtype == torch.float32 and not x3 and not out_f32 and sft is None and out_rows is None and out_parity is None and res is None
     if x3:   # split-half operands: x (N,H,W,2*Cin) = [hi | lo], w (Cout, kh*kw*3*Cin), y (N,Ho,Wo,2*Cout) unless out_f32
@@ -374,7 +387,8 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                    res=None if res is None else res[sl], post_relu=post_relu,
                    sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
                    tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3,
-                   gn=None if st is None else (st, 0, i), x3_fold=x3_fold, out_x3=out_x3)
+                   gn=None if st is None else (st, 0, i), x3_fold=x3_fold, out_x3=out_x3,
+                   affine_in=None if affine_in is None else (affine_in[0][sl], affine_in[1][sl], affine_in[2]))
         return out if st is None else st.bind(out, cst)
     hv, wv = (h * 2, wd * 2) if ups else (h, wd)
     ho = (hv + pad[0] + pad[1] - kh) // stride + 1
@@ -448,7 +462,14 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         d.kernel, (d.force_bm, d.force_bn), d.stages = cfg if cfg is not None else (0, (0, 0), 0)
     ws_bytes = L.pgt_conv2d_workspace_bytes(C.byref(d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None   # split-K scratch
-    if st is not None:
+    if affine_in is not None:
+        a_sc, a_sh, a_act = affine_in
+        assert st is None and sft is None and a_sc.shape == (n, cin) and a_sh.shape == (n, cin) and a_sc.is_contiguous() and a_sh.is_contiguous()
+        if not L.pgt_conv2d_affine_in_ok(C.byref(d)):
+            raise hip.PgtError("conv2d: ops.affine_in_fuses and pgt_conv2d_affine_in_ok disagree on this launch")
+        hip.check(L.pgt_conv2d_affine_in(C.byref(d), _p(x), _p(a_sc), _p(a_sh), int(a_act), _p(w), _p(bias), _p(res), _p(out), _stream()),
+                  "pgt_conv2d_affine_in")
+    elif st is not None:
         hip.check(L.pgt_conv2d_gn(C.byref(d), _p(x), _p(w), _p(bias), _p(res), _p(dec), _p(shift), _p(out), _p(st.ws), _p(ws),
                                   ws_bytes, _stream()), "pgt_conv2d_gn")
         if not isinstance(gn, tuple):
@@ -466,6 +487,32 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                      "shape": (n, h, wd, cin, cout, kh, stride, int(ups)), "events": (e0, e1),
                      "cfg": (d.kernel, d.force_bm, d.force_bn), "x3": bool(x3), "dt": str(x.dtype).replace("torch.", "")})
     return out
+
+
+def affine_in_fuses(x, cout, kh, kw, stride, pad, *, ups=False, act=ACT_NONE, res=None, post_relu=False, sft=None, out=None,
+                    out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, out_parity=None, out_rows=None, x3=False,
+                    out_x3=False, bias=None, **_other):
+    """Does the library have the fused-operand form (pgt_conv2d_affine_in) for this conv?  Mirror of ring_legal (csrc/igemm.hip)
+    - the library re-checks (pgt_conv2d_affine_in_ok) and conv2d raises if the two ever disagree."""
+    if not USE_FUSED_GN_APPLY or x3 or out_x3 or x.dtype not in (torch.float16, torch.bfloat16) or x.dim() != 4:
+        return False
+    n, h, wd, cin = x.shape
+    p2 = lambda v: v > 0 and (v & (v - 1)) == 0      # noqa: E731
+    if not (cin == 64 and 1 <= cout <= 64 and kh == 3 and kw == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) and not ups):
+        return False
+    if not (p2(wd) and p2(h) and wd >= 128 and h >= 4 and _ld_img(x) % 8 == 0):
+        return False
+    if act != ACT_NONE or post_relu or sft is not None or out_parity is not None or out_rows is not None or scalar_epi:
+        return False
+    if kernel not in (0, 8) or tuple(tile) != (0, 0) or splitk not in (0, 1):
+        return False
+    if n * h * wd * _ld_img(x) * x.element_size() >= (1 << 31):
+        return True if n > 1 else False       # (conv2d runs frame chunks: each chunk is asked again)
+    aligned = cout % 8 == 0 and (out is None or (_ld_img(out) % 8 == 0 and out.data_ptr() % 16 == 0)) and \
+        (res is None or (_ld_img(res) % 8 == 0 and res.data_ptr() % 16 == 0))
+    if res is not None and n * h * wd * _ld_img(res) * res.element_size() >= (1 << 32):
+        return False
+    return aligned or cout <= 32
 
 
 def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False, gn=None):
@@ -601,6 +648,23 @@ def mean_field_bias(mean, defect_t, bias=None):
     out = torch.empty((r, cout), dtype=torch.float32, device=mean.device)
     with _Prof("mean_field", 2.0 * r * k * cout, float(defect_t.numel() * 4)):
         hip.check(hip.lib().pgt_mean_field_bias(_p(mean), _p(defect_t), _p(bias), r, k, cout, _p(out), _stream()), "pgt_mean_field_bias")
+    return out
+
+
+def frame_bias(x, defect_t, bias=None, affine_in=None):
+    """(N, Cout) fp32 per-frame bias of a compensated 16-bit layer in ONE launch (pgt_frame_bias): bias + mean_n @ defect_t with
+    mean_n the sampled channel mean of frame n of x (N,H,W,K) / (N,HW,K) - or of act(x * scale + shift) rounded to x.dtype when
+    the layer reads its operand through the fused GroupNorm apply (affine_in=(scale, shift, act))."""
+    if x.dim() == 3:
+        x = x.unsqueeze(1)
+    n, h, w, k = x.shape
+    cout = defect_t.shape[1]
+    assert defect_t.shape[0] == k and defect_t.is_contiguous() and defect_t.dtype == torch.float32
+    out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    sc, sh, act = affine_in if affine_in is not None else (None, None, ACT_NONE)
+    with _Prof("mean_field", 2.0 * n * k * cout, float(n * min(h * w, 1024) * k * x.element_size() + defect_t.numel() * 4)):
+        hip.check(hip.lib().pgt_frame_bias(_dt(x), _p(x), _ld_img(x), n, h * w, k, _p(sc), _p(sh), int(act), _p(defect_t), _p(bias), cout,
+                                           _p(out), _stream()), "pgt_frame_bias")
     return out
 
 

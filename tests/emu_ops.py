@@ -121,7 +121,9 @@ def _store(val, out, dtype):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0, out_x3=False,
-           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False):
+           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False, affine_in=None):
+    if affine_in is not None:      # the fused operand (pgt_conv2d_affine_in) = the apply pass's result, rounded to the tensor's type
+        x = affine_act(x, affine_in[0], affine_in[1], affine_in[2], x3=x3)
     n, h, wd, cin = x.shape
     cout = w.shape[0]
     if x3:
@@ -252,6 +254,18 @@ def sampled_channel_mean(x):
 def mean_field_bias(mean, defect_t, bias=None):
     y = mean.float() @ defect_t.float()
     return y if bias is None else y + bias.float()
+
+
+def frame_bias(x, defect_t, bias=None, affine_in=None):
+    """pgt_frame_bias: sampled mean (of the fused operand when affine_in is given) + mean-field bias in one call"""
+    if affine_in is not None:
+        x = affine_act(x if x.dim() == 4 else x.unsqueeze(1), affine_in[0], affine_in[1], affine_in[2])
+    return mean_field_bias(sampled_channel_mean(x), defect_t, bias)
+
+
+def affine_in_fuses(x, cout, kh, kw, stride, pad, **_kw):
+    """the emulation has no kernels to choose from: the fused-operand form is always 'available' (conv2d applies it itself)"""
+    return True
 
 
 def _rownorm(x, eps):
@@ -561,7 +575,7 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "sample_rows", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
        "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update", "sampled_channel_mean", "mean_field_bias",
-       "sampled_rownorm_mean", "weight_defect", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp", "attn_proj_mlp_sample"]
+       "frame_bias", "affine_in_fuses", "sampled_rownorm_mean", "weight_defect", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp", "attn_proj_mlp_sample"]
 
 
 def install(monkeypatch):

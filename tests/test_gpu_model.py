@@ -370,9 +370,80 @@ def test_psnr_contract_sweep_against_reference_fixtures(tail_models):
             if diff.numel() == 0:
                 assert abs(rec["dpsnr_db"]) <= 1e-3 and rec["psnr_build_vs_ref_db"] >= 75.0, rec
             else:
+                # an explicit allow-list (round 5): a NEW window with a differently resolved near-tie fails instead of being
+                # absorbed by a count; (4077, 6): ONE token, reference margin 1.4e-6 (a quarter of the reference's own fp32
+                # summation-order noise), the fp32 build takes the reference's code there
                 near_ties += 1
+                assert (seed, j + 1) in NEAR_TIE_WINDOWS and diff.numel() == 1, rec
     _LOG["operating_point_sweep/x3f16_vs_reference"] = {"windows": recs, "windows_with_a_near_tie_resolved_differently": near_ties}
-    assert near_ties <= 2, recs
+
+
+NEAR_TIE_WINDOWS = {(4077, 6)}
+
+
+@pytest.fixture(scope="module")
+def tail_models_s1(cfg, manifest):
+    """the SECOND operating point (tests/golden/r5_scheme.py: weight seed 1, re-calibrated SFT gains, its own fitted tail) in the
+    default mode and fp32"""
+    from pgtformer_amd import PGTFormer
+    from pgtformer_amd.weightgen import generate_state_dict
+    from tests.golden.r5_scheme import SEED, second_point_state_dict
+
+    sd = second_point_state_dict(generate_state_dict(manifest, cfg, seed=SEED))
+    out = {}
+    for prec in ("x3f16", "fp32"):
+        m = PGTFormer(**cfg)
+        m.load_state_dict(sd, strict=True)
+        out[prec] = m.prepare(DEV, prec)
+    return out
+
+
+def test_psnr_contract_at_a_second_operating_point(tail_models_s1):
+    """the contract at an INDEPENDENT draw of everything it depends on - all 961 tensors from weight seed 1
+    (other rounding defects D = W - half(W), other activation ranges for the half decoder), SFT gains re-calibrated on the
+    reference for that draw, a decoder tail fitted on a window of another clip (7077 w2) - against REFERENCE fixtures
+    (tests/golden/r5_golden_s1.npz, make_golden_r5.py: 8 windows of 3 clips, one fitted, seven held out; the reference's codes,
+    its top-2 margins, every 8th fp32 row of the middle frame; PSNR(reference, GT) 26.3 - 28.9 dB).  Benchmarked path (uint8
+    frames, overlap-aware windows, middle-only tail), default mode:
+      * every code equals the reference's (the smallest reference margin over the 8 windows is 1.1e-4: no near-tie to excuse);
+      * |PSNR(build, GT) - PSNR(reference, GT)| <= 1e-3 dB and PSNR(build, reference) >= 75 dB on every window;
+      * no half store of the forward sits at the saturation limit (check_range);
+    fp32 mode: every code equal, <= 1e-4 dB."""
+    from pgtformer_amd.synth import make_clip
+
+    g = np.load(os.path.join(GOLD, "r5_golden_s1.npz"))
+    tags = sorted({k.split(".")[0] for k in g.files})
+    assert len(tags) == 8
+    recs = []
+    clips = {}
+    for tag in tags:
+        seed, i = int(tag[1:5]), int(tag[6:])
+        if seed not in clips:
+            clips[seed] = make_clip({7077: 5, 8077: 5, 9077: 7}[seed], 512, seed=seed)
+        lq_u8, gt = clips[seed]
+        frames = torch.from_numpy(lq_u8[i - 1:i + 2]).to(DEV)
+        ref = torch.from_numpy(g[f"{tag}.out_mid_rows"]).double()
+        gt_rows = torch.from_numpy(gt[i]).permute(2, 0, 1)[:, ::8, :].double()
+        ref_codes = g[f"{tag}.codes"].astype(np.int64).reshape(-1)
+        rec = {"window": tag, "psnr_ref_vs_gt_db": psnr(ref, gt_rows), "smallest_reference_margin": float(g[f"{tag}.top2_margin"].min())}
+        for prec in ("x3f16", "fp32"):
+            m = tail_models_s1[prec]
+            out, _, _ = m.forward_nhwc(frames, w=1.0, win=m.window_index(1, 3, DEV), middle_only=True)
+            rows = out[0].float().cpu().permute(2, 0, 1)[:, ::8, :].double()
+            codes = m.last_codes.cpu().numpy().astype(np.int64).reshape(-1)
+            rec[prec] = {"dpsnr_db": psnr(rows, gt_rows) - psnr(ref, gt_rows), "psnr_build_vs_ref_db": psnr(rows, ref),
+                         "differing_tokens": int((codes != ref_codes).sum())}
+        recs.append(rec)
+        assert rec["psnr_ref_vs_gt_db"] >= 25.0, rec
+        assert rec["x3f16"]["differing_tokens"] == 0 and rec["fp32"]["differing_tokens"] == 0, rec
+        assert abs(rec["x3f16"]["dpsnr_db"]) <= 1e-3 and rec["x3f16"]["psnr_build_vs_ref_db"] >= 75.0, rec
+        assert abs(rec["fp32"]["dpsnr_db"]) <= 1e-4 and rec["fp32"]["psnr_build_vs_ref_db"] >= 90.0, rec
+    m = tail_models_s1["x3f16"]
+    fr = torch.from_numpy(clips[7077][0][:4]).to(DEV)
+    bad = m.check_range(fr, w=1.0, win=m.window_index(2, 3, DEV))
+    _LOG["operating_point_2/x3f16_vs_reference"] = {"windows": recs, "tensors_range_checked": m.last_range_launches,
+                                                    "saturating": [list(map(str, r)) for r in bad]}
+    assert m.last_range_launches > 300 and bad == [], bad
 
 
 def test_whole_model_pure_bf16_report(models, golden_window):

@@ -543,6 +543,105 @@ def test_conv2d_c64_kernel(shape, dtype):
           E.conv2d(x, wt, b, sft=(dec, shf, 0.6), **kw), dtype)
 
 
+V8_SHAPES = [("v8_w128", 3, 8, 128, 64), ("v8_w512_two_strips", 2, 128, 512, 64), ("v8_w256_c40", 1, 16, 256, 40), ("v8_h4", 2, 4, 128, 64),
+             ("v8_c8", 1, 32, 128, 8), ("v8_c3_scalar_epilogue", 2, 32, 128, 3), ("v8_c24", 1, 64, 256, 24)]
+
+
+@pytest.mark.parametrize("dtype", H16, ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", V8_SHAPES, ids=[s[0] for s in V8_SHAPES])
+def test_conv2d_c64_ring_kernel(shape, dtype):
+    """igemm8 (round 5; 3x3, Cin = 64, Cout <= 64, W >= 128: a ring of row images in LDS, weights as the MFMA A operand, epilogue
+    straight from the accumulators) against the emulation, against igemm6 on the same launch, with a per-frame bias and a residual,
+    fp32 output, channel-slice views, repeat-run determinism - and the FUSED operand: conv(act(x * scale[n, c] + shift[n, c]))
+    (pgt_conv2d_affine_in: the GroupNorm apply + SiLU of the Normalize in front of the conv) equals affine_act followed by the
+    same kernel BIT FOR BIT (same operand bits, same accumulation order)."""
+    name, n, h, w_, cout = shape
+    cin = 64
+    O = ops()
+    x = rnd((n, h, w_, cin), 810, dtype)
+    wt = rnd((cout, 9 * cin), 811, dtype, 1.0 / np.sqrt(9 * cin))
+    wt[:, 0] += (torch.arange(cout, dtype=torch.float32) * 0.01).to(dtype)
+    b = rnd((cout,), 812, torch.float32, 0.1)
+    kw = dict(kh=3, kw=3, pad=(1, 1, 1, 1))
+    gx, gw, gb = g(x), g(wt), g(b)
+    want = E.conv2d(x, wt, b, **kw)
+    got = O.conv2d(gx, gw, gb, kernel=8, **kw)
+    check(f"{name}_v8", got, want, dtype)
+    check(f"{name}_v8_auto", O.conv2d(gx, gw, gb, **kw), want, dtype)
+    check(f"{name}_v8_v6", got, O.conv2d(gx, gw, gb, kernel=6, **kw), dtype, 0.2)
+    res = rnd(tuple(want.shape), 813, dtype)
+    gres = g(res)
+    got = O.conv2d(gx, gw, gb, res=gres, kernel=8, **kw)
+    check(f"{name}_v8_res", got, E.conv2d(x, wt, b, res=res, **kw), dtype)
+    for _ in range(10):
+        assert torch.equal(O.conv2d(gx, gw, gb, res=gres, kernel=8, **kw), got), f"{name}: igemm8 is not run-to-run deterministic"
+    check(f"{name}_v8_f32out", O.conv2d(gx, gw, gb, out_f32=True, kernel=8, **kw), want, dtype)
+    if (h * w_) % 512 == 0:
+        fb = rnd((n, cout), 814, torch.float32, 0.3)
+        check(f"{name}_v8_frame_bias", O.conv2d(gx, gw, g(fb), res=gres, kernel=8, **kw), E.conv2d(x, wt, fb, res=res, **kw), dtype)
+    if cout % 8 == 0:           # input and output as channel slices of wider buffers
+        wide_in, wide_out = g(rnd((n, h, w_, cin + 16), 815, dtype)), torch.zeros((n, h, w_, cout + 8), dtype=dtype, device=DEV)
+        wide_in[..., 8:8 + cin] = gx
+        O.conv2d(wide_in[..., 8:8 + cin], gw, gb, out=wide_out[..., 8:], kernel=8, **kw)
+        check(f"{name}_v8_views", wide_out[..., 8:], want, dtype)
+        assert float(wide_out[..., :8].abs().max()) == 0.0
+    # ---- the fused operand
+    sc = (1.0 + 0.3 * rnd((n, cin), 816)).contiguous()
+    sh = (0.2 * rnd((n, cin), 817)).contiguous()
+    for act in (E.ACT_SILU, E.ACT_NONE):
+        xa = O.affine_act(gx, g(sc), g(sh), act)
+        two = O.conv2d(xa, gw, gb, res=gres, kernel=8, **kw)
+        one = O.conv2d(gx, gw, gb, res=gres, affine_in=(g(sc), g(sh), act), **kw)
+        assert torch.equal(one, two), f"{name}: fused operand (act {act}) differs from affine_act + conv: {(one.float() - two.float()).abs().max().item():.3e}"
+        check(f"{name}_v8_fused_act{act}", one, E.conv2d(E.affine_act(x, sc, sh, act), wt, b, res=res, **kw), dtype)
+    # no fused form for a launch the ring kernel does not cover (W = 64): the library says so and refuses the call
+    import ctypes as _C
+
+    from pgtformer_amd import hip as _hip
+    dd = _hip.ConvDesc()
+    dd.dtype, dd.N, dd.H, dd.W, dd.Cin, dd.ldx = (1 if dtype == torch.bfloat16 else 3), 1, 32, 64, 64, 64
+    dd.KH = dd.KW = 3
+    dd.stride = dd.pad_t = dd.pad_l = 1
+    dd.Ho, dd.Wo, dd.Cout, dd.ldy = 32, 64, cout, cout
+    assert _hip.lib().pgt_conv2d_affine_in_ok(_C.byref(dd)) == 0
+    d_x = g(rnd((1, 32, 64, 64), 1, dtype))
+    yy = torch.empty((1, 32, 64, cout), dtype=dtype, device=DEV)
+    rc = _hip.lib().pgt_conv2d_affine_in(_C.byref(dd), d_x.data_ptr(), g(sc).data_ptr(), g(sh).data_ptr(), 3, gw.data_ptr(), None, None,
+                                         yy.data_ptr(), None)
+    assert rc == -22 and b"fused-operand" in _hip.lib().pgt_last_error()
+    dd.W = dd.Wo = dd.ldx * 2
+    dd.H = dd.Ho = 16
+    assert _hip.lib().pgt_conv2d_affine_in_ok(_C.byref(dd)) == (1 if (cout % 8 == 0 or cout <= 32) else 0)
+    # ... and ops.conv2d then runs the apply pass itself
+    small = O.conv2d(d_x, gw, gb, affine_in=(g(sc[:1].contiguous()), g(sh[:1].contiguous()), E.ACT_SILU), **kw)
+    assert torch.equal(small, O.conv2d(O.affine_act(d_x, g(sc[:1].contiguous()), g(sh[:1].contiguous()), E.ACT_SILU), gw, gb, **kw))
+
+
+@pytest.mark.parametrize("dtype", H16, ids=["bf16", "f16"])
+def test_frame_bias_one_launch(dtype):
+    """pgt_frame_bias (round 5): sampled channel mean + mean-field bias in ONE launch, against the emulation and against the two
+    launches it replaces; with the fused-operand form (the sample is taken of act(x * scale + shift) rounded to the tensor's type),
+    on channel slices, deterministic."""
+    O = ops()
+    for (n, h, w, c, cw, cout) in [(3, 32, 32, 64, 64, 64), (2, 128, 128, 256, 320, 256), (2, 512, 512, 64, 64, 3), (5, 4, 8, 72, 72, 40),
+                                   (1, 64, 64, 576, 576, 128), (2, 32, 32, 1056, 1056, 512), (96, 32, 32, 512, 512, 512)]:
+        buf = rnd((n, h, w, cw), 31 + c, dtype) + 0.25
+        x = buf[..., :c]
+        dt_ = rnd((c, cout), 32) * 1e-3
+        b = rnd((cout,), 33)
+        want = E.sampled_channel_mean(x) @ dt_ + b
+        got = O.frame_bias(g(buf)[..., :c], g(dt_), g(b))
+        check(f"frame_bias_{n}x{h}x{w}x{c}->{cout}", got, want, torch.float32, tol_scale=0.05)
+        two = O.mean_field_bias(O.sampled_channel_mean(g(buf)[..., :c]), g(dt_), g(b))
+        check(f"frame_bias_vs_two_launches_{c}", got, two, torch.float32, tol_scale=0.01)
+        assert torch.equal(got, O.frame_bias(g(buf)[..., :c], g(dt_), g(b)))
+        check(f"frame_bias_nobias_{c}", O.frame_bias(g(buf)[..., :c], g(dt_)), want - b, torch.float32, tol_scale=0.05)
+        sc, sh = (1.0 + 0.3 * rnd((n, c), 34)).contiguous(), (0.2 * rnd((n, c), 35)).contiguous()
+        xa = O.affine_act(g(buf)[..., :c], g(sc), g(sh), E.ACT_SILU)
+        fused = O.frame_bias(g(buf)[..., :c], g(dt_), g(b), affine_in=(g(sc), g(sh), E.ACT_SILU))
+        assert torch.equal(fused, O.frame_bias(xa, g(dt_), g(b))), f"frame_bias: fused-operand sample differs ({c})"
+
+
 def test_conv2d_output_parity_placement_splitk():
     """Split-K with output placement: the fp32 slabs stay dense, the reduce kernel scatters the rows (small, deep-K layer:
     the first decoder up-sampling at 16x16)."""
