@@ -63,6 +63,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(32, physical cores))")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary figures of the line: value_full_tail (the reference's discarded decoder work) and micro "
+                         "(BASELINE.json configs 4 / 5 points)")
+    ap.add_argument("--dump-clip", default="",
+                    help="--clip-frames mode, rank 0: write the sha256 of the restored clip (uint8 frames in order) to this file")
     ap.add_argument("--clip-frames", type=int, default=0,
                     help="BASELINE.json configs[2]: ONE synthetic clip of this many frames (256 in the config), sharded by "
                          "output-frame range over the --gpus ranks with one all_gather of boundary frames, restored frames gathered "
@@ -203,6 +208,56 @@ def live_roofline(runner, frames, precision, nwin):
                                  for r in top]}
 
 
+def traced_family(precision, nwin, algorithmic_tflop_per_window):
+    """The rocprofv3-traced steady-state time of the conv / linear family (tools/rocpd_stats.py family_summary, committed under
+    profiles/ by the measurement pass) - quoted only if it was taken with THIS build of the kernels (sha of the sources)."""
+    sha = _lib_sha16()
+    for name in sorted(os.listdir(os.path.join(REPO, "profiles")), reverse=True):
+        if not name.endswith("traced_family.json"):
+            continue
+        tj = json.load(open(os.path.join(REPO, "profiles", name)))
+        if tj.get("windows_per_forward") == nwin and tj.get("precision") == precision and tj.get("lib_sha16") == sha:
+            ms = tj["igemm_family_ms_per_window"]
+            ach = algorithmic_tflop_per_window / (ms * 1e-3)
+            return {"source": f"profiles/{name} (rocprofv3 --kernel-trace of bench.py --lanes 1, HIP-graph replay, same library build)",
+                    "igemm_ms_per_window": ms, "achieved": round(ach, 2), "frac": round(ach / PEAK_TFLOPS[precision], 4),
+                    "all_kernels_ms_per_window": tj.get("all_kernels_ms_per_window")}
+    return None
+
+
+def micro_points():
+    """BASELINE.json configs[3] / configs[4] points, event-timed (tools/bench_micro.py has the full sweeps; the rocprofv3 sweep of
+    config 5 is profiles/r5_config5_sweep.csv): nearest-code search at 262144 tokens, window attention 3x8x8 / C = 512 / fp16."""
+    from pgtformer_amd import ops
+    from tools.bench_micro import timeit
+    out = []
+    heads, c, win = 8, 512, (3, 8, 8)
+    n = win[0] * win[1] * win[2]
+    bias = (0.02 * torch.randn((heads, n, n), device="cuda")).float()
+    for (d, h, w) in [(3, 64, 64), (3, 128, 128), (6, 128, 128), (3, 256, 256)]:
+        nw = (d // win[0]) * (h // win[1]) * (w // win[2])
+        qkv = torch.randn((d * h * w, 3 * c), device="cuda").to(torch.float16)
+        us = timeit(lambda: ops.window_attention3d(qkv, bias, 1, d, h, w, c, heads, win, (0, 0, 0)), 20)
+        byts = d * h * w * c * 2 * 4
+        out.append({"config": 5, "bench": "window_attention3d 3x8x8 C=512 fp16", "nW": nw, "us": round(us, 1),
+                    "hbm_frac": round(byts / us / 1e3 / PEAK_HBM_GBS, 3)})
+    t, h, w, c2 = 3, 128, 128, 256
+    qkv = torch.randn((t * h * w, 3 * c2), device="cuda").to(torch.float16)
+    b2 = (0.02 * torch.randn((heads, 48, 48), device="cuda")).float()
+    us = timeit(lambda: ops.window_attention(qkv, b2, 1, t, h, w, c2, heads, (4, 4), (2, 2)), 20)
+    out.append({"config": 5, "bench": "window_attention 3x4x4 C=256 fp16 (shipping shape, shifted)", "nW": 1024, "us": round(us, 1),
+                "hbm_frac": round(t * h * w * c2 * 2 * 4 / us / 1e3 / PEAK_HBM_GBS, 3)})
+    book = torch.randn((1024, 512), device="cuda")
+    enorm = book.pow(2).sum(1).contiguous()
+    book_t = book.to(torch.bfloat16).contiguous()
+    x = torch.randn((262144, 512), device="cuda").to(torch.bfloat16)
+    xn = ops.row_sumsq(x)
+    us = timeit(lambda: ops.rq_nearest(x, book_t, xn, enorm), 10)
+    out.append({"config": 4, "bench": "rq_nearest (arg-min inside the distance GEMM) bf16", "Ntok": 262144, "us": round(us, 1),
+                "mfma_frac": round(2.0 * 262144 * 1024 * 512 / us / 1e6 / 2500.0, 3)})
+    return out
+
+
 def _cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -270,9 +325,11 @@ def clip_mode(args, model, dev, rank, world):
         if rank == 0:
             out_host.copy_(allf, non_blocking=True)                       # D2H of the restored clip
 
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()     # (also a 1-rank world under PGT_FORCE_COLLECTIVE=1)
+
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -284,10 +341,16 @@ def clip_mode(args, model, dev, rank, world):
         one_pass()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+    if rank == 0 and args.dump_clip:
+        import hashlib
+        with open(args.dump_clip, "w") as f:
+            json.dump({"frames": F, "sha256": hashlib.sha256(out_host.numpy().tobytes()).hexdigest(), "world": world,
+                       "collectives": "RCCL" if (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                                 and torch.distributed.get_backend() == "nccl") else "none"}, f)
     return {"metric": "restored 512x512 frames/sec", "value": round(F * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision], "data": "synthetic",
@@ -314,9 +377,13 @@ def main():
     backend = os.environ.get("PGT_DIST_BACKEND", "nccl")      # "gloo": several ranks on ONE GPU (a test rig for the N > 1 control flow)
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
-    if world > 1:
+    # under torchrun (RANK set) the process group exists even in a 1-rank world when PGT_FORCE_COLLECTIVE=1: the collectives of
+    # the path then run through RCCL on ONE GPU (tests/test_gpu_model.py::test_configs2_clip_through_rccl_at_one_gpu)
+    dist_on = world > 1 or ("RANK" in os.environ and os.environ.get("PGT_FORCE_COLLECTIVE") == "1")
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -341,7 +408,7 @@ def main():
         res = clip_mode(args, model, dev, rank, world)
         if rank == 0:
             print(json.dumps(res), flush=True)
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
         return
@@ -364,13 +431,13 @@ def main():
     warm_host[1:n_warm + 1].copy_(clip[:n_warm])                                          # are written in place
 
     def one_pass_host(n):
-        restore_clip_host(runner, padded_host if n == n_local else warm_host, out_host[:n], rank, world)
+        restore_clip_host(runner, padded_host if n == n_local else warm_host, out_host[:n], rank, world, n_total=n * world)
 
     local_dev = clip.to(dev)
     out_dev = torch.empty_like(local_dev)
 
     def one_pass_resident(n):
-        padded = parallel.padded_local_clip(local_dev[:n], rank, world)
+        padded = parallel.padded_local_clip(local_dev[:n], rank, world, n_total=n * world)
         runner.run_clip(padded, out_dev[:n])
 
     def fence():
@@ -414,9 +481,10 @@ def main():
                                        "identical restored frames; --full-tail for the reference's discarded work)"),
                       "clip_location": "HBM (uint8 frames resident when the timed region starts; restored uint8 frames left in HBM)",
                       "value_definition": "measurement contract (4): whole-job throughput with the inputs resident in HBM when the timed "
-                                          "region starts; the PCIe-inclusive rate of the same job from pinned host memory "
-                                          "(configs[1]: u8 on host; H2D / D2H double-buffered inside the timed region) is "
-                                          "value_from_pinned_host",
+                                          "region starts (the contract rules the PCIe-inclusive rate out as `value`); the rate of the "
+                                          "same job from pinned host memory (configs[1]: u8 on host; H2D / D2H double-buffered inside "
+                                          "the timed region) is value_from_pinned_host; value_full_tail: with the two frames per "
+                                          "window the reference decodes and discards",
                       "parallelism": f"frame-range shard x{world}, 1 all_gather of boundary frames"}}
     if world > 1 and os.environ.get("PGT_BENCH_CONFIGS2", "1") != "0":
         # BASELINE.json configs[2] as named, in the same run (so that a multi-GPU scaling run records it without extra flags):
@@ -440,11 +508,34 @@ def main():
             nin = runner.static_in.shape[0]
             res["roofline"] = live_roofline(runner, local_dev[:nin] if runner.overlap else torch.cat(
                 [local_dev[i:i + 3] for i in range(B)], 0), args.precision, B)
+            tr = traced_family(args.precision, B, res["roofline"]["algorithmic_gflop_per_launch"] * res["roofline"]["launches_per_forward"] / B / 1e3)
+            if tr is not None:      # the same family in the rocprofv3 trace of the steady state (launches NOT isolated)
+                res["roofline"]["traced"] = tr
+        if world == 1 and not args.no_extras and not args.full_tail:
+            # the reference's forward decodes all three frames of a window and the driver drops two (archs/pgtformer_arch.py:684-712,
+            # inference.py:15): the same job with that discarded work computed too
+            del runner
+            torch.cuda.empty_cache()
+            try:
+                r2 = WindowRunner(model, 1.0, not args.no_graph, 512, 512, batch=B, overlap=not args.no_overlap, full_tail=True, lanes=args.lanes)
+                n_ft = min(n_local, 4 * B)
+                pad_ft = parallel.padded_local_clip(local_dev[:n_ft], rank, world, n_total=n_ft)
+                r2.run_clip(pad_ft, out_dev[:n_ft])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r2.run_clip(pad_ft, out_dev[:n_ft])
+                torch.cuda.synchronize()
+                res["value_full_tail"] = round(n_ft / (time.perf_counter() - t0), 3)
+                del r2
+                torch.cuda.empty_cache()
+                res["micro"] = micro_points()
+            except Exception as e:      # noqa: BLE001  (secondary figures: recorded, not raised)
+                res["extras_error"] = repr(e)[:300]
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, lq_u8[:3] if lq_u8.shape[0] >= 3 else np.repeat(lq_u8[:1], 3, 0),
                                                threads=args.cpu_threads)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -24,6 +24,13 @@ import os as _os
 SIDE_STREAM = _os.environ.get("PGT_SIDE_STREAM", "1") != "0"
 
 
+def _range_pop(module, args, output):
+    """forward hook of PGTFormer.check_range: leaves the module's record context; returns None explicitly (a hook's non-None
+    return value REPLACES the module's output - the root module's name is '', which `pop() and None` would hand back)"""
+    ops.RANGE_CTX.pop()
+    return None
+
+
 # ----------------------------------------------------------------------------------------------
 # BiSeNet (reference: pgtformer_arch.py:34-397).  Eval-mode BatchNorm is folded into the preceding
 # conv at pack time; ReLU / sigmoid / residual adds are conv epilogues.
@@ -571,7 +578,7 @@ class PGTFormer(TDCRQVAE3):
         recs, hooks = [], []
         for name, mod in self.named_modules():          # records carry the innermost module whose forward() is running
             hooks.append(mod.register_forward_pre_hook(lambda m, a, n=name: ops.RANGE_CTX.append(n)))
-            hooks.append(mod.register_forward_hook(lambda m, a, o: ops.RANGE_CTX.pop() and None))
+            hooks.append(mod.register_forward_hook(_range_pop))
         ops.RANGE_CHECK = recs
         try:
             self.forward_nhwc(window_u8, w=w, win=win, middle_only=not full_tail)

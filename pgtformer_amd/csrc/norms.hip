@@ -603,82 +603,90 @@ __global__ __launch_bounds__(256) void mean_field_bias_kernel(const float* __res
 // floor, 11-18 us, and sit in the dependency chain in front of every compensated layer): out[n][o] = bias[o] +
 // sum_k defect_t[k][o] * mean_n[k], mean_n[k] over frame n's pixel sample of the layer's operand - x itself, or
 // T(in_act(x * in_scale[n][k] + in_shift[n][k])) when the layer reads its operand through the fused GroupNorm apply
-// (pgt_conv2d_affine_in: the normalised tensor never exists).  One workgroup of 1024 threads per frame: K / 8 channel chunks
-// x PL pixel lanes (all loads of a thread are independent: up to 8 in flight), per-lane sums reduced over the lanes in lane
-// order, then Cout outputs x KS slices of K reduced in slice order: no atomics, one fixed order whatever the grid.
+// (pgt_conv2d_affine_in: the normalised tensor never exists).  Grid (K / 64 slices, frames), as sampled_mean_kernel: workgroup
+// (j, n) takes the sampled sums of its 64 channels, multiplies them into a partial output row part[n][j][:], and the workgroup
+// that arrives LAST for frame n (a self-resetting counter per frame) adds the partial rows in slice order: one fixed order
+// whatever the arrival order - deterministic without a second launch.
 template <typename T>
-__global__ __launch_bounds__(1024) void frame_bias_kernel(const T* __restrict__ x, int ldx, int HW, int K, const float* __restrict__ in_scale,
-                                                          const float* __restrict__ in_shift, int in_act,
-                                                          const float* __restrict__ defect_t, const float* __restrict__ bias,
-                                                          int Cout, float* __restrict__ out) {
-    extern __shared__ float fbs[];                 // [PL][K] lane sums (then [KS][Cout-slice] partial products) | mean[K]
-    const int QC = K / 8;
-    const int PL = 1024 / QC < 1 ? 1 : 1024 / QC;
-    float* mean = fbs + (size_t)PL * K;
-    const int n = blockIdx.x;
+__global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x, int ldx, int HW, int K, const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift, int in_act,
+                                                         const float* __restrict__ defect_t, const float* __restrict__ bias,
+                                                         int Cout, float* __restrict__ out, float* __restrict__ part,
+                                                         unsigned* __restrict__ counters) {
+    __shared__ float sm[32][64 + 1];
+    __shared__ float mean[64];
+    __shared__ int is_last;
+    const int cc = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int j = blockIdx.x, KS = gridDim.x, n = blockIdx.y;
+    const int c0 = j * 64 + cc * 8;
     int run, cells, cell;
     mean_sample_geometry(HW, &run, &cells, &cell);
     const int S = cells * run;
-    for (int q0 = 0; q0 < QC; q0 += 1024) {        // (K > 8192: more than one chunk per thread; not a shape of this model)
-        const int q = q0 + (int)threadIdx.x % QC, pl = (int)threadIdx.x / QC;
-        if (q < QC && pl < PL) {
-            float acc[8], sc[8], sh[8];
+    float acc[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { acc[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < K) {
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+        if (in_scale) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = in_scale[(long)n * K + c0 + e]; sh[e] = in_shift[(long)n * K + c0 + e]; }
+        }
+        const T* base = x + (long)n * HW * ldx + c0;
+#pragma unroll 4
+        for (int i = pl; i < S; i += 32) {
+            float v[8];
+            RowIO<T, 8, sizeof(T) == 2>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
             if (in_scale) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { sc[e] = in_scale[(long)n * K + q * 8 + e]; sh[e] = in_shift[(long)n * K + q * 8 + e]; }
-            }
-            const T* base = x + (long)n * HW * ldx + q * 8;
-#pragma unroll 8
-            for (int i = pl; i < S; i += PL) {
-                float v[8];
-                RowIO<T, 8, sizeof(T) == 2>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
-                if (in_scale) {
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                act_vec<T, 8>(v, in_act);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-                    act_vec<T, 8>(v, in_act);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {      // the rounding the consuming kernel applies to its operand
-                        T r;
-                        stf(&r, v[e]);
-                        v[e] = ldf(&r);
-                    }
+                for (int e = 0; e < 8; ++e) {      // the rounding the consuming kernel applies to its operand
+                    T r;
+                    stf(&r, v[e]);
+                    v[e] = ldf(&r);
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += v[e];
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fbs[(size_t)pl * K + q * 8 + e] = acc[e];
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
         }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[pl][cc * 8 + e] = acc[e];
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += 1024) {
-        float t = 0.f;
-        for (int l = 0; l < PL; ++l) t += fbs[(size_t)l * K + k];
-        mean[k] = t / (float)S;
+    if (threadIdx.x < 64) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tot += sm[k][threadIdx.x];
+        mean[threadIdx.x] = j * 64 + (int)threadIdx.x < K ? tot / (float)S : 0.f;
     }
     __syncthreads();
-    // out: 1024 threads = OL outputs x KS slices of K
-    const int OL = Cout >= 1024 ? 1024 : (Cout >= 512 ? 512 : (Cout >= 256 ? 256 : (Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32))));
-    const int KS = 1024 / OL;
-    const int ol = threadIdx.x % OL, ks = threadIdx.x / OL;
-    const int kq = (K + KS - 1) / KS, k0 = ks * kq, k1 = k0 + kq < K ? k0 + kq : K;
-    for (int o0 = 0; o0 < Cout; o0 += OL) {
-        const int o = o0 + ol;
+    const int kn = K - j * 64 < 64 ? K - j * 64 : 64;
+    float* prow = part + ((long)n * KS + j) * Cout;
+    // Cross-workgroup hand-over WITHOUT device-scope fences: on this chip a release / acquire fence at agent scope writes back
+    // and invalidates the XCD's whole L2 (8 XCDs, one L2 each) - measured: 768 workgroups fencing per call cost 3.8 % of the
+    // step and evict the concurrent forward's working set.  Instead the partial rows are written and read with agent-scope
+    // RELAXED atomics (sc1 accesses: coherent at the memory side, per access), and the counter is bumped only after this
+    // workgroup's stores have completed (vmcnt(0) + barrier).
+    for (int o = threadIdx.x; o < Cout; o += 256) {
+        const float* d = defect_t + (long)j * 64 * Cout + o;
         float a = 0.f;
-        if (o < Cout) {
 #pragma unroll 8
-            for (int k = k0; k < k1; ++k) a += defect_t[(long)k * Cout + o] * mean[k];
-        }
-        __syncthreads();                           // (the lane sums / the previous slice's partial products are consumed)
-        fbs[ks * OL + ol] = a;
-        __syncthreads();
-        if (ks == 0 && o < Cout) {
-            float t = bias ? bias[o] : 0.f;
-            for (int j = 0; j < KS; ++j) t += fbs[j * OL + ol];
-            out[(long)n * Cout + o] = t;
-        }
+        for (int k = 0; k < kn; ++k) a += d[(long)k * Cout] * mean[k];
+        __hip_atomic_store(prow + o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial values have reached the coherent level ...
+    __syncthreads();                                   // ... every thread's have
+    if (threadIdx.x == 0) is_last = atomicInc(counters + n, (unsigned)(KS - 1)) == (unsigned)(KS - 1);
+    __syncthreads();
+    if (!is_last) return;
+    for (int o = threadIdx.x; o < Cout; o += 256) {
+        float t = bias ? bias[o] : 0.f;
+        const float* pr = part + (long)n * KS * Cout + o;
+        for (int q = 0; q < KS; ++q) t += __hip_atomic_load(pr + (long)q * Cout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // slice order
+        out[(long)n * Cout + o] = t;
     }
 }
 
@@ -936,20 +944,24 @@ extern "C" int pgt_mean_field_bias(const float* mean, const float* defect_t, con
     return 0;
 }
 
+extern "C" size_t pgt_frame_bias_workspace_bytes(int32_t N, int32_t K, int32_t Cout) {
+    if (N < 1 || K < 1 || Cout < 1) return 0;
+    return (size_t)N * ((K + 63) / 64) * Cout * sizeof(float);
+}
+
 extern "C" int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t K, const float* in_scale,
                               const float* in_shift, int32_t in_act, const float* defect_t, const float* bias, int32_t Cout,
-                              float* out, pgt_stream_t stream) {
-    PGT_CHECK(x && defect_t && out && N >= 1 && HW >= 1 && Cout >= 1, "frame_bias: null argument");
-    PGT_CHECK(K >= 8 && K % 8 == 0 && K <= 3840 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "frame_bias: K=%d (a multiple of 8, <= 3840) / ldx=%d / x alignment", K, ldx);
+                              float* out, void* workspace, size_t workspace_bytes, uint32_t* counters, pgt_stream_t stream) {
+    PGT_CHECK(x && defect_t && out && workspace && counters && N >= 1 && HW >= 1 && Cout >= 1, "frame_bias: null argument");
+    PGT_CHECK(K >= 8 && K % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "frame_bias: K=%d (a multiple of 8) / ldx=%d / x alignment", K, ldx);
     PGT_CHECK((in_scale == nullptr) == (in_shift == nullptr), "frame_bias: in_scale and in_shift go together");
-    const int QC = K / 8, PL = 1024 / QC < 1 ? 1 : 1024 / QC;
-    size_t lds = ((size_t)PL * K + K) * sizeof(float);
-    if (lds < (1024 + (size_t)K) * sizeof(float)) lds = (1024 + (size_t)K) * sizeof(float);
+    PGT_CHECK(workspace_bytes >= pgt_frame_bias_workspace_bytes(N, K, Cout) && ((uintptr_t)workspace & 3) == 0, "frame_bias: workspace too small");
+    const dim3 grid((K + 63) / 64, N), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PGT_BF16)
-        hipLaunchKernelGGL((frame_bias_kernel<bf16_t>), dim3(N), dim3(1024), lds, st, (const bf16_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out);
+        hipLaunchKernelGGL((frame_bias_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters);
     else if (dtype == PGT_F16)
-        hipLaunchKernelGGL((frame_bias_kernel<half_t>), dim3(N), dim3(1024), lds, st, (const half_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out);
+        hipLaunchKernelGGL((frame_bias_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters);
     else
         PGT_CHECK(false, "frame_bias: dtype %d (PGT_BF16 / PGT_F16: the compensated layers are the single-plane 16-bit ones)", dtype);
     PGT_LAUNCH_CHECK();

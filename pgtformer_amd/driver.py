@@ -37,6 +37,11 @@ class WindowRunner:
         if check_range is None:
             check_range = os.environ.get("PGT_RANGE_CHECK", "1") != "0" and getattr(model, "precision", "") in ("x3f16", "bf16x3")
         self._range_pending = bool(check_range) and model.dev.type == "cuda"
+        self._range_bad = None         # the saturating layers of a failed check: every later launch keeps raising
+        # PGT_RANGE_CHECK_EVERY=N: re-check on every N-th launch of lane 0 (default 0: the first batch only - a clip whose later
+        # frames drive the decoder out of range is then not noticed; the check costs one eager forward)
+        self._range_every = int(os.environ.get("PGT_RANGE_CHECK_EVERY", "0"))
+        self._launches = 0
         self.full_tail = full_tail     # True: all 3 frames of every window through the decoder's per-frame tail (discarded)
         self.dev = model.dev
         self.t = model.t
@@ -64,10 +69,12 @@ class WindowRunner:
         # decoder's rounding level); PGT_AUTOTUNE_CACHE=<file> reloads / stores the tuned table across processes
         cache = os.environ.get("PGT_AUTOTUNE_CACHE")
         tune = os.environ.get("PGT_AUTOTUNE", "0") == "1" and self.dev.type == "cuda"
+        self._tune_fresh = False
         if tune:
             from . import ops
             if not (cache and os.path.exists(cache) and ops.load_autotune(cache)):
                 ops.enable_autotune()
+                self._tune_fresh = True
         if use_graph:
             for lane in range(self.lanes):
                 self._capture(lane)
@@ -75,14 +82,19 @@ class WindowRunner:
         elif tune:
             self._forward(self.static_in)
             torch.cuda.synchronize(self.dev)
-        if tune and cache and not os.path.exists(cache):
+        if tune and cache and self._tune_fresh:       # no file yet, or a stale one (other library version / key layout): (re)written
             ops.save_autotune(cache)
 
     def _forward(self, frames_u8, lane=0):
+        from . import ops
         kw = {"win": self.win} if self.overlap else {}
         if self.full_tail:
             kw["full_tail"] = True
-        return self.model.restore_middle_u8(frames_u8, w=self.w, out=self.static_outs[lane], **kw)
+        keep, ops.LANE = ops.LANE, lane        # forwards of different lanes run concurrently: own arrival counters (ops.frame_bias)
+        try:
+            return self.model.restore_middle_u8(frames_u8, w=self.w, out=self.static_outs[lane], **kw)
+        finally:
+            ops.LANE = keep
 
     def _capture(self, lane=0):
         s = torch.cuda.Stream(device=self.dev)
@@ -100,21 +112,31 @@ class WindowRunner:
     def _launch(self, lane=0):
         """one forward on the frames currently in the lane's static input -> (batch,H,W,3) uint8 (overwritten by the next
         launch of that lane); runs on the current stream."""
-        if self._range_pending:
-            self._range_pending = False
+        if self._range_bad is not None:
+            self._raise_range()
+        self._launches += lane == 0
+        if self._range_pending or (self._range_every > 0 and lane == 0 and self._launches % self._range_every == 0 and self._launches > 1):
             kw = {"win": self.win} if self.overlap else {}
             bad = self.model.check_range(self.static_ins[lane], w=self.w, full_tail=self.full_tail, **kw)
+            # the eager pass's activations (one more set on top of the graph pools) go back to the driver before the replay
+            torch.cuda.synchronize(self.dev)
+            torch.cuda.empty_cache()
             if bad:
-                from .hip import PgtError
-                raise PgtError("activations leave the IEEE-half range in precision %r (stores saturate at +-65504): %s ... - "
-                               "prepare the model with precision='bf16x3' (bf16 decoder, no range limit) or 'fp32'"
-                               % (self.model.precision, bad[:4]))
+                self._range_bad = bad          # stays set: a caller that catches the error and calls again is refused again
+                self._raise_range()
+            self._range_pending = False        # only after a clean pass
         if self.graphs[lane] is None:
             res = self._forward(self.static_ins[lane], lane)
         else:
             self.graphs[lane].replay()
             res = self.static_ress[lane]
         return res.reshape(self.batch, *res.shape[-3:])
+
+    def _raise_range(self):
+        from .hip import PgtError
+        raise PgtError("activations leave the IEEE-half range in precision %r (stores saturate at +-65504): %s ... - "
+                       "prepare the model with precision='bf16x3' (bf16 decoder, no range limit) or 'fp32'"
+                       % (self.model.precision, self._range_bad[:4]))
 
     def run(self, frames_u8):
         """frames_u8: uint8 device tensor, (batch+2,H,W,3) consecutive frames (overlap) or (batch*3,H,W,3) windows back to
@@ -232,9 +254,9 @@ def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True, n_
     range.  n_total: the clip's frame count when the caller knows it (otherwise the ranks' counts are summed first)."""
     local = frames_u8.to(runner.dev, non_blocking=True)
     n_local = local.shape[0]
-    padded = parallel.padded_local_clip(local, rank, world, group)   # one all_gather of boundary frames
+    padded = parallel.padded_local_clip(local, rank, world, group, n_total)   # one all_gather of boundary frames
     out = runner.run_clip(padded, torch.empty_like(local)) if n_local else torch.empty_like(local)
-    if world > 1 and gather:
+    if (world > 1 or parallel._force_collective()) and gather:
         if n_total is None:
             cnt = torch.tensor([n_local], device=runner.dev)
             torch.distributed.all_reduce(cnt, group=group)
@@ -243,7 +265,7 @@ def restore_clip(runner, frames_u8, rank=0, world=1, group=None, gather=True, n_
     return out
 
 
-def restore_clip_host(runner, padded_host, out_host, rank=0, world=1, group=None):
+def restore_clip_host(runner, padded_host, out_host, rank=0, world=1, group=None, n_total=None):
     """Streaming form for host-resident clips.  padded_host: pinned uint8 (n_local+2,H,W,3) whose rows 1..n_local hold this
     rank's own frames (rows 0 and -1 are filled here with the halo frames: one all_gather of boundary frames on the
     device, replicate padding at the clip ends); out_host: pinned uint8 (n_local,H,W,3).  H2D / forward / D2H are
@@ -257,7 +279,7 @@ def restore_clip_host(runner, padded_host, out_host, rank=0, world=1, group=None
         parallel.exchange_halo(torch.empty((0,) + tuple(padded_host.shape[1:]), dtype=torch.uint8, device=dev), rank, world, group)
         return out_host
     edge = torch.stack([padded_host[1], padded_host[n_local]]).to(dev, non_blocking=True)    # first / last own frame
-    prev_halo, next_halo = parallel.exchange_halo(edge, rank, world, group)
+    prev_halo, next_halo = parallel.exchange_halo(edge, rank, world, group, n_total)     # (n_total known: no device -> host read)
     padded_host[0].copy_(prev_halo, non_blocking=True)
     padded_host[n_local + 1].copy_(next_halo, non_blocking=True)
     torch.cuda.current_stream(dev).synchronize()     # the two halo frames are on the host before the pipeline reads them

@@ -57,7 +57,8 @@ SIGNATURES = {
     "pgt_attn_proj_mlp": [i32, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, i32, vp],
     "pgt_attn_proj_mlp_sample_workspace_bytes": [i32, i32],
     "pgt_attn_proj_mlp_sample": [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp, vp, vp],
-    "pgt_frame_bias": [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp],
+    "pgt_frame_bias_workspace_bytes": [i32, i32, i32],
+    "pgt_frame_bias": [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, sz, vp, vp],
     "pgt_mean_field_bias": [vp, vp, vp, i32, i32, i32, vp, vp],
     "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pgt_window_attention3d": [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -98,7 +99,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz,
              "pgt_commit_loss_workspace_bytes": sz, "pgt_conv_gn_workspace_bytes": sz,
-             "pgt_conv2d_workspace_bytes": sz, "pgt_packed_weight_bytes": sz, "pgt_attn_proj_mlp_sample_workspace_bytes": sz, "pgt_sampled_rownorm_workspace_bytes": sz}
+             "pgt_conv2d_workspace_bytes": sz, "pgt_packed_weight_bytes": sz, "pgt_attn_proj_mlp_sample_workspace_bytes": sz, "pgt_sampled_rownorm_workspace_bytes": sz,
+             "pgt_frame_bias_workspace_bytes": sz}
 
 
 class PgtError(RuntimeError):

@@ -345,7 +345,10 @@ class VSTSREncoderTransformerBlock(HipModule):
         """Operands of the fused token-row chains (ops.ln_linear, ops.attn_proj_mlp: half layers of 256 channels): norm1 folded
         into the [q | k | v] projection, norm2 into fc1 (pgt_fold_layernorm), proj / fc1 / fc2 stacked into one matrix."""
         self.fused = False
-        if not (USE_ROWCHAIN and self.dim == 256 and self.attn.q.bias is not None):
+        # the chains are built for the shipping blocks: 256 channels, Mlp hidden width == dim (mlp_ratio 1, the reference's
+        # EncoderLayer call sites: archs/tdcrqvae3_arch.py:499), biased q / kv; anything else runs layer by layer
+        if not (USE_ROWCHAIN and self.dim == 256 and self.attn.q.bias is not None and self.attn.kv.bias is not None and
+                self.mlp.fc1.out_features == self.dim == self.mlp.fc2.in_features):
             return
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()   # noqa: E731
         a, m = self.attn, self.mlp
@@ -374,7 +377,9 @@ class VSTSREncoderTransformerBlock(HipModule):
 
     def forward(self, xt, B, H, W, out=None, gn_images=None):
         """xt: (B*D*H*W, C) tokens in (b,d,y,x) order; out: optional (rows, C) view receiving the result.
-        gn_images: number of images (B*D) when a GroupNorm follows: fc2's epilogue leaves its statistics."""
+        gn_images: number of images (B*D) when a GroupNorm follows: fc2's epilogue leaves its statistics (layer-by-layer path
+        only: the fused chains have no statistics epilogue, the GroupNorm that follows then takes its own statistics pass -
+        +0.2 ms per such block at 128 x 128, counted under "groupnorm statistics pass" in bench.py)."""
         C = self.dim
         win, shift = get_window_size((H, W), self.window_size, self.shift_size)
         x3 = _is_x3(self.dt)

@@ -269,6 +269,9 @@ def enable_autotune(flag=True):
     AUTOTUNE = ({} if AUTOTUNE is None else AUTOTUNE) if flag else None
 
 
+_TUNE_KEY_LEN = 25      # fields of an AUTOTUNE key (conv2d); a cache file with another arity is stale
+
+
 def _tune_tag():
     """library version + device architecture a tuned table is valid for (kernel variants / legality change with both)."""
     arch = ""
@@ -291,6 +294,8 @@ def load_autotune(path):
     import json
     blob = json.load(open(path))
     if not isinstance(blob, dict) or blob.get("tag") != _tune_tag():
+        return False
+    if any(len(k) != _TUNE_KEY_LEN for k, _ in blob["table"]):      # written with another key layout: start afresh (and re-save)
         return False
     enable_autotune()
     for k, v in blob["table"]:
@@ -651,6 +656,25 @@ def mean_field_bias(mean, defect_t, bias=None):
     return out
 
 
+# pgt_frame_bias: per-frame arrival counters (zero between calls).  Consecutive calls on one stream share them; forwards that run
+# CONCURRENTLY need their own: the driver's lanes set LANE around their forwards (driver.WindowRunner).  Allocated once per
+# (device, lane) OUTSIDE any graph capture (the lanes' eager warm-up passes come first) and never freed.
+LANE = 0
+_FB_COUNTERS = {}
+_FB_MAX_FRAMES = 4096
+
+
+def _fb_counters(device, n):
+    key = (str(device), LANE)
+    c = _FB_COUNTERS.get(key)
+    if c is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise hip.PgtError("frame_bias: first use for lane %d inside a graph capture (run one eager forward first)" % LANE)
+        c = _FB_COUNTERS[key] = torch.zeros(_FB_MAX_FRAMES, dtype=torch.int32, device=device)
+    assert n <= _FB_MAX_FRAMES
+    return c
+
+
 def frame_bias(x, defect_t, bias=None, affine_in=None):
     """(N, Cout) fp32 per-frame bias of a compensated 16-bit layer in ONE launch (pgt_frame_bias): bias + mean_n @ defect_t with
     mean_n the sampled channel mean of frame n of x (N,H,W,K) / (N,HW,K) - or of act(x * scale + shift) rounded to x.dtype when
@@ -661,10 +685,13 @@ def frame_bias(x, defect_t, bias=None, affine_in=None):
     cout = defect_t.shape[1]
     assert defect_t.shape[0] == k and defect_t.is_contiguous() and defect_t.dtype == torch.float32
     out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    L = hip.lib()
+    nbytes = L.pgt_frame_bias_workspace_bytes(n, k, cout)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     sc, sh, act = affine_in if affine_in is not None else (None, None, ACT_NONE)
     with _Prof("mean_field", 2.0 * n * k * cout, float(n * min(h * w, 1024) * k * x.element_size() + defect_t.numel() * 4)):
-        hip.check(hip.lib().pgt_frame_bias(_dt(x), _p(x), _ld_img(x), n, h * w, k, _p(sc), _p(sh), int(act), _p(defect_t), _p(bias), cout,
-                                           _p(out), _stream()), "pgt_frame_bias")
+        hip.check(L.pgt_frame_bias(_dt(x), _p(x), _ld_img(x), n, h * w, k, _p(sc), _p(sh), int(act), _p(defect_t), _p(bias), cout,
+                                   _p(out), _p(ws), nbytes, _p(_fb_counters(x.device, n)), _stream()), "pgt_frame_bias")
     return out
 
 

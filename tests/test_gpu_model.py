@@ -790,3 +790,32 @@ def test_range_telemetry_reports_saturated_half_stores(tail_models):
             conv.weight.copy_(keep)
         conv._pack(m.dev, conv.dt)
     assert m.check_range(fr, w=1.0, win=m.window_index(2, 3, DEV)) == []
+
+
+def test_configs2_clip_through_rccl_at_one_gpu(tmp_path):
+    """BASELINE.json configs[2] (256-frame clip, frame-range shard, ONE all_gather of boundary frames, restored frames gathered to
+    rank 0) at N = 1 through the REAL collective library: bench.py --clip-frames 256 under torchrun --nproc-per-node 1 with the
+    `nccl` backend (= RCCL) and PGT_FORCE_COLLECTIVE=1, so that the all_gather / gather / barrier / all_reduce of the path run on a
+    1-rank RCCL communicator - against the same job in a plain process (no process group): the restored clips are bit-equal (sha256
+    over the 256 uint8 frames).  What this cannot show: more than one rank (one GPU per box; the gloo world-2 / world-8 tests of
+    tests/test_abi_and_parallel.py cover the sharding logic)."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["bench.py", "--gpus", "1", "--clip-frames", "256", "--steps", "1", "--warmup", "1"]
+    env = dict(os.environ, PGT_RANGE_CHECK="0")
+    a, b = str(tmp_path / "rccl.json"), str(tmp_path / "plain.json")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541"] + common + ["--dump-clip", a], cwd=repo, env=dict(env, PGT_FORCE_COLLECTIVE="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["config"]["clip_frames"] == 256 and line["n_gpus"] == 1
+    r2 = subprocess.run([sys.executable] + common + ["--dump-clip", b], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    ja, jb = json.load(open(a)), json.load(open(b))
+    _LOG["configs2_n1_rccl"] = {"rccl": ja, "plain": jb, "frames_per_s_rccl": line["value"],
+                                "frames_per_s_plain": json.loads(r2.stdout.strip().splitlines()[-1])["value"]}
+    assert ja["collectives"] == "RCCL" and jb["collectives"] == "none" and ja["frames"] == jb["frames"] == 256
+    assert ja["sha256"] == jb["sha256"]

@@ -58,6 +58,13 @@ def test_traffic_table_and_stats_on_a_synthetic_trace(tmp_path):
     rd = list(csv.reader(open(stats)))
     assert rd[0][:3] == ["kernel", "calls", "total_us"] and rd[1][0] == IG and int(rd[1][1]) == 4 and float(rd[1][2]) == 4000.0
     assert rd[-1][0] == "TOTAL" and float(rd[-1][2]) == 4402.0 and abs(float(rd[-1][-1]) - 4402.0 / 64) < 0.06
+    # the traced conv / linear family per window (what bench.py quotes as roofline.traced): 4 launches of 1 ms over 64 windows
+    fam = str(tmp_path / "fam.json")
+    rocpd_stats.family_summary(f, fam, 64.0, 32, "x3f16")
+    fj = json.load(open(fam))
+    assert fj["igemm_family_ms_per_window"] == round(4.0 / 64, 4) and fj["all_kernels_ms_per_window"] == round(4.402 / 64, 4)
+    assert fj["lib_sha16"] == pmc_traffic.source_sha16() and fj["precision"] == "x3f16" and fj["windows_per_forward"] == 32
+    assert list(fj["kernels_us_per_window"]) == [IG[:120]]
 
 
 def test_mfma_utilisation_on_a_synthetic_trace(tmp_path):
