@@ -18,7 +18,7 @@ import sqlite3
 import sys
 
 
-FAMILY = ("%igemm%_kernel%", "%conv3x3_c64_kernel%", "%conv3x3_c64_x3_kernel%", "%linear_k256_kernel%", "%splitk_epilogue_kernel%", "%rowchain%_kernel%")   # the conv / linear kernels of csrc/igemm*.hip
+FAMILY = ("%igemm%_kernel%", "%conv3x3_c64_kernel%", "%conv3x3_c64_x3_kernel%", "%conv3x3_c64_ring_kernel%", "%linear_k256_kernel%", "%splitk_epilogue_kernel%", "%rowchain%_kernel%")   # the conv / linear kernels of csrc/igemm*.hip
 
 
 def source_sha16():
@@ -49,7 +49,7 @@ def per_kernel(db, counter, likes):
 def main(fetch_db, write_db, out, precision=None, windows_per_forward=None):
     f_kib, nf = per_kernel(fetch_db, "FETCH_SIZE", FAMILY)
     w_kib, nw = per_kernel(write_db, "WRITE_SIZE", FAMILY)
-    res = {"kernel": "conv/linear family: igemm*_kernel (igemm, igemm2, igemm4, igemm5), conv3x3_c64_kernel / conv3x3_c64_x3_kernel (igemm6, igemm6x3), linear_k256_kernel (igemm7), rowchain kernels (fused LayerNorm -> Linear / proj -> Mlp chains), split-K reduce", "launches": nf,
+    res = {"kernel": "conv/linear family: igemm*_kernel (igemm, igemm2, igemm4, igemm5), conv3x3_c64_kernel / conv3x3_c64_x3_kernel / conv3x3_c64_ring_kernel (igemm6, igemm6x3, igemm8), linear_k256_kernel (igemm7), rowchain kernels (fused LayerNorm -> Linear / proj -> Mlp chains), split-K reduce", "launches": nf,
            "fetch_bytes_per_launch_raw": f_kib * 1024 / max(nf, 1),
            "fetch_bytes_per_launch_corrected_x2": 2 * f_kib * 1024 / max(nf, 1),
            "write_bytes_per_launch": w_kib * 1024 / max(nw, 1),
