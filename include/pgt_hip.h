@@ -447,6 +447,27 @@ int pgt_nhwc_to_nchw_f32(int32_t dtype, const void* x, int32_t ldx, int32_t N, i
 int pgt_frame_to_u8(int32_t dtype, const void* x, int32_t ldx, int32_t H, int32_t W, uint8_t* y,
                     pgt_stream_t stream);
 
+/* ---- whole-graph entry: a recorded forward replayed by the library ("pgt_forward_window") -------------------
+ * The reference's graph is Python (PGTFormer.forward, archs/pgtformer_arch.py:598-714; driver inference.py:12-19) and so is this
+ * build's host.  pgtformer_amd/export.py records ONE forward of a prepared model - B sliding 3-frame windows, uint8 frames in,
+ * restored uint8 middle frames out - as a tape of the calls of this header, pointers resolved to {persistent block (repacked
+ * weights, tables, counters: stored in the file), workspace, input, output}; a non-Python host then needs three calls:
+ *   pgt_program_load(path, &prog)       reads the file, uploads the persistent block (the only allocation)
+ *   pgt_program_run(prog, in, out, ws, ws_bytes, stream)   replays the launches in order on `stream`: no allocation, no
+ *                                       synchronisation, caller-owned buffers (pgt_program_io_bytes / _workspace_bytes give the
+ *                                       sizes); results equal the Python host's forward bit for bit; hipGraph-capturable
+ *   pgt_program_destroy(prog)
+ * A program is specific to what was recorded (checkpoint, precision mode, window batch, frame size: pgt_program_info).  One
+ * program serves one stream at a time (its persistent block holds the arrival counters of pgt_frame_bias).                   */
+typedef struct pgt_program pgt_program;
+int pgt_program_load(const char* path, pgt_program** out);
+void pgt_program_destroy(pgt_program* prog);
+size_t pgt_program_workspace_bytes(const pgt_program* prog);
+int pgt_program_io_bytes(const pgt_program* prog, size_t* input_bytes, size_t* output_bytes);
+const char* pgt_program_info(const pgt_program* prog);
+int pgt_program_run(const pgt_program* prog, const void* input_u8, void* output_u8, void* workspace, size_t workspace_bytes,
+                    pgt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

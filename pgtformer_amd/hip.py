@@ -96,15 +96,55 @@ SIGNATURES = {
     "pgt_prep_input": [i32, vp, i32, i32, i32, i32, vp, vp, vp],
     "pgt_nhwc_to_nchw_f32": [i32, vp, i32, i32, i32, i32, i32, vp, vp],
     "pgt_frame_to_u8": [i32, vp, i32, i32, i32, vp, vp],
+    "pgt_program_load": [C.c_char_p, C.POINTER(C.c_void_p)],
+    "pgt_program_destroy": [vp],
+    "pgt_program_workspace_bytes": [vp],
+    "pgt_program_io_bytes": [vp, C.POINTER(sz), C.POINTER(sz)],
+    "pgt_program_info": [vp],
+    "pgt_program_run": [vp, vp, vp, vp, sz, vp],
 }
 _RESTYPES = {"pgt_version": C.c_char_p, "pgt_last_error": C.c_char_p, "pgt_groupnorm_workspace_bytes": sz,
              "pgt_commit_loss_workspace_bytes": sz, "pgt_conv_gn_workspace_bytes": sz,
              "pgt_conv2d_workspace_bytes": sz, "pgt_packed_weight_bytes": sz, "pgt_attn_proj_mlp_sample_workspace_bytes": sz, "pgt_sampled_rownorm_workspace_bytes": sz,
-             "pgt_frame_bias_workspace_bytes": sz}
+             "pgt_frame_bias_workspace_bytes": sz, "pgt_program_workspace_bytes": sz, "pgt_program_info": C.c_char_p,
+             "pgt_program_destroy": None}
 
 
 class PgtError(RuntimeError):
     pass
+
+
+# ---- call tracing (pgtformer_amd.export: the launch schedule of a forward as a tape a non-Python host replays) ------------------
+# TRACE = None, or a list that receives (function name, [argument objects as passed]) for every call made through lib().
+TRACE = None
+TRACE_TENSORS = None       # {data_ptr: (storage base address, storage bytes)} of the tensors ops._p handed out while tracing
+
+
+class _TracedLib:
+    """lib() while TRACE is a list: attribute access yields the real function wrapped in a recorder"""
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+
+        def call(*args):
+            if TRACE is not None:
+                rec = []
+                for a in args:      # pointer arguments are resolved to their storage NOW: the allocator may hand the address out again later
+                    if isinstance(a, C.c_void_p):
+                        v = a.value or 0
+                        rec.append(("ptr", v) + tuple(TRACE_TENSORS.get(v, (None, None))))
+                    elif a is None:
+                        rec.append(("ptr", 0, None, None))
+                    elif hasattr(a, "_obj"):           # C.byref(struct)
+                        rec.append(("blob", bytes(a._obj)))
+                    else:
+                        rec.append(("val", a))
+                TRACE.append((name, rec))
+            return fn(*args)
+        return call
 
 
 def lib():
@@ -123,6 +163,8 @@ def lib():
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, i32)
         _LIB = h
+    if TRACE is not None:
+        return _TracedLib(_LIB)
     return _LIB
 
 

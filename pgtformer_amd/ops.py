@@ -223,7 +223,12 @@ def _dev(t):
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(_dev(t).data_ptr())
+    if t is None:
+        return None
+    if hip.TRACE_TENSORS is not None:      # export: which storage a pointer argument belongs to (pgtformer_amd.export)
+        st = t.untyped_storage()
+        hip.TRACE_TENSORS[t.data_ptr()] = (st.data_ptr(), st.nbytes())
+    return C.c_void_p(_dev(t).data_ptr())
 
 
 def _stream(t=None):

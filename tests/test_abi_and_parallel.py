@@ -163,3 +163,52 @@ def test_synth_clip_is_deterministic():
     assert np.array_equal(w2[2], a[2]) and np.array_equal(w2[1], a[2])
     c, gc = make_clip(2, 64, seed=7, start=1)          # a frame depends on the seed and its own index only
     assert np.array_equal(c, a[1:3]) and np.array_equal(gc, ga[1:3])
+
+
+def test_program_dispatch_table_is_current_and_tape_placement():
+    """The whole-graph entry's plumbing that needs no GPU: (1) csrc/program_dispatch.inc is what tools/gen_program_dispatch.py
+    generates from hip.SIGNATURES today (a signature change without regenerating would replay tapes with shifted arguments);
+    (2) export.build_program places pointers: persistent storages keep their offsets, temporaries that shared an address range
+    share the workspace range, input / output pointers are relative to the caller's buffers, the stream is the last argument."""
+    import subprocess
+    import sys
+
+    import torch
+
+    from pgtformer_amd import export, hip
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(repo, "tools", "gen_program_dispatch.py"), "--check"]).returncode == 0
+    names = export.tape_functions()
+    assert "pgt_conv2d_ws" in names and "pgt_version" not in names and "pgt_program_run" not in names
+    for n in names:      # every tape function takes the stream last (the replay substitutes the caller's)
+        assert hip.SIGNATURES[n][-1] is hip.vp, n
+
+    class T:      # stands in for the input / output tensors
+        def __init__(self, ptr, n):
+            self._p, self._n = ptr, n
+
+        def data_ptr(self):
+            return self._p
+
+        def numel(self):
+            return self._n
+
+        def element_size(self):
+            return 1
+    inp, out = T(0x1000, 100), T(0x2000, 50)
+    persistent = {0x9000: (64, None)}
+    P = lambda v, base=None, nb=None: ("ptr", v, base, nb)      # noqa: E731
+    calls = [("pgt_zero2d", [P(0x5000, 0x5000, 300), ("val", 3), ("val", 100), ("val", 1), P(0)]),
+             ("pgt_version", []),
+             ("pgt_copy2d", [("val", 0), P(0x1010), ("val", 8), ("val", 8), P(0x5100, 0x5100, 64), ("val", 8), ("val", 4), ("val", 8), P(0)]),
+             ("pgt_copy2d", [("val", 0), P(0x9020, 0x9000, 64), ("val", 8), ("val", 8), P(0x2008), ("val", 8), ("val", 4), ("val", 8), P(0)]),
+             ("pgt_zero2d", [P(0x7000, 0x7000, 16), ("val", 1), ("val", 16), ("val", 1), P(0)])]
+    tape, playout, work = export.build_program(calls, persistent, inp, out)
+    assert len(tape) == 4 and playout == {0x9000: (0, 64)}
+    assert work == 512 + 256                                   # [0x5000, 0x512c) merged with [0x5100, 0x5140) -> 300 B -> 512; 16 B -> 256
+    k = export
+    assert tape[0][1][0] == (k.K_PTR, k.R_WORK, 0) and tape[0][1][-1] == (k.K_STREAM, 0, 0)
+    assert tape[1][1][1] == (k.K_PTR, k.R_IN, 0x10) and tape[1][1][4] == (k.K_PTR, k.R_WORK, 0x100)
+    assert tape[2][1][1] == (k.K_PTR, k.R_PERSIST, 0x20) and tape[2][1][4] == (k.K_PTR, k.R_OUT, 8)
+    assert tape[3][1][0] == (k.K_PTR, k.R_WORK, 512)
+    assert torch is not None

@@ -819,3 +819,48 @@ def test_configs2_clip_through_rccl_at_one_gpu(tmp_path):
                                 "frames_per_s_plain": json.loads(r2.stdout.strip().splitlines()[-1])["value"]}
     assert ja["collectives"] == "RCCL" and jb["collectives"] == "none" and ja["frames"] == jb["frames"] == 256
     assert ja["sha256"] == jb["sha256"]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "x3f16"])
+def test_exported_program_replays_bit_equal_from_python_and_from_c(models, prec, tmp_path):
+    """The whole-graph entry (pgt_program_load / _run / _destroy; SURVEY section 8b `pgt_forward_window`): one forward of the
+    prepared model on 2 sliding windows is recorded as a tape of C-ABI calls (pgtformer_amd/export.py), then replayed
+      (a) through the library from this process on FRESH buffers (another workspace address, other frames than the recorded ones),
+      (b) by a C host that links libpgt_hip.so and the HIP runtime only (tests/c/program_smoke.c),
+    and both equal the Python host's restore_middle_u8 BIT FOR BIT - in fp32 and in the default mode (same kernels, same order,
+    fixed-order reductions)."""
+    import subprocess
+
+    from pgtformer_amd.export import export_program, run_program
+    from pgtformer_amd.synth import make_clip
+
+    m = models[prec]
+    path = str(tmp_path / f"pgt_{prec}.prog")
+    info = export_program(m, 2, path)
+    assert info["calls"] > 400 and info["workspace_bytes"] > 0 and os.path.getsize(path) > info["persistent_bytes"]
+    # (a) the recorded input reproduces the recorded output; other frames reproduce the Python host's result for them
+    got = run_program(path, info["input"])
+    assert torch.equal(got.reshape(info["output"].shape), info["output"])
+    lq_u8, _ = make_clip(4, 512, seed=4321)
+    frames = torch.from_numpy(lq_u8).to(DEV)
+    want = m.restore_middle_u8(frames, w=1.0, win=m.window_index(2, 3, DEV))
+    pad = torch.empty(12345, dtype=torch.uint8, device=DEV)      # (moves the next allocations: the replay must not depend on addresses)
+    got = run_program(path, frames).reshape(want.shape)
+    del pad
+    assert torch.equal(got, want), int((got.int() - want.int()).abs().max())
+    # (b) a C host
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "program_smoke")
+    lib_dir = os.path.join(repo, "pgtformer_amd", "lib")
+    cc = subprocess.run(["gcc", "-D__HIP_PLATFORM_AMD__", os.path.join(repo, "tests", "c", "program_smoke.c"), "-I", os.path.join(repo, "include"),
+                         "-I", "/opt/rocm/include", "-L", lib_dir, "-lpgt_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib_dir,
+                         "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    fin, fout = str(tmp_path / "in.u8"), str(tmp_path / "out.u8")
+    lq_u8.tofile(fin)
+    r = subprocess.run([exe, path, fin, fout, "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    c_out = torch.from_numpy(np.fromfile(fout, dtype=np.uint8).reshape(tuple(want.shape)))
+    _LOG[f"exported_program/{prec}"] = {"calls": info["calls"], "persistent_mb": round(info["persistent_bytes"] / 1e6, 1),
+                                        "workspace_mb": round(info["workspace_bytes"] / 1e6, 1), "c_host_stdout": r.stdout.strip().splitlines()[-3:]}
+    assert torch.equal(c_out, want.cpu()), int((c_out.int() - want.cpu().int()).abs().max())
