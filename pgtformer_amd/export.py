@@ -49,6 +49,9 @@ def _align(n):
 
 def _live_cuda_storages(device):
     """{storage address: (bytes, storage)} of every CUDA tensor alive on `device` right now"""
+    device = torch.device(device)
+    if device.index is None:          # "cuda" names the current device; tensors report "cuda:<index>"
+        device = torch.device("cuda", torch.cuda.current_device())
     out = {}
     for o in gc.get_objects():
         try:
@@ -202,7 +205,9 @@ def export_program(model, n_windows, path, w=1.0, height=512, width=512, overlap
     """Record `model.restore_middle_u8` on `n_windows` sliding 3-frame windows (uint8 frames in -> restored uint8 middle frames out,
     reference inference.py:12-19) and write the program file.  Returns a dict with the sizes and the example input / output
     (device tensors) of the recorded forward - what pgt_program_run must reproduce bit for bit."""
-    dev = model.dev
+    dev = torch.device(model.dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     t = model.t
     n_in = n_windows + t - 1 if overlap else n_windows * t
     g = torch.Generator().manual_seed(1234)
@@ -222,6 +227,8 @@ def export_program(model, n_windows, path, w=1.0, height=512, width=512, overlap
     calls, _ = record(fwd, dev)
     want = out.clone()
     tape, playout, work_bytes = build_program(calls, persistent, frames, out)
+    if not playout:
+        raise hip.PgtError("export: the recorded forward touched no persistent storage (no weights found on %s)" % dev)
     meta = (f"precision={getattr(model, 'precision', '?')} windows={n_windows} frames_in={n_in} size={height}x{width} overlap={int(overlap)} "
             f"full_tail={int(full_tail)} w={w} lib={hip.lib().pgt_version().decode()}").encode()
     persist_bytes = write_program(path, tape, playout, work_bytes, frames.numel(), out.numel(), meta, storages=persistent)
