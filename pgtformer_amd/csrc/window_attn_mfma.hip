@@ -73,6 +73,12 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
     constexpr int DT = HD / 16;       // 16-wide head-dim tiles of O^T
     constexpr int NP = X3 ? 2 : 1;    // operand planes
     constexpr float LOG2E = 1.44269504088896340736f;
+    // Windows of more than one 48-key group (N = 96 .. 192: the Video-Swin form, BASELINE config 5): the K rows are staged in LDS
+    // ONCE per workgroup next to V^T (round 5).  Before, every wave fetched every key group's K fragments from global memory
+    // inside the group loop - (NW - 1) dependent L2 / HBM round trips per wave that nothing overlapped (config 5: 0.25 of HBM).
+    constexpr bool KLDS = NW > 1;
+    constexpr int KSTR = HD * 2 + 16;   // K row stride in bytes (dims contiguous, 16-byte pad: conflict-free ds_read_b128 over 16 keys)
+    __shared__ __attribute__((aligned(16))) char k_all[KLDS ? NP * N * KSTR : 16];
     __shared__ __attribute__((aligned(16))) char vt_all[HPW * NP * HD * VSTR];
     __shared__ int tok[N];
     __shared__ int reg[N];
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
     // below, so that the three operands travel together - the kernel is a chain of dependent HBM round trips otherwise (V rows ->
     // LDS -> barrier -> Q -> K: measured 3.3 TB/s at 16 waves per CU, round 4)
     uint4 qf[3][KS], ql[X3 ? 3 : 1][KS];
-    uint4 kf0[3][KS], kl0[X3 ? 3 : 1][KS];
+    uint4 kf0[KLDS ? 1 : 3][KS], kl0[(X3 && !KLDS) ? 3 : 1][KS];
     int qidx[3], rq[3];
 #pragma unroll
     for (int qt = 0; qt < 3; ++qt) {
@@ -146,10 +152,31 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[qt][ks] = *reinterpret_cast<const uint4*>(qrow + ks * 32);
-            kf0[qt][ks] = *reinterpret_cast<const uint4*>(krow + ks * 32);
+            if constexpr (!KLDS) kf0[qt][ks] = *reinterpret_cast<const uint4*>(krow + ks * 32);
             if constexpr (X3) {
                 ql[qt][ks] = *reinterpret_cast<const uint4*>(qrow + qlo + ks * 32);
-                kl0[qt][ks] = *reinterpret_cast<const uint4*>(krow + qlo + ks * 32);
+                if constexpr (!KLDS) kl0[qt][ks] = *reinterpret_cast<const uint4*>(krow + qlo + ks * 32);
+            }
+        }
+    }
+    if constexpr (KLDS) {   // ---- K image: work item = (plane, key, 16-byte chunk of its head slice); all loads first, then the LDS writes
+        constexpr int CH = HD / 8, ITEMS = NP * N * CH, PER = (ITEMS + 64 * NW - 1) / (64 * NW);
+        uint4 kv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int it = tid + u * 64 * NW;
+            kv[u] = make_uint4(0, 0, 0, 0);
+            if (it < ITEMS) {
+                const int pl = it / (N * CH), it2 = it % (N * CH), key = it2 / CH, c = it2 % CH;
+                kv[u] = *reinterpret_cast<const uint4*>(qkv + (long)tok[key] * ldqkv + pl * qlo + C + head * HD + c * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int it = tid + u * 64 * NW;
+            if (it < ITEMS) {
+                const int pl = it / (N * CH), it2 = it % (N * CH), key = it2 / CH, c = it2 % CH;
+                *reinterpret_cast<uint4*>(k_all + (pl * N + key) * KSTR + c * 16) = kv[u];
             }
         }
     }
@@ -181,6 +208,18 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // BPRE: the NEXT key group's bias rows requested while this group multiplies.  36 more live registers: with 64-wide heads the
+    // kernel then needs 336 VGPRs = one workgroup per CU instead of two (236) - not taken there; the second workgroup hides the
+    // ~1 us of an L2 round trip better than the prefetch does
+    constexpr bool BPRE = KLDS && HD == 32;
+    float4 bvs_next[BPRE ? 3 : 1][3];
+    if constexpr (BPRE) {
+#pragma unroll
+        for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+                bvs_next[qt][kt] = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + kt * 16 + 4 * g);
+    }
     for (int kg = 0; kg < NW; ++kg) {   // groups of 48 keys
         uint4 kf[3][KS], kl[X3 ? 3 : 1][KS];
 #pragma unroll
@@ -188,7 +227,11 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
             const uint16_t* krow = qkv + (long)tok[kg * 48 + kt * 16 + col] * ldqkv + C + head * HD + g * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (kg == 0) {                       // (requested before the V^T staging)
+                if constexpr (KLDS) {                // fragment = 16 keys x 32 dims: key row (kg*48 + kt*16 + col), dims ks*32 + g*8 .. +8
+                    const char* kr = k_all + (kg * 48 + kt * 16 + col) * KSTR + ks * 64 + g * 16;
+                    kf[kt][ks] = *reinterpret_cast<const uint4*>(kr);
+                    if constexpr (X3) kl[kt][ks] = *reinterpret_cast<const uint4*>(kr + N * KSTR);
+                } else if (kg == 0) {                // (requested before the V^T staging)
                     kf[kt][ks] = kf0[kt][ks];
                     if constexpr (X3) kl[kt][ks] = kl0[kt][ks];
                 } else {
@@ -203,11 +246,22 @@ __global__ __launch_bounds__(64 * NW * HPW, (HD == 32 && NW == 1 && HPW == 1) ? 
 #pragma unroll
             for (int r = 0; r < 4; ++r) rk[kt][r] = reg[kg * 48 + kt * 16 + 4 * g + r];
         float4 bvs[3][3];        // the group's bias rows requested together, ahead of the products that want them (-4 %, round 4)
+        if constexpr (BPRE) {
 #pragma unroll
-        for (int qt = 0; qt < 3; ++qt)
+            for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
-                bvs[qt][kt] = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + kg * 48 + kt * 16 + 4 * g);
+                for (int kt = 0; kt < 3; ++kt) {
+                    bvs[qt][kt] = bvs_next[qt][kt];
+                    if (kg + 1 < NW)
+                        bvs_next[qt][kt] = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + (kg + 1) * 48 + kt * 16 + 4 * g);
+                }
+        } else {
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt)
+                    bvs[qt][kt] = *reinterpret_cast<const float4*>(bias + ((long)head * N + qidx[qt]) * N + kg * 48 + kt * 16 + 4 * g);
+        }
         __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks every load to its use)
 #pragma unroll
         for (int qt = 0; qt < 3; ++qt) {
