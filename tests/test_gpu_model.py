@@ -178,8 +178,7 @@ def _reduced_record(out, logits, lq, codes, g, gt):
 @pytest.mark.parametrize("prec", ["x3f16", "bf16x3", "mixed"])
 def test_whole_model_default_mode_matches_reference(models, golden_window, prec):
     """The modes with a split-half (or fp32) code branch reproduce the reference: every arg-max code
-    (archs/pgtformer_arch.py:663) equals the fp32 reference's except where the reference's own top-2 logit margin is < 1e-3,
-    logits / lq_feat to fp32-class error, and the restored frames to >= 55 dB with the IEEE-half decoder (x3f16, the
+    (archs/pgtformer_arch.py:663) equals the fp32 reference's, logits / lq_feat to fp32-class error, and the restored frames to >= 55 dB with the IEEE-half decoder (x3f16, the
     default), >= 35 dB with the bf16 decoder.  (Random-tail weights: the frames are noise against the GT - the PSNR contract
     is asserted at the fitted-tail operating point, test_psnr_contract_at_the_operating_point.)"""
     g = np.load(os.path.join(GOLD, "full_golden.npz"))
@@ -189,9 +188,10 @@ def test_whole_model_default_mode_matches_reference(models, golden_window, prec)
     assert torch.isfinite(out).all()
     rec = _reduced_record(out, logits, lq, codes, g, gt)
     _LOG[f"whole/{prec}"] = rec
-    assert rec["max_mismatch_margin"] < 1e-3, rec
-    assert rec["code_agreement"] >= 0.997, rec
-    assert rec["logits_err"] < 2e-3 and rec["lq_feat_err"] < 1e-3, rec
+    # round 5: the gate is what is measured - every code of the golden window equal (kernel selection is static: the same bits on
+    # every box), logits within 1e-4 (measured 1.24e-5 / 5e-6); rounds 1-4 tolerated 0.3 % differing codes below a margin of 1e-3
+    assert rec["n_mismatch"] == 0, rec
+    assert rec["logits_err"] < 1e-4 and rec["lq_feat_err"] < 1e-3, rec
     floor = 55.0 if prec == "x3f16" else 35.0
     assert rec["psnr_full_sub4_clamped_db"] >= floor and rec["psnr_mid_crop_clamped_db"] >= floor - 0.5, rec
     rec["psnr_vs_gt_abs_diff_db"] = abs(rec["psnr_build_vs_gt_db"] - rec["psnr_ref_vs_gt_db"])   # reported only: noise vs GT here
