@@ -189,14 +189,16 @@ int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* b
  * dependency chain in front of a compensated layer): out[n][o] = bias[o] + sum_k defect_t[k][o] * mean_n[k], mean_n over frame
  * n's pixel sample of x (N, HW, K; PGT_F16 / PGT_BF16) - or, with in_scale / in_shift (fp32 (N, K)), of the operand a layer
  * fed through pgt_conv2d_affine_in multiplies: in_act(x * in_scale + in_shift) rounded to the tensor's type.  K % 8 == 0.
- * workspace: pgt_frame_bias_workspace_bytes(N, K, Cout) bytes of scratch (partial rows per 64-channel slice of K).
+ * out_groups = 1: out is (N, Cout).  out_groups = G > 1: defect_t / bias hold G layers side by side (Cout = G x Csub columns:
+ * the four sub-pixel convolutions of an Upsample read ONE operand) and out is (G, N, Csub) - one contiguous per-frame bias matrix per
+ * layer.  workspace: pgt_frame_bias_workspace_bytes(N, K, Cout) bytes of scratch (partial rows per 64-channel slice of K).
  * counters: N uint32, ZERO before the first call and left zero by every call (the workgroup that finishes a frame last adds
  * its partial rows in slice order - one fixed order whatever the arrival order: deterministic); calls that may run
  * CONCURRENTLY (other streams) need their own counters, consecutive calls on one stream share them. */
 size_t pgt_frame_bias_workspace_bytes(int32_t N, int32_t K, int32_t Cout);
 int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t K, const float* in_scale,
-                   const float* in_shift, int32_t in_act, const float* defect_t, const float* bias, int32_t Cout, float* out,
-                   void* workspace, size_t workspace_bytes, uint32_t* counters, pgt_stream_t stream);
+                   const float* in_shift, int32_t in_act, const float* defect_t, const float* bias, int32_t Cout,
+                   int32_t out_groups, float* out, void* workspace, size_t workspace_bytes, uint32_t* counters, pgt_stream_t stream);
 /* pgt_weight_defect: the (K x Cout) fp32 operand `defect_t` of pgt_mean_field_bias for a layer, from its fp32 reference weight
  * (Cout, Cin, KH, KW) (x out_scale[o] where given, e.g. the BatchNorm fold) and the packed 16-bit operand pgt_pack_conv_weight
  * wrote for it: defect_t[k][o] = sum over taps of (w * scale - packed)[o][k][tap], K = Cin_pad; sum_taps = 0 keeps one row per

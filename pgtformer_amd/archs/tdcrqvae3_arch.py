@@ -43,7 +43,7 @@ class Upsample(HipModule):
         if dtype == torch.float32:
             return
         w = self.conv.weight.detach().float()                       # (Cout, Cin, 3, 3)
-        self.sub_w, self.sub_def = {}, {}
+        self.sub_w, self.sub_def, self._def4 = {}, {}, None
         for py in (0, 1):
             for px in (0, 1):
                 w2 = torch.stack([torch.stack([sum(w[:, :, ky, kx] for ky in self._ROWS[py][a] for kx in self._ROWS[px][b])
@@ -59,9 +59,18 @@ class Upsample(HipModule):
         out = torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=x.dtype)
         # a TDResnetBlock's GroupNorm follows: the four launches share one statistics workspace (4 sub-ranges)
         st = ops.GnStats(n, 4, h * w, cout, 32, x.device) if (ops.USE_EPILOGUE_GN and ops.gn_ok(n, h * w, cout)) else None
-        mean = ops.sampled_channel_mean(x) if (self.sub_def[(0, 0)] is not None and (h * w) % 512 == 0) else None
+        mean = fb = None
+        if self.sub_def[(0, 0)] is not None and (h * w) % 512 == 0:
+            if ops.USE_FRAME_BIAS and x.dtype in (torch.float16, torch.bfloat16):
+                # the four sub-pixel convolutions read ONE operand: their defects side by side, one launch, (4, N, Cout) biases
+                if getattr(self, "_def4", None) is None:
+                    self._def4 = torch.cat([self.sub_def[k] for k in self.sub_w], 1).contiguous()
+                    self._pb4 = None if self.conv.pb is None else self.conv.pb.repeat(4).contiguous()
+                fb = ops.frame_bias(x, self._def4, self._pb4, groups=4)
+            else:
+                mean = ops.sampled_channel_mean(x)
         for i, ((py, px), w2) in enumerate(self.sub_w.items()):
-            b = self.conv.pb if mean is None else ops.mean_field_bias(mean, self.sub_def[(py, px)], self.conv.pb)
+            b = fb[i] if fb is not None else (self.conv.pb if mean is None else ops.mean_field_bias(mean, self.sub_def[(py, px)], self.conv.pb))
             ops.conv2d(x, w2, b, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, out_parity=(py, px),
                        gn=None if st is None else (st, i))
         return out if st is None else st.bind(out, cout)

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
 #pragma unroll
             for (int i = 0; i < NPB; ++i) rr[i][0] = rr[i][1] = u32x4{0u, 0u, 0u, 0u};
             if (has_res && vec) {
-                const int soff = mrow * p.ldr * 2;
+                const int soff = (int)((unsigned)mrow * (unsigned)p.ldr * 2u);      // (< 4 GiB by the launcher's check: 32-bit unsigned)
 #pragma unroll
                 for (int i = 0; i < NPB; ++i) {
                     const unsigned vo = (unsigned)(((pxb + 32 * i) * p.ldr + cb) * 2);

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x
                                                          const float* __restrict__ in_shift, int in_act,
                                                          const float* __restrict__ defect_t, const float* __restrict__ bias,
                                                          int Cout, float* __restrict__ out, float* __restrict__ part,
-                                                         unsigned* __restrict__ counters) {
+                                                         unsigned* __restrict__ counters, int csub) {
     __shared__ float sm[32][64 + 1];
     __shared__ float mean[64];
     __shared__ int is_last;
@@ -686,7 +686,9 @@ __global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x
         float t = bias ? bias[o] : 0.f;
         const float* pr = part + (long)n * KS * Cout + o;
         for (int q = 0; q < KS; ++q) t += __hip_atomic_load(pr + (long)q * Cout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // slice order
-        out[(long)n * Cout + o] = t;
+        // out_groups > 1: (groups, N, Cout / groups) - one contiguous (N, csub) bias matrix per group of output columns
+        const int grp = o / csub;
+        out[((long)grp * gridDim.y + n) * csub + (o - grp * csub)] = t;
     }
 }
 
@@ -951,17 +953,20 @@ extern "C" size_t pgt_frame_bias_workspace_bytes(int32_t N, int32_t K, int32_t C
 
 extern "C" int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t K, const float* in_scale,
                               const float* in_shift, int32_t in_act, const float* defect_t, const float* bias, int32_t Cout,
-                              float* out, void* workspace, size_t workspace_bytes, uint32_t* counters, pgt_stream_t stream) {
+                              int32_t out_groups, float* out, void* workspace, size_t workspace_bytes, uint32_t* counters,
+                              pgt_stream_t stream) {
     PGT_CHECK(x && defect_t && out && workspace && counters && N >= 1 && HW >= 1 && Cout >= 1, "frame_bias: null argument");
+    PGT_CHECK(out_groups >= 1 && Cout % out_groups == 0, "frame_bias: out_groups=%d must divide Cout=%d", out_groups, Cout);
+    const int csub = Cout / out_groups;
     PGT_CHECK(K >= 8 && K % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "frame_bias: K=%d (a multiple of 8) / ldx=%d / x alignment", K, ldx);
     PGT_CHECK((in_scale == nullptr) == (in_shift == nullptr), "frame_bias: in_scale and in_shift go together");
     PGT_CHECK(workspace_bytes >= pgt_frame_bias_workspace_bytes(N, K, Cout) && ((uintptr_t)workspace & 3) == 0, "frame_bias: workspace too small");
     const dim3 grid((K + 63) / 64, N), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PGT_BF16)
-        hipLaunchKernelGGL((frame_bias_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters);
+        hipLaunchKernelGGL((frame_bias_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters, csub);
     else if (dtype == PGT_F16)
-        hipLaunchKernelGGL((frame_bias_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters);
+        hipLaunchKernelGGL((frame_bias_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters, csub);
     else
         PGT_CHECK(false, "frame_bias: dtype %d (PGT_BF16 / PGT_F16: the compensated layers are the single-plane 16-bit ones)", dtype);
     PGT_LAUNCH_CHECK();

@@ -680,23 +680,26 @@ def _fb_counters(device, n):
     return c
 
 
-def frame_bias(x, defect_t, bias=None, affine_in=None):
+def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1):
     """(N, Cout) fp32 per-frame bias of a compensated 16-bit layer in ONE launch (pgt_frame_bias): bias + mean_n @ defect_t with
     mean_n the sampled channel mean of frame n of x (N,H,W,K) / (N,HW,K) - or of act(x * scale + shift) rounded to x.dtype when
-    the layer reads its operand through the fused GroupNorm apply (affine_in=(scale, shift, act))."""
+    the layer reads its operand through the fused GroupNorm apply (affine_in=(scale, shift, act)).
+    groups = G > 1: defect_t (K, G * Csub) and bias (G * Csub) hold G layers that read the same operand side by side; returns
+    (G, N, Csub) - out[g] is layer g's contiguous (N, Csub) bias matrix."""
     if x.dim() == 3:
         x = x.unsqueeze(1)
     n, h, w, k = x.shape
     cout = defect_t.shape[1]
     assert defect_t.shape[0] == k and defect_t.is_contiguous() and defect_t.dtype == torch.float32
-    out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    assert cout % groups == 0
+    out = torch.empty((n, cout) if groups == 1 else (groups, n, cout // groups), dtype=torch.float32, device=x.device)
     L = hip.lib()
     nbytes = L.pgt_frame_bias_workspace_bytes(n, k, cout)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     sc, sh, act = affine_in if affine_in is not None else (None, None, ACT_NONE)
     with _Prof("mean_field", 2.0 * n * k * cout, float(n * min(h * w, 1024) * k * x.element_size() + defect_t.numel() * 4)):
         hip.check(L.pgt_frame_bias(_dt(x), _p(x), _ld_img(x), n, h * w, k, _p(sc), _p(sh), int(act), _p(defect_t), _p(bias), cout,
-                                   _p(out), _p(ws), nbytes, _p(_fb_counters(x.device, n)), _stream()), "pgt_frame_bias")
+                                   int(groups), _p(out), _p(ws), nbytes, _p(_fb_counters(x.device, n)), _stream()), "pgt_frame_bias")
     return out
 
 

@@ -256,11 +256,13 @@ def mean_field_bias(mean, defect_t, bias=None):
     return y if bias is None else y + bias.float()
 
 
-def frame_bias(x, defect_t, bias=None, affine_in=None):
-    """pgt_frame_bias: sampled mean (of the fused operand when affine_in is given) + mean-field bias in one call"""
+def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1):
+    """pgt_frame_bias: sampled mean (of the fused operand when affine_in is given) + mean-field bias in one call; groups > 1:
+    (G, N, Csub) - the G layers' bias matrices"""
     if affine_in is not None:
         x = affine_act(x if x.dim() == 4 else x.unsqueeze(1), affine_in[0], affine_in[1], affine_in[2])
-    return mean_field_bias(sampled_channel_mean(x), defect_t, bias)
+    y = mean_field_bias(sampled_channel_mean(x), defect_t, bias)
+    return y if groups == 1 else y.reshape(y.shape[0], groups, -1).permute(1, 0, 2).contiguous()
 
 
 def affine_in_fuses(x, cout, kh, kw, stride, pad, **_kw):

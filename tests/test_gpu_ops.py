@@ -640,6 +640,10 @@ def test_frame_bias_one_launch(dtype):
         xa = O.affine_act(g(buf)[..., :c], g(sc), g(sh), E.ACT_SILU)
         fused = O.frame_bias(g(buf)[..., :c], g(dt_), g(b), affine_in=(g(sc), g(sh), E.ACT_SILU))
         assert torch.equal(fused, O.frame_bias(xa, g(dt_), g(b))), f"frame_bias: fused-operand sample differs ({c})"
+        if cout % 4 == 0:       # G layers side by side (the four sub-pixel convolutions of an Upsample): (G, N, Csub), same numbers
+            grouped = O.frame_bias(g(buf)[..., :c], g(dt_), g(b), groups=4)
+            assert tuple(grouped.shape) == (4, n, cout // 4) and grouped.is_contiguous()
+            assert torch.equal(grouped.permute(1, 0, 2).reshape(n, cout), got)
 
 
 def test_conv2d_output_parity_placement_splitk():
