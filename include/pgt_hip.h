@@ -191,14 +191,21 @@ int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* b
  * fed through pgt_conv2d_affine_in multiplies: in_act(x * in_scale + in_shift) rounded to the tensor's type.  K % 8 == 0.
  * out_groups = 1: out is (N, Cout).  out_groups = G > 1: defect_t / bias hold G layers side by side (Cout = G x Csub columns:
  * the four sub-pixel convolutions of an Upsample read ONE operand) and out is (G, N, Csub) - one contiguous per-frame bias matrix per
- * layer.  workspace: pgt_frame_bias_workspace_bytes(N, K, Cout) bytes of scratch (partial rows per 64-channel slice of K).
+ * layer.  The N "frames" may be BANDS of images (N = images x bands, HW = pixels of a band: consecutive rows of the raster; the
+ * conv then takes bias_rows = HW): the mean field is resolved down the image; scale_div = bands tells which coefficient row of
+ * in_scale / in_shift (one per image) a band uses (1 otherwise); sample_cells (0 = 64) bounds the sample of a band to
+ * sample_cells x 16 pixels (pgt_sampled_pixel_cells(HW, sample_cells, i) = its i-th pixel), so that 16 bands of a small map do not
+ * add up to a pass over the whole tensor.
+ * workspace: pgt_frame_bias_workspace_bytes(N, K, Cout) bytes of scratch (partial rows per 64-channel slice of K).
  * counters: N uint32, ZERO before the first call and left zero by every call (the workgroup that finishes a frame last adds
  * its partial rows in slice order - one fixed order whatever the arrival order: deterministic); calls that may run
  * CONCURRENTLY (other streams) need their own counters, consecutive calls on one stream share them. */
 size_t pgt_frame_bias_workspace_bytes(int32_t N, int32_t K, int32_t Cout);
 int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t K, const float* in_scale,
                    const float* in_shift, int32_t in_act, const float* defect_t, const float* bias, int32_t Cout,
-                   int32_t out_groups, float* out, void* workspace, size_t workspace_bytes, uint32_t* counters, pgt_stream_t stream);
+                   int32_t out_groups, int32_t scale_div, int32_t sample_cells, float* out, void* workspace, size_t workspace_bytes,
+                   uint32_t* counters, pgt_stream_t stream);
+int pgt_sampled_pixel_cells(int32_t HW, int32_t sample_cells, int32_t i);
 /* pgt_weight_defect: the (K x Cout) fp32 operand `defect_t` of pgt_mean_field_bias for a layer, from its fp32 reference weight
  * (Cout, Cin, KH, KW) (x out_scale[o] where given, e.g. the BatchNorm fold) and the packed 16-bit operand pgt_pack_conv_weight
  * wrote for it: defect_t[k][o] = sum over taps of (w * scale - packed)[o][k][tap], K = Cin_pad; sum_taps = 0 keeps one row per

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x
                                                          const float* __restrict__ in_shift, int in_act,
                                                          const float* __restrict__ defect_t, const float* __restrict__ bias,
                                                          int Cout, float* __restrict__ out, float* __restrict__ part,
-                                                         unsigned* __restrict__ counters, int csub) {
+                                                         unsigned* __restrict__ counters, int csub, int scale_div, int cells_max) {
     __shared__ float sm[32][64 + 1];
     __shared__ float mean[64];
     __shared__ int is_last;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x
     const int j = blockIdx.x, KS = gridDim.x, n = blockIdx.y;
     const int c0 = j * 64 + cc * 8;
     int run, cells, cell;
-    mean_sample_geometry(HW, &run, &cells, &cell);
+    mean_sample_geometry(HW, &run, &cells, &cell, cells_max);
     const int S = cells * run;
     float acc[8];
 #pragma unroll
@@ -631,7 +631,10 @@ __global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x
         for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
         if (in_scale) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[e] = in_scale[(long)n * K + c0 + e]; sh[e] = in_shift[(long)n * K + c0 + e]; }
+            for (int e = 0; e < 8; ++e) {      // (scale_div frames - bands - per image: one coefficient row per image)
+                sc[e] = in_scale[(long)(n / scale_div) * K + c0 + e];
+                sh[e] = in_shift[(long)(n / scale_div) * K + c0 + e];
+            }
         }
         const T* base = x + (long)n * HW * ldx + c0;
 #pragma unroll 4
@@ -930,6 +933,14 @@ extern "C" int pgt_sampled_pixel(int32_t HW, int32_t i) {
     return mean_sample_pixel(i, cell, run);
 }
 
+extern "C" int pgt_sampled_pixel_cells(int32_t HW, int32_t sample_cells, int32_t i) {
+    int run, cells, cell;
+    if (HW < 1 || i < 0) return -1;
+    mean_sample_geometry(HW, &run, &cells, &cell, sample_cells);
+    if (i >= cells * run) return -1;
+    return mean_sample_pixel(i, cell, run);
+}
+
 extern "C" int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* bias, int32_t R, int32_t K, int32_t Cout,
                                    float* out, pgt_stream_t stream) {
     PGT_CHECK(mean && defect_t && out && R >= 1 && K >= 1 && Cout >= 1, "mean_field_bias: null argument");
@@ -953,10 +964,11 @@ extern "C" size_t pgt_frame_bias_workspace_bytes(int32_t N, int32_t K, int32_t C
 
 extern "C" int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t HW, int32_t K, const float* in_scale,
                               const float* in_shift, int32_t in_act, const float* defect_t, const float* bias, int32_t Cout,
-                              int32_t out_groups, float* out, void* workspace, size_t workspace_bytes, uint32_t* counters,
-                              pgt_stream_t stream) {
+                              int32_t out_groups, int32_t scale_div, int32_t sample_cells, float* out, void* workspace,
+                              size_t workspace_bytes, uint32_t* counters, pgt_stream_t stream) {
     PGT_CHECK(x && defect_t && out && workspace && counters && N >= 1 && HW >= 1 && Cout >= 1, "frame_bias: null argument");
     PGT_CHECK(out_groups >= 1 && Cout % out_groups == 0, "frame_bias: out_groups=%d must divide Cout=%d", out_groups, Cout);
+    PGT_CHECK(scale_div >= 1 && N % scale_div == 0, "frame_bias: scale_div=%d must divide N=%d", scale_div, N);
     const int csub = Cout / out_groups;
     PGT_CHECK(K >= 8 && K % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "frame_bias: K=%d (a multiple of 8) / ldx=%d / x alignment", K, ldx);
     PGT_CHECK((in_scale == nullptr) == (in_shift == nullptr), "frame_bias: in_scale and in_shift go together");
@@ -964,9 +976,9 @@ extern "C" int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t
     const dim3 grid((K + 63) / 64, N), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PGT_BF16)
-        hipLaunchKernelGGL((frame_bias_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters, csub);
+        hipLaunchKernelGGL((frame_bias_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters, csub, scale_div, sample_cells);
     else if (dtype == PGT_F16)
-        hipLaunchKernelGGL((frame_bias_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters, csub);
+        hipLaunchKernelGGL((frame_bias_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters, csub, scale_div, sample_cells);
     else
         PGT_CHECK(false, "frame_bias: dtype %d (PGT_BF16 / PGT_F16: the compensated layers are the single-plane 16-bit ones)", dtype);
     PGT_LAUNCH_CHECK();

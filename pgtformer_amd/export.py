@@ -33,7 +33,7 @@ R_PERSIST, R_WORK, R_IN, R_OUT = 0, 1, 2, 3
 K_INT, K_F32, K_NULL, K_PTR, K_DESC, K_STREAM = 0, 1, 2, 3, 4, 5
 # functions that only answer questions (no launch, no stream): never part of a tape
 QUERIES = {"pgt_version", "pgt_last_error", "pgt_conv2d_workspace_bytes", "pgt_conv_gn_workspace_bytes", "pgt_conv2d_affine_in_ok",
-           "pgt_groupnorm_workspace_bytes", "pgt_sampled_pixel", "pgt_frame_bias_workspace_bytes", "pgt_sampled_rownorm_workspace_bytes",
+           "pgt_groupnorm_workspace_bytes", "pgt_sampled_pixel", "pgt_sampled_pixel_cells", "pgt_frame_bias_workspace_bytes", "pgt_sampled_rownorm_workspace_bytes",
            "pgt_attn_proj_mlp_sample_workspace_bytes", "pgt_packed_weight_bytes", "pgt_commit_loss_workspace_bytes",
            "pgt_program_load", "pgt_program_destroy", "pgt_program_run", "pgt_program_workspace_bytes", "pgt_program_io_bytes", "pgt_program_info"}
 

@@ -58,7 +58,8 @@ SIGNATURES = {
     "pgt_attn_proj_mlp_sample_workspace_bytes": [i32, i32],
     "pgt_attn_proj_mlp_sample": [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp, vp, vp],
     "pgt_frame_bias_workspace_bytes": [i32, i32, i32],
-    "pgt_frame_bias": [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, vp, sz, vp, vp],
+    "pgt_frame_bias": [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp, vp],
+    "pgt_sampled_pixel_cells": [i32, i32, i32],
     "pgt_mean_field_bias": [vp, vp, vp, i32, i32, i32, vp, vp],
     "pgt_window_attention": [i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pgt_window_attention3d": [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],

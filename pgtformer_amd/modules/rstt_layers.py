@@ -92,8 +92,11 @@ def _frame_bias(x, pdef, pb, frames=None, affine_in=None):
         x = x.as_strided((frames, x.shape[0] // frames, x.shape[1]), (x.stride(0) * (x.shape[0] // frames), x.stride(0), 1))
     elif (x.shape[1] * x.shape[2]) % 512:
         return pb
+    div = 1
+    if x.dim() == 4 and ops.USE_FRAME_BIAS and x.dtype in (torch.float16, torch.bfloat16):
+        x, div = ops.banded(x)        # convolutions: ops.WCOMP_BANDS bias vectors per frame (the token-row chains keep one per frame)
     if ops.USE_FRAME_BIAS and x.dtype in (torch.float16, torch.bfloat16):
-        return ops.frame_bias(x, pdef, pb, affine_in=affine_in)        # one launch (pgt_frame_bias)
+        return ops.frame_bias(x, pdef, pb, affine_in=affine_in, scale_div=div, sample_cells=ops.band_sample_cells(div))        # one launch
     if affine_in is not None:
         x = ops.affine_act(x, *affine_in)
     return ops.mean_field_bias(ops.sampled_channel_mean(x), pdef, pb)

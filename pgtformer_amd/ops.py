@@ -680,12 +680,39 @@ def _fb_counters(device, n):
     return c
 
 
-def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1):
+# The mean field of the weight-rounding compensation is taken per horizontal BAND of a frame: WCOMP_BANDS bias vectors per frame, each
+# for hw / bands consecutive output rows of the raster (pgt_conv_desc::bias_rows) - the part of (W - W16) x that varies slowly down
+# the image is put back as well.  Measured on the two operating points (profiles/r5_i_bands.jsonl): max |dPSNR| 7.2e-4 / 1.02e-3 with
+# one vector per frame, 7.2e-4 / 7.3e-4 with 16 bands.  PGT_WCOMP_BANDS=1: one vector per frame (rounds 3-4).
+WCOMP_BANDS = int(_os.environ.get("PGT_WCOMP_BANDS", "16"))
+
+
+def banded(x, bands=None):
+    """(view, b): x (N,H,W,C) image batch as (N*b, H*W/b, C) - b horizontal bands per frame, the largest power-of-two divisor of
+    `bands` for which a band is a whole number of 512-pixel tiles (b = 1: the frames themselves)"""
+    n, h, w, c = x.shape
+    hw = h * w
+    b = WCOMP_BANDS if bands is None else bands
+    while b > 1 and (hw % b or (hw // b) % 512):
+        b //= 2
+    b = max(1, b)
+    ld = _ld_img(x)
+    return x.as_strided((n * b, hw // b, c), ((hw // b) * ld, ld, 1), x.storage_offset()), b
+
+
+def band_sample_cells(b):
+    """cells of the pixel sample of one band when a frame is cut in b bands: 64 (x 16 pixels) for whole frames, never fewer than 16"""
+    return 0 if b <= 1 else max(16, 64 // b)
+
+
+def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1, scale_div=1, sample_cells=0):
     """(N, Cout) fp32 per-frame bias of a compensated 16-bit layer in ONE launch (pgt_frame_bias): bias + mean_n @ defect_t with
     mean_n the sampled channel mean of frame n of x (N,H,W,K) / (N,HW,K) - or of act(x * scale + shift) rounded to x.dtype when
     the layer reads its operand through the fused GroupNorm apply (affine_in=(scale, shift, act)).
     groups = G > 1: defect_t (K, G * Csub) and bias (G * Csub) hold G layers that read the same operand side by side; returns
-    (G, N, Csub) - out[g] is layer g's contiguous (N, Csub) bias matrix."""
+    (G, N, Csub) - out[g] is layer g's contiguous (N, Csub) bias matrix.
+    scale_div: x's frames are bands of images (ops.banded): scale / shift hold one row per IMAGE = per scale_div frames.
+    sample_cells: 0 = the library's 64 cells x 16 pixels per frame; bands pass band_sample_cells(b)."""
     if x.dim() == 3:
         x = x.unsqueeze(1)
     n, h, w, k = x.shape
@@ -697,9 +724,9 @@ def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1):
     nbytes = L.pgt_frame_bias_workspace_bytes(n, k, cout)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     sc, sh, act = affine_in if affine_in is not None else (None, None, ACT_NONE)
-    with _Prof("mean_field", 2.0 * n * k * cout, float(n * min(h * w, 1024) * k * x.element_size() + defect_t.numel() * 4)):
+    with _Prof("mean_field", 2.0 * n * k * cout, float(n * min(h * w, 16 * (sample_cells or 64)) * k * x.element_size() + defect_t.numel() * 4)):
         hip.check(L.pgt_frame_bias(_dt(x), _p(x), _ld_img(x), n, h * w, k, _p(sc), _p(sh), int(act), _p(defect_t), _p(bias), cout,
-                                   int(groups), _p(out), _p(ws), nbytes, _p(_fb_counters(x.device, n)), _stream()), "pgt_frame_bias")
+                                   int(groups), int(scale_div), int(sample_cells), _p(out), _p(ws), nbytes, _p(_fb_counters(x.device, n)), _stream()), "pgt_frame_bias")
     return out
 
 
@@ -846,12 +873,12 @@ def weight_defect(w, packed, scale=None, sum_taps=True):
     return out
 
 
-def sampled_pixels(hw):
-    """pixel indices of the library's sample of an hw-pixel frame (host-side mirror for tests / emulation)"""
+def sampled_pixels(hw, cells=0):
+    """pixel indices of the library's sample of an hw-pixel frame (host-side mirror for tests / emulation); cells: see frame_bias"""
     L = hip.lib()
     out, i = [], 0
     while True:
-        p = L.pgt_sampled_pixel(hw, i)
+        p = L.pgt_sampled_pixel_cells(hw, cells, i) if cells else L.pgt_sampled_pixel(hw, i)
         if p < 0:
             return out
         out.append(p)

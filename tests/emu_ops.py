@@ -237,18 +237,22 @@ def channel_stats(x, want_var=True):
 _SAMPLES = {}
 
 
-def sampled_pixels(hw):
+def sampled_pixels(hw, cells=0):
     """the library's pixel sample of an hw-pixel frame (pgt_sampled_pixel is host code: callable without a GPU)"""
-    if hw not in _SAMPLES:
+    if (hw, cells) not in _SAMPLES:
         from pgtformer_amd import ops as real_ops
-        _SAMPLES[hw] = torch.tensor(real_ops.sampled_pixels(hw), dtype=torch.long)
-    return _SAMPLES[hw]
+        _SAMPLES[(hw, cells)] = torch.tensor(real_ops.sampled_pixels(hw, cells), dtype=torch.long)
+    return _SAMPLES[(hw, cells)]
 
 
-def sampled_channel_mean(x):
+def band_sample_cells(b):
+    return 0 if b <= 1 else max(16, 64 // b)
+
+
+def sampled_channel_mean(x, cells=0):
     if x.dim() == 4:
         x = x.reshape(x.shape[0], x.shape[1] * x.shape[2], x.shape[3])
-    return x[:, sampled_pixels(x.shape[1]), :].float().mean(1)
+    return x[:, sampled_pixels(x.shape[1], cells), :].float().mean(1)
 
 
 def mean_field_bias(mean, defect_t, bias=None):
@@ -256,12 +260,26 @@ def mean_field_bias(mean, defect_t, bias=None):
     return y if bias is None else y + bias.float()
 
 
-def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1):
+WCOMP_BANDS = 16
+
+
+def banded(x, bands=None):
+    n, h, w, c = x.shape
+    hw = h * w
+    b = WCOMP_BANDS if bands is None else bands
+    while b > 1 and (hw % b or (hw // b) % 512):
+        b //= 2
+    b = max(1, b)
+    return x.reshape(n * b, hw // b, c), b
+
+
+def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1, scale_div=1, sample_cells=0):
     """pgt_frame_bias: sampled mean (of the fused operand when affine_in is given) + mean-field bias in one call; groups > 1:
     (G, N, Csub) - the G layers' bias matrices"""
     if affine_in is not None:
-        x = affine_act(x if x.dim() == 4 else x.unsqueeze(1), affine_in[0], affine_in[1], affine_in[2])
-    y = mean_field_bias(sampled_channel_mean(x), defect_t, bias)
+        sc, sh = (t.repeat_interleave(scale_div, 0) for t in affine_in[:2])
+        x = affine_act(x if x.dim() == 4 else x.unsqueeze(1), sc, sh, affine_in[2])
+    y = mean_field_bias(sampled_channel_mean(x, sample_cells), defect_t, bias)
     return y if groups == 1 else y.reshape(y.shape[0], groups, -1).permute(1, 0, 2).contiguous()
 
 
@@ -577,7 +595,7 @@ ALL = ["conv2d", "linear", "groupnorm_affine", "affine_act", "groupnorm_act", "l
        "maxpool3x3s2", "gate_add", "resize_bilinear_ac", "copy_into", "cast", "prep_input", "nhwc_to_nchw_f32",
        "frame_to_u8", "to_x3", "from_x3", "x3_to_half", "pack_conv_weight", "fold_batchnorm", "sample_rows", "gather_frames", "window_attention3d", "rq_nearest", "rq_soft_codes", "commit_loss",
        "straight_through", "zero_", "vq_cluster_stats", "vq_ema_update", "sampled_channel_mean", "mean_field_bias",
-       "frame_bias", "affine_in_fuses", "sampled_rownorm_mean", "weight_defect", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp", "attn_proj_mlp_sample"]
+       "frame_bias", "banded", "band_sample_cells", "affine_in_fuses", "sampled_rownorm_mean", "weight_defect", "fold_layernorm", "ln_linear", "ln_mlp", "attn_proj_mlp", "attn_proj_mlp_sample"]
 
 
 def install(monkeypatch):

@@ -640,6 +640,18 @@ def test_frame_bias_one_launch(dtype):
         xa = O.affine_act(g(buf)[..., :c], g(sc), g(sh), E.ACT_SILU)
         fused = O.frame_bias(g(buf)[..., :c], g(dt_), g(b), affine_in=(g(sc), g(sh), E.ACT_SILU))
         assert torch.equal(fused, O.frame_bias(xa, g(dt_), g(b))), f"frame_bias: fused-operand sample differs ({c})"
+        if (h * w) % 1024 == 0:     # bands: the frames are horizontal bands of the images, the coefficient rows stay per image (scale_div)
+            xb, nb = O.banded(g(buf)[..., :c], 2)
+            assert nb == 2 and tuple(xb.shape) == (2 * n, h * w // 2, c)
+            fb_bands = O.frame_bias(xb, g(dt_), g(b), affine_in=(g(sc), g(sh), E.ACT_SILU), scale_div=2)
+            assert torch.equal(fb_bands, O.frame_bias(O.banded(xa, 2)[0], g(dt_), g(b)))
+            check(f"frame_bias_bands_{c}", O.frame_bias(xb, g(dt_), g(b)), E.sampled_channel_mean(x.reshape(2 * n, h * w // 2, c)) @ dt_ + b,
+                  torch.float32, tol_scale=0.05)
+            # a sparser sample per band (sample_cells): 16 cells x 16 pixels, the pixels pgt_sampled_pixel_cells names
+            idx = E.sampled_pixels(h * w // 2, 16)
+            assert len(idx) == min(h * w // 2, 256) and len(set(idx.tolist())) == len(idx)
+            check(f"frame_bias_bands_sparse_{c}", O.frame_bias(xb, g(dt_), g(b), sample_cells=16),
+                  E.sampled_channel_mean(x.reshape(2 * n, h * w // 2, c), 16) @ dt_ + b, torch.float32, tol_scale=0.05)
         if cout % 4 == 0:       # G layers side by side (the four sub-pixel convolutions of an Upsample): (G, N, Csub), same numbers
             grouped = O.frame_bias(g(buf)[..., :c], g(dt_), g(b), groups=4)
             assert tuple(grouped.shape) == (4, n, cout // 4) and grouped.is_contiguous()

@@ -261,7 +261,8 @@ def test_weight_rounding_compensation_host_logic(monkeypatch):
         R.USE_WCOMP = True
     # frames that are not whole 512-row tiles: the plain (Cout,) bias is used
     assert R._frame_bias(torch.zeros((2, 8, 8, 32), dtype=torch.float16), conv.pdef, conv.pb) is conv.pb
-    assert R._frame_bias(torch.zeros((2, 32, 32, 32), dtype=torch.float16), conv.pdef, conv.pb).shape == (2, 32)
+    # 32 x 32 = 1024 pixels = two bands of 512: one bias vector per band (ops.banded; round 5), (frames x bands, Cout)
+    assert R._frame_bias(torch.zeros((2, 32, 32, 32), dtype=torch.float16), conv.pdef, conv.pb).shape == (4, 32)
     # token rows: per-frame bias only with a frame count that divides the rows into whole tiles
     lin = R.Linear(64, 48)
     R.prepare_tree(lin, torch.device("cpu"), torch.float16)
