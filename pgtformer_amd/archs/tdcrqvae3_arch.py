@@ -67,7 +67,7 @@ class Upsample(HipModule):
                     self._def4 = torch.cat([self.sub_def[k] for k in self.sub_w], 1).contiguous()
                     self._pb4 = None if self.conv.pb is None else self.conv.pb.repeat(4).contiguous()
                 xb, nb = ops.banded(x)                          # (bands of the INPUT image = bands of every sub-pixel output)
-                fb = ops.frame_bias(xb, self._def4, self._pb4, groups=4, sample_cells=ops.band_sample_cells(nb))
+                fb = ops.frame_bias(xb, self._def4, self._pb4, groups=4, scale_div=nb, sample_cells=ops.band_sample_cells(nb))
             else:
                 mean = ops.sampled_channel_mean(x)
         for i, ((py, px), w2) in enumerate(self.sub_w.items()):

@@ -700,9 +700,12 @@ def banded(x, bands=None):
     return x.as_strided((n * b, hw // b, c), ((hw // b) * ld, ld, 1), x.storage_offset()), b
 
 
+_BAND_CELLS_MIN = int(_os.environ.get("PGT_WCOMP_CELLS", "16"))      # (A/B: smallest sample of a band, in cells of 16 pixels)
+
+
 def band_sample_cells(b):
     """cells of the pixel sample of one band when a frame is cut in b bands: 64 (x 16 pixels) for whole frames, never fewer than 16"""
-    return 0 if b <= 1 else max(16, 64 // b)
+    return 0 if b <= 1 else max(_BAND_CELLS_MIN, 64 // b)
 
 
 def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1, scale_div=1, sample_cells=0):
@@ -711,7 +714,8 @@ def frame_bias(x, defect_t, bias=None, affine_in=None, groups=1, scale_div=1, sa
     the layer reads its operand through the fused GroupNorm apply (affine_in=(scale, shift, act)).
     groups = G > 1: defect_t (K, G * Csub) and bias (G * Csub) hold G layers that read the same operand side by side; returns
     (G, N, Csub) - out[g] is layer g's contiguous (N, Csub) bias matrix.
-    scale_div: x's frames are bands of images (ops.banded): scale / shift hold one row per IMAGE = per scale_div frames.
+    scale_div: x's frames are bands of images (ops.banded), scale_div of them per image (1, 2, 4, 8 or 16): one workgroup serves the
+    bands of an image; scale / shift hold one row per IMAGE.
     sample_cells: 0 = the library's 64 cells x 16 pixels per frame; bands pass band_sample_cells(b)."""
     if x.dim() == 3:
         x = x.unsqueeze(1)
