@@ -608,40 +608,41 @@ __global__ __launch_bounds__(256) void mean_field_bias_kernel(const float* __res
 // that arrives LAST for frame n (a self-resetting counter per frame) adds the partial rows in slice order: one fixed order
 // whatever the arrival order - deterministic without a second launch.
 template <typename T, int BANDS>
-__global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x, int ldx, int HW, int K, const float* __restrict__ in_scale,
-                                                         const float* __restrict__ in_shift, int in_act,
-                                                         const float* __restrict__ defect_t, const float* __restrict__ bias,
-                                                         int Cout, float* __restrict__ out, float* __restrict__ part,
-                                                         unsigned* __restrict__ counters, int csub, int cells_max) {
-    // BANDS consecutive frames (the bands of ONE image: scale_div of the C entry) per workgroup: the slice of defect_t is read once and
-    // multiplied into all of them - with one workgroup per band the 64 x Cout slice was re-read 16 times per image (400 MB of L2 reads
-    // per call at 16 bands: the whole cost of the bands, round 5)
-    __shared__ float sm[32][64 + 1];
+__global__ __launch_bounds__(1024) void frame_bias_kernel(const T* __restrict__ x, int ldx, int HW, int K, const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift, int in_act,
+                                                          const float* __restrict__ defect_t, const float* __restrict__ bias,
+                                                          int Cout, float* __restrict__ out, float* __restrict__ part,
+                                                          unsigned* __restrict__ counters, int csub, int cells_max) {
+    // BANDS consecutive frames (the bands of ONE image: scale_div of the C entry) per workgroup of 1024 threads = 8 channel chunks x
+    // 128 pixel lanes; the lanes are dealt to the bands (128 / BANDS each), so that ALL bands' sample loads are in flight together
+    // (band after band, 256 threads: 16 x two dependent HBM round trips = 50 us per launch at 16 bands, round 5) and the slice of
+    // defect_t is read once for all of them.
+    constexpr int LANES = 128, LPB = LANES / BANDS;     // pixel lanes, lanes per band
+    __shared__ float sm[LANES][64 + 1];
     __shared__ float mean[BANDS][64];
     __shared__ int is_last;
     const int cc = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int bnd_l = pl / LPB, sub = pl - bnd_l * LPB;      // this lane's band and its index among the band's lanes
     const int j = blockIdx.x, KS = gridDim.x, img = blockIdx.y, nframes = gridDim.y * BANDS;
     const int c0 = j * 64 + cc * 8;
     int run, cells, cell;
     mean_sample_geometry(HW, &run, &cells, &cell, cells_max);
     const int S = cells * run;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
-    if (in_scale && c0 < K) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = in_scale[(long)img * K + c0 + e]; sh[e] = in_shift[(long)img * K + c0 + e]; }
-    }
-#pragma unroll 1
-    for (int bnd = 0; bnd < BANDS; ++bnd) {
-        const long n = (long)img * BANDS + bnd;
+    {
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         if (c0 < K) {
-            const T* base = x + n * HW * ldx + c0;
-#pragma unroll 4
-            for (int i = pl; i < S; i += 32) {
+            float sc[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+            if (in_scale) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sc[e] = in_scale[(long)img * K + c0 + e]; sh[e] = in_shift[(long)img * K + c0 + e]; }
+            }
+            const T* base = x + ((long)img * BANDS + bnd_l) * HW * ldx + c0;
+#pragma unroll 8
+            for (int i = sub; i < S; i += LPB) {
                 float v[8];
                 RowIO<T, 8, sizeof(T) == 2>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
                 if (in_scale) {
@@ -659,16 +660,16 @@ __global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x
                 for (int e = 0; e < 8; ++e) acc[e] += v[e];
             }
         }
-        __syncthreads();                               // (the previous band's sums are consumed)
 #pragma unroll
         for (int e = 0; e < 8; ++e) sm[pl][cc * 8 + e] = acc[e];
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            float tot = 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < BANDS * 64) {                    // mean[band][k]: the band's lanes in lane order
+        const int bq = threadIdx.x >> 6, k = threadIdx.x & 63;
+        float tot = 0.f;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) tot += sm[k][threadIdx.x];
-            mean[bnd][threadIdx.x] = j * 64 + (int)threadIdx.x < K ? tot / (float)S : 0.f;
-        }
+        for (int l = 0; l < LPB; ++l) tot += sm[bq * LPB + l][k];
+        mean[bq][k] = j * 64 + k < K ? tot / (float)S : 0.f;
     }
     __syncthreads();
     const int kn = K - j * 64 < 64 ? K - j * 64 : 64;
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x
     // step and evict the concurrent forward's working set.  Instead the partial rows are written and read with agent-scope
     // RELAXED atomics (sc1 accesses: coherent at the memory side, per access), and the counter is bumped only after this
     // workgroup's stores have completed (vmcnt(0) + barrier).
-    for (int o = threadIdx.x; o < Cout; o += 256) {
+    for (int o = threadIdx.x; o < Cout; o += 1024) {
         const float* d = defect_t + (long)j * 64 * Cout + o;
         float a[BANDS];
 #pragma unroll
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x
     if (threadIdx.x == 0) is_last = atomicInc(counters + img, (unsigned)(KS - 1)) == (unsigned)(KS - 1);
     __syncthreads();
     if (!is_last) return;
-    for (int o = threadIdx.x; o < Cout; o += 256) {
+    for (int o = threadIdx.x; o < Cout; o += 1024) {
         const int grp = o / csub;
 #pragma unroll 1
         for (int bnd = 0; bnd < BANDS; ++bnd) {
@@ -990,7 +991,7 @@ extern "C" int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t
     PGT_CHECK((in_scale == nullptr) == (in_shift == nullptr), "frame_bias: in_scale and in_shift go together");
     PGT_CHECK(workspace_bytes >= pgt_frame_bias_workspace_bytes(N, K, Cout) && ((uintptr_t)workspace & 3) == 0, "frame_bias: workspace too small");
     PGT_CHECK(scale_div == 1 || scale_div == 2 || scale_div == 4 || scale_div == 8 || scale_div == 16, "frame_bias: scale_div=%d (bands per image) must be 1, 2, 4, 8 or 16", scale_div);
-    const dim3 grid((K + 63) / 64, N / scale_div), blk(256);      // a workgroup = one 64-channel slice of K x the bands of one image
+    const dim3 grid((K + 63) / 64, N / scale_div), blk(1024);      // a workgroup = one 64-channel slice of K x the bands of one image
     hipStream_t st = (hipStream_t)stream;
 #define FB_GO(T_, B_)                                                                                                                  \
     hipLaunchKernelGGL((frame_bias_kernel<T_, B_>), grid, blk, 0, st, (const T_*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, \
