@@ -644,7 +644,7 @@ def test_frame_bias_one_launch(dtype):
             xb, nb = O.banded(g(buf)[..., :c], 2)
             assert nb == 2 and tuple(xb.shape) == (2 * n, h * w // 2, c)
             fb_bands = O.frame_bias(xb, g(dt_), g(b), affine_in=(g(sc), g(sh), E.ACT_SILU), scale_div=2)
-            assert torch.equal(fb_bands, O.frame_bias(O.banded(xa, 2)[0], g(dt_), g(b)))
+            assert torch.equal(fb_bands, O.frame_bias(O.banded(xa, 2)[0], g(dt_), g(b), scale_div=2))      # (same lanes per band: same sums)
             check(f"frame_bias_bands_{c}", O.frame_bias(xb, g(dt_), g(b)), E.sampled_channel_mean(x.reshape(2 * n, h * w // 2, c)) @ dt_ + b,
                   torch.float32, tol_scale=0.05)
             # a sparser sample per band (sample_cells): 16 cells x 16 pixels, the pixels pgt_sampled_pixel_cells names
