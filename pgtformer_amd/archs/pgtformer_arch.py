@@ -489,7 +489,11 @@ class PGTFormer(TDCRQVAE3):
             self.__dict__["_side_stream"] = side
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                cond, pos = condition_branch()
+                keep_branch, ops.BRANCH = ops.BRANCH, 1      # concurrent with the encoder: its own frame_bias arrival counters
+                try:
+                    cond, pos = condition_branch()
+                finally:
+                    ops.BRANCH = keep_branch
         else:
             cond, pos = condition_branch()
         self.last_cond = cond

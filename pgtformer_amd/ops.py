@@ -661,20 +661,23 @@ def mean_field_bias(mean, defect_t, bias=None):
     return out
 
 
-# pgt_frame_bias: per-frame arrival counters (zero between calls).  Consecutive calls on one stream share them; forwards that run
-# CONCURRENTLY need their own: the driver's lanes set LANE around their forwards (driver.WindowRunner).  Allocated once per
+# pgt_frame_bias: per-frame arrival counters (zero between calls).  Consecutive calls on one stream share them; launches that run
+# CONCURRENTLY need their own: the driver's lanes set LANE around their forwards (driver.WindowRunner), the model sets BRANCH around the
+# sub-network it runs on a second stream.  Allocated once per
 # (device, lane) OUTSIDE any graph capture (the lanes' eager warm-up passes come first) and never freed.
 LANE = 0
+BRANCH = 0          # 1 inside the condition branch that PGTFormer forks onto a second stream (archs/pgtformer_arch.py): in the pure-bf16 mode
+#                     BiSeNet's convolutions are compensated too, and its frame_bias launches run CONCURRENTLY with the encoder's
 _FB_COUNTERS = {}
 _FB_MAX_FRAMES = 4096
 
 
 def _fb_counters(device, n):
-    key = (str(device), LANE)
+    key = (str(device), LANE, BRANCH)
     c = _FB_COUNTERS.get(key)
     if c is None:
         if torch.cuda.is_current_stream_capturing():
-            raise hip.PgtError("frame_bias: first use for lane %d inside a graph capture (run one eager forward first)" % LANE)
+            raise hip.PgtError("frame_bias: first use for lane %d / branch %d inside a graph capture (run one eager forward first)" % (LANE, BRANCH))
         c = _FB_COUNTERS[key] = torch.zeros(_FB_MAX_FRAMES, dtype=torch.int32, device=device)
     assert n <= _FB_MAX_FRAMES
     return c

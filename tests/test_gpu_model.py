@@ -471,6 +471,8 @@ def test_teacher_forced_decoder_and_concat_paths(models, golden_window, prec):
     out_d, _, _ = m.forward_nhwc(frames, w=1.0, codes=codes)
     out_c, _, _ = m.forward_nhwc(frames, w=1.0, codes=codes, direct=False)
     torch.cuda.synchronize()
+    for _ in range(4):      # (round 5: a race between the two streams of a forward showed as a RARE difference here - repeat)
+        assert torch.equal(m.forward_nhwc(frames, w=1.0, codes=codes)[0], out_d)
     assert torch.equal(m.last_codes.cpu().reshape(-1), codes.reshape(-1).to(torch.int32))
     same = torch.equal(out_d, out_c)
     dmax = float((out_d.float() - out_c.float()).abs().max())

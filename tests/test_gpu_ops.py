@@ -617,6 +617,40 @@ def test_conv2d_c64_ring_kernel(shape, dtype):
     assert torch.equal(small, O.conv2d(O.affine_act(d_x, g(sc[:1].contiguous()), g(sh[:1].contiguous()), E.ACT_SILU), gw, gb, **kw))
 
 
+def test_frame_bias_concurrent_streams_need_their_own_counters():
+    """The arrival counters of pgt_frame_bias are shared by consecutive launches of ONE stream; launches that run concurrently must
+    not share them (found in round 5: in the pure-bf16 mode BiSeNet's compensated convs on the side stream raced with the encoder's,
+    a flaky bit-difference).  ops.BRANCH / ops.LANE select the counter set: two streams with their own sets always reproduce the
+    single-stream result."""
+    O = ops()
+    x = (rnd((96, 64, 64, 256), 71, torch.float16) + 0.25)
+    dt_, b = rnd((256, 256), 72) * 1e-3, rnd((256,), 73)
+    gx, gd, gb = g(x), g(dt_), g(b)
+    want = O.frame_bias(gx, gd, gb).clone()
+    assert O._fb_counters(gx.device, 96) is not None
+    keep = O.BRANCH
+    try:
+        O.BRANCH = 1
+        c1 = O._fb_counters(gx.device, 96)
+        O.BRANCH = 0
+        assert c1.data_ptr() != O._fb_counters(gx.device, 96).data_ptr()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = []
+        for i in range(200):
+            with torch.cuda.stream(s1):
+                O.BRANCH = 0
+                outs.append(O.frame_bias(gx, gd, gb))
+            with torch.cuda.stream(s2):
+                O.BRANCH = 1
+                outs.append(O.frame_bias(gx, gd, gb))
+        torch.cuda.synchronize()
+    finally:
+        O.BRANCH = keep
+    assert all(torch.equal(o, want) for o in outs)
+    assert int(O._fb_counters(gx.device, 96).abs().sum()) == 0 and int(c1.abs().sum()) == 0      # every call left its counters at zero
+
+
 @pytest.mark.parametrize("dtype", H16, ids=["bf16", "f16"])
 def test_frame_bias_one_launch(dtype):
     """pgt_frame_bias (round 5): sampled channel mean + mean-field bias in ONE launch, against the emulation and against the two
