@@ -192,9 +192,8 @@ int pgt_mean_field_bias(const float* mean, const float* defect_t, const float* b
  * out_groups = 1: out is (N, Cout).  out_groups = G > 1: defect_t / bias hold G layers side by side (Cout = G x Csub columns:
  * the four sub-pixel convolutions of an Upsample read ONE operand) and out is (G, N, Csub) - one contiguous per-frame bias matrix per
  * layer.  The N "frames" may be BANDS of images (N = images x bands, HW = pixels of a band: consecutive rows of the raster; the
- * conv then takes bias_rows = HW): the mean field is resolved down the image; scale_div = bands per image (1, 2, 4, 8, 16; N a multiple
- * of it): one workgroup serves the bands of an image (defect_t is read once for all of them, in_scale / in_shift hold one row per image,
- * counters: one per image); sample_cells (0 = 64) bounds the sample of a band to
+ * conv then takes bias_rows = HW): the mean field is resolved down the image; scale_div = bands tells which coefficient row of
+ * in_scale / in_shift (one per image) a band uses (1 otherwise); sample_cells (0 = 64) bounds the sample of a band to
  * sample_cells x 16 pixels (pgt_sampled_pixel_cells(HW, sample_cells, i) = its i-th pixel), so that 16 bands of a small map do not
  * add up to a pass over the whole tensor.
  * workspace: pgt_frame_bias_workspace_bytes(N, K, Cout) bytes of scratch (partial rows per 64-channel slice of K).

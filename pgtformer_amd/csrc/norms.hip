@@ -607,108 +607,91 @@ __global__ __launch_bounds__(256) void mean_field_bias_kernel(const float* __res
 // (j, n) takes the sampled sums of its 64 channels, multiplies them into a partial output row part[n][j][:], and the workgroup
 // that arrives LAST for frame n (a self-resetting counter per frame) adds the partial rows in slice order: one fixed order
 // whatever the arrival order - deterministic without a second launch.
-template <typename T, int BANDS>
-__global__ __launch_bounds__(1024) void frame_bias_kernel(const T* __restrict__ x, int ldx, int HW, int K, const float* __restrict__ in_scale,
-                                                          const float* __restrict__ in_shift, int in_act,
-                                                          const float* __restrict__ defect_t, const float* __restrict__ bias,
-                                                          int Cout, float* __restrict__ out, float* __restrict__ part,
-                                                          unsigned* __restrict__ counters, int csub, int cells_max) {
-    // BANDS consecutive frames (the bands of ONE image: scale_div of the C entry) per workgroup of 1024 threads = 8 channel chunks x
-    // 128 pixel lanes; the lanes are dealt to the bands (128 / BANDS each), so that ALL bands' sample loads are in flight together
-    // (band after band, 256 threads: 16 x two dependent HBM round trips = 50 us per launch at 16 bands, round 5) and the slice of
-    // defect_t is read once for all of them.
-    constexpr int LANES = 128, LPB = LANES / BANDS;     // pixel lanes, lanes per band
-    __shared__ float sm[LANES][64 + 1];
-    __shared__ float mean[BANDS][64];
+template <typename T>
+__global__ __launch_bounds__(256) void frame_bias_kernel(const T* __restrict__ x, int ldx, int HW, int K, const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift, int in_act,
+                                                         const float* __restrict__ defect_t, const float* __restrict__ bias,
+                                                         int Cout, float* __restrict__ out, float* __restrict__ part,
+                                                         unsigned* __restrict__ counters, int csub, int scale_div, int cells_max) {
+    __shared__ float sm[32][64 + 1];
+    __shared__ float mean[64];
     __shared__ int is_last;
     const int cc = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const int bnd_l = pl / LPB, sub = pl - bnd_l * LPB;      // this lane's band and its index among the band's lanes
-    const int j = blockIdx.x, KS = gridDim.x, img = blockIdx.y, nframes = gridDim.y * BANDS;
+    const int j = blockIdx.x, KS = gridDim.x, n = blockIdx.y;
     const int c0 = j * 64 + cc * 8;
     int run, cells, cell;
     mean_sample_geometry(HW, &run, &cells, &cell, cells_max);
     const int S = cells * run;
-    {
-        float acc[8];
+    float acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        if (c0 < K) {
-            float sc[8], sh[8];
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < K) {
+        float sc[8], sh[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
-            if (in_scale) {
+        for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+        if (in_scale) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { sc[e] = in_scale[(long)img * K + c0 + e]; sh[e] = in_shift[(long)img * K + c0 + e]; }
-            }
-            const T* base = x + ((long)img * BANDS + bnd_l) * HW * ldx + c0;
-#pragma unroll 8
-            for (int i = sub; i < S; i += LPB) {
-                float v[8];
-                RowIO<T, 8, sizeof(T) == 2>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
-                if (in_scale) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-                    act_vec<T, 8>(v, in_act);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {      // the rounding the consuming kernel applies to its operand
-                        T r;
-                        stf(&r, v[e]);
-                        v[e] = ldf(&r);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            for (int e = 0; e < 8; ++e) {      // (scale_div frames - bands - per image: one coefficient row per image)
+                sc[e] = in_scale[(long)(n / scale_div) * K + c0 + e];
+                sh[e] = in_shift[(long)(n / scale_div) * K + c0 + e];
             }
         }
+        const T* base = x + (long)n * HW * ldx + c0;
+#pragma unroll 4
+        for (int i = pl; i < S; i += 32) {
+            float v[8];
+            RowIO<T, 8, sizeof(T) == 2>::ld(base + (long)mean_sample_pixel(i, cell, run) * ldx, v);
+            if (in_scale) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sm[pl][cc * 8 + e] = acc[e];
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+                act_vec<T, 8>(v, in_act);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {      // the rounding the consuming kernel applies to its operand
+                    T r;
+                    stf(&r, v[e]);
+                    v[e] = ldf(&r);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[pl][cc * 8 + e] = acc[e];
     __syncthreads();
-    if (threadIdx.x < BANDS * 64) {                    // mean[band][k]: the band's lanes in lane order
-        const int bq = threadIdx.x >> 6, k = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
         float tot = 0.f;
 #pragma unroll
-        for (int l = 0; l < LPB; ++l) tot += sm[bq * LPB + l][k];
-        mean[bq][k] = j * 64 + k < K ? tot / (float)S : 0.f;
+        for (int k = 0; k < 32; ++k) tot += sm[k][threadIdx.x];
+        mean[threadIdx.x] = j * 64 + (int)threadIdx.x < K ? tot / (float)S : 0.f;
     }
     __syncthreads();
     const int kn = K - j * 64 < 64 ? K - j * 64 : 64;
+    float* prow = part + ((long)n * KS + j) * Cout;
     // Cross-workgroup hand-over WITHOUT device-scope fences: on this chip a release / acquire fence at agent scope writes back
     // and invalidates the XCD's whole L2 (8 XCDs, one L2 each) - measured: 768 workgroups fencing per call cost 3.8 % of the
     // step and evict the concurrent forward's working set.  Instead the partial rows are written and read with agent-scope
     // RELAXED atomics (sc1 accesses: coherent at the memory side, per access), and the counter is bumped only after this
     // workgroup's stores have completed (vmcnt(0) + barrier).
-    for (int o = threadIdx.x; o < Cout; o += 1024) {
+    for (int o = threadIdx.x; o < Cout; o += 256) {
         const float* d = defect_t + (long)j * 64 * Cout + o;
-        float a[BANDS];
-#pragma unroll
-        for (int bnd = 0; bnd < BANDS; ++bnd) a[bnd] = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < kn; ++k) {
-            const float dv = d[(long)k * Cout];
-#pragma unroll
-            for (int bnd = 0; bnd < BANDS; ++bnd) a[bnd] += dv * mean[bnd][k];
-        }
-#pragma unroll
-        for (int bnd = 0; bnd < BANDS; ++bnd)
-            __hip_atomic_store(part + (((long)img * BANDS + bnd) * KS + j) * Cout + o, a[bnd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float a = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < kn; ++k) a += d[(long)k * Cout] * mean[k];
+        __hip_atomic_store(prow + o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial values have reached the coherent level ...
     __syncthreads();                                   // ... every thread's have
-    if (threadIdx.x == 0) is_last = atomicInc(counters + img, (unsigned)(KS - 1)) == (unsigned)(KS - 1);
+    if (threadIdx.x == 0) is_last = atomicInc(counters + n, (unsigned)(KS - 1)) == (unsigned)(KS - 1);
     __syncthreads();
     if (!is_last) return;
-    for (int o = threadIdx.x; o < Cout; o += 1024) {
+    for (int o = threadIdx.x; o < Cout; o += 256) {
+        float t = bias ? bias[o] : 0.f;
+        const float* pr = part + (long)n * KS * Cout + o;
+        for (int q = 0; q < KS; ++q) t += __hip_atomic_load(pr + (long)q * Cout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // slice order
+        // out_groups > 1: (groups, N, Cout / groups) - one contiguous (N, csub) bias matrix per group of output columns
         const int grp = o / csub;
-#pragma unroll 1
-        for (int bnd = 0; bnd < BANDS; ++bnd) {
-            const long n = (long)img * BANDS + bnd;
-            float t = bias ? bias[o] : 0.f;
-            const float* pr = part + n * KS * Cout + o;
-            for (int q = 0; q < KS; ++q) t += __hip_atomic_load(pr + (long)q * Cout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // slice order
-            // out_groups > 1: (groups, N, Cout / groups) - one contiguous (N, csub) bias matrix per group of output columns
-            out[((long)grp * nframes + n) * csub + (o - grp * csub)] = t;
-        }
+        out[((long)grp * gridDim.y + n) * csub + (o - grp * csub)] = t;
     }
 }
 
@@ -990,21 +973,14 @@ extern "C" int pgt_frame_bias(int32_t dtype, const void* x, int32_t ldx, int32_t
     PGT_CHECK(K >= 8 && K % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "frame_bias: K=%d (a multiple of 8) / ldx=%d / x alignment", K, ldx);
     PGT_CHECK((in_scale == nullptr) == (in_shift == nullptr), "frame_bias: in_scale and in_shift go together");
     PGT_CHECK(workspace_bytes >= pgt_frame_bias_workspace_bytes(N, K, Cout) && ((uintptr_t)workspace & 3) == 0, "frame_bias: workspace too small");
-    PGT_CHECK(scale_div == 1 || scale_div == 2 || scale_div == 4 || scale_div == 8 || scale_div == 16, "frame_bias: scale_div=%d (bands per image) must be 1, 2, 4, 8 or 16", scale_div);
-    const dim3 grid((K + 63) / 64, N / scale_div), blk(1024);      // a workgroup = one 64-channel slice of K x the bands of one image
+    const dim3 grid((K + 63) / 64, N), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define FB_GO(T_, B_)                                                                                                                  \
-    hipLaunchKernelGGL((frame_bias_kernel<T_, B_>), grid, blk, 0, st, (const T_*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, \
-                       Cout, out, (float*)workspace, counters, csub, sample_cells)
-#define FB_T(T_)                                                                                              \
-    switch (scale_div) { case 1: FB_GO(T_, 1); break; case 2: FB_GO(T_, 2); break; case 4: FB_GO(T_, 4); break;  \
-                         case 8: FB_GO(T_, 8); break; default: FB_GO(T_, 16); }
-    if (dtype == PGT_BF16) { FB_T(bf16_t) }
-    else if (dtype == PGT_F16) { FB_T(half_t) }
+    if (dtype == PGT_BF16)
+        hipLaunchKernelGGL((frame_bias_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters, csub, scale_div, sample_cells);
+    else if (dtype == PGT_F16)
+        hipLaunchKernelGGL((frame_bias_kernel<half_t>), grid, blk, 0, st, (const half_t*)x, ldx, HW, K, in_scale, in_shift, in_act, defect_t, bias, Cout, out, (float*)workspace, counters, csub, scale_div, sample_cells);
     else
         PGT_CHECK(false, "frame_bias: dtype %d (PGT_BF16 / PGT_F16: the compensated layers are the single-plane 16-bit ones)", dtype);
-#undef FB_T
-#undef FB_GO
     PGT_LAUNCH_CHECK();
     return 0;
 }
