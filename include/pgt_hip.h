@@ -444,7 +444,8 @@ int pgt_zero2d(void* dst, int64_t ldd_bytes, int64_t rows, int32_t row_bytes, pg
 int pgt_count_saturated(const void* x, int64_t ldx, int64_t rows, int32_t cols, int32_t* count, pgt_stream_t stream);
 
 /* ---- driver edges (inference.py:6-19) ----------------------------------------------------------
- * input window -> channels-last 8-channel (RGB + 5 zero) tensors: raw = v/255 (encoder input) and
+ * input window -> channels-last tensors of ONE 16-byte chunk per pixel (RGB + zeros: 4 channels in fp32, 8 in a 16-bit
+ * dtype - the input-channel granularity of pgt_conv2d): raw = v/255 (encoder input) and
  * norm = (v/255 - mean)/std (BiSeNet input, transforms.Normalize pgtformer_arch.py:554-556,606).
  * src_kind 0: uint8 (N,H,W,3) HWC frames; 1: fp32 (N,3,H,W) in [0,1] */
 int pgt_prep_input(int32_t dtype, const void* src, int32_t src_kind, int32_t N, int32_t H, int32_t W,

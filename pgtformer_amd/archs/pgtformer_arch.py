@@ -69,7 +69,7 @@ def create_layer_basic(in_chan, out_chan, bnum, stride=1):
 class Resnet18(HipModule):
     def __init__(self):
         super().__init__()
-        self.conv1 = Conv2d(3, 64, 7, stride=2, padding=3, bias=False, cin_pad=8)
+        self.conv1 = Conv2d(3, 64, 7, stride=2, padding=3, bias=False, cin_pad="chunk")
         self.bn1 = _bn(64)
         self.conv1._bn_ref = (self.bn1,)
         self.layer1 = create_layer_basic(64, 64, bnum=2, stride=1)
@@ -200,7 +200,7 @@ class BiSeNet(HipModule):
                 m._pack(device, X3F)
 
     def forward(self, x):
-        """x: (N,512,512,8) ImageNet-normalised -> (N,32,32,64): 3*n_classes parsing logits + zero pad."""
+        """x: (N,512,512,ops.input_channels(dtype)) ImageNet-normalised -> (N,32,32,64): 3*n_classes parsing logits + zero pad."""
         nc = self.n_classes
         feat_res8, feat_cp8, feat_cp16 = self.cp(x)
         feat_fuse = self.ffm(feat_res8, feat_cp8)

@@ -310,7 +310,7 @@ class Encoder(HipModule):
         super().__init__()
         self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
         self.resolution, self.in_channels = resolution, in_channels
-        self.conv_in = Conv2d(in_channels, ch, 3, padding=1, cin_pad=8)
+        self.conv_in = Conv2d(in_channels, ch, 3, padding=1, cin_pad="chunk")
         curr_res = resolution
         in_ch_mult = (1,) + tuple(ch_mult)
         self.down = nn.ModuleList()
@@ -363,7 +363,7 @@ class Encoder(HipModule):
         return h
 
     def forward(self, x, return_multi_res_feats=False, feat_out=None, win=None, want_feats=None, feat_dtype=None):
-        """x: (F, H, W, 8) channel-padded input (reference: :540-573).  feat_out: {level: (B*T,h,w,C) view} - the
+        """x: (F, H, W, ops.input_channels(dtype)) channel-padded input (reference: :540-573).  feat_out: {level: (B*T,h,w,C) view} - the
         level's feature map is delivered in that view (a channel slice of the decoder-side concat buffer): written
         in place by the producing kernel when the dtypes and frame order allow it, else copied / gathered into it.
 
@@ -652,7 +652,7 @@ class TDCRQVAE3(HubMixin, HipModule):
 
     # -- stage-I API (reference: :760-813) ----------------------------------------------------
     def _ingest(self, x):
-        """(B*T,3,H,W) fp32 in [0,1] or uint8 (B*T,H,W,3) -> raw / ImageNet-normalised (B*T,H,W,8)."""
+        """(B*T,3,H,W) fp32 in [0,1] or uint8 (B*T,H,W,3) -> raw / ImageNet-normalised (B*T,H,W,ops.input_channels(in_dt))."""
         self._check_ready()
         x = x.to(self.dev)
         if x.dim() == 5:                      # the reference's (b, t, c, h, w) clips (tdcrqvae3_arch.py:760-764)

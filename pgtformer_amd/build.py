@@ -33,7 +33,7 @@ def build(force=False, verbose=True):
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hdr_m = max(os.path.getmtime(os.path.join(d, f)) for d in (CSRC, INCLUDE) for f in os.listdir(d)
-                if f.endswith(".h"))
+                if f.endswith((".h", ".inc")))
     objs, todo = [], []
     for src in sources():
         sp = os.path.join(CSRC, src)

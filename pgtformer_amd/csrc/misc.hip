@@ -214,13 +214,12 @@ __global__ void copy2d_vec16_kernel(const uint4* __restrict__ src, long lds16, u
 template <typename T>
 __global__ void prep_input_kernel(const void* __restrict__ src, int kind, int N, int H, int W, T* __restrict__ raw,
                                   T* __restrict__ norm) {
+    constexpr int CP = 16 / (int)sizeof(T);      // channels of an output pixel: RGB + zeros up to one 16-byte chunk
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // pixel index
     if (i >= (long)N * H * W) return;
     const float mean[3] = {0.485f, 0.456f, 0.406f};
     const float stdv[3] = {0.229f, 0.224f, 0.225f};
-    float r[8], nn[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) r[c] = nn[c] = 0.f;
+    float r[3];
     if (kind == 0) {
         const uint8_t* s = (const uint8_t*)src + i * 3;
 #pragma unroll
@@ -232,13 +231,15 @@ __global__ void prep_input_kernel(const void* __restrict__ src, int kind, int N,
 #pragma unroll
         for (int c = 0; c < 3; ++c) r[c] = s[c * hw];
     }
+    union { uint4 v; T e[CP]; } a, b;
+    a.v = b.v = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) nn[c] = (r[c] - mean[c]) / stdv[c];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        if (raw) stf(raw + i * 8 + c, r[c]);
-        if (norm) stf(norm + i * 8 + c, nn[c]);
+    for (int c = 0; c < 3; ++c) {
+        stf(a.e + c, r[c]);
+        stf(b.e + c, (r[c] - mean[c]) / stdv[c]);
     }
+    if (raw) *reinterpret_cast<uint4*>(raw + i * CP) = a.v;
+    if (norm) *reinterpret_cast<uint4*>(norm + i * CP) = b.v;
 }
 
 template <typename T>
@@ -623,6 +624,7 @@ extern "C" int pgt_prep_input(int32_t dtype, const void* src, int32_t src_kind, 
                               void* raw, void* norm, pgt_stream_t stream) {
     PGT_CHECK(src && (raw || norm), "prep_input: null argument");
     PGT_CHECK(src_kind == 0 || src_kind == 1, "prep_input: src_kind must be 0 (u8 NHWC) or 1 (f32 NCHW)");
+    PGT_CHECK(((((uintptr_t)raw) | ((uintptr_t)norm)) & 15) == 0, "prep_input: raw / norm must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g = grid1d((long)N * H * W);
     DT_DISPATCH_T(dtype, "prep_input",

@@ -94,9 +94,17 @@ extern "C" int pgt_program_load(const char* path, pgt_program** out) {
         if (!rd(f, &fid, 2) || !rd(f, &na, 2) || fid >= nfn || na > 32) return fail("bad call record");
         if (map[fid] < 0) return fail("the tape calls a function this library does not have");
         Call cl{map[fid], (uint32_t)pr->args.size(), na};
+        // the record against the parameter list of the function it names: count and class of every argument (a descriptor
+        // is host memory, a pointer device memory, an integer must not land in a pointer parameter)
+        const char* sig = kTapeSig[cl.fn];
+        if (strlen(sig) != na) return fail("argument count of another library version");
         for (uint16_t k = 0; k < na; ++k) {
             ArgRec r;
             if (!rd(f, &r.kind, 4) || !rd(f, &r.aux, 4) || !rd(f, &r.value, 8)) return fail("bad argument record");
+            const char want = sig[k];
+            const bool ok = r.kind == K_INT ? want == 'i' : r.kind == K_F32 ? want == 'f' : r.kind == K_DESC ? want == 'd' :
+                            r.kind == K_STREAM ? want == 's' : (r.kind == K_NULL || r.kind == K_PTR) ? want == 'p' : false;
+            if (!ok) return fail("argument of the wrong class for its parameter");
             pr->args.push_back(r);
         }
         pr->calls.push_back(cl);
@@ -107,12 +115,12 @@ extern "C" int pgt_program_load(const char* path, pgt_program** out) {
     if (pool_bytes && !rd(f, pr->pool.data(), pool_bytes)) return fail("truncated descriptor pool");
     // every argument is checked once here, so that pgt_program_run cannot step outside the regions
     for (const ArgRec& r : pr->args) {
-        if (r.kind == K_DESC && (r.value + r.aux > pool_bytes || r.aux != sizeof(pgt_conv_desc))) return fail("descriptor of another library version");
+        if (r.kind == K_DESC && (r.aux != sizeof(pgt_conv_desc) || r.value > pool_bytes || pool_bytes - r.value < r.aux || r.value % 8 != 0))
+            return fail("descriptor of another library version");
         if (r.kind == K_PTR) {
             const uint64_t lim = r.aux == R_PERSIST ? pr->persist_bytes : r.aux == R_WORK ? pr->work_bytes : r.aux == R_IN ? pr->in_bytes : r.aux == R_OUT ? pr->out_bytes : 0;
             if (r.value >= lim) return fail("pointer outside its region");
         }
-        if (r.kind > K_STREAM) return fail("unknown argument kind");
     }
     if (pr->persist_bytes) {
         if (hipMalloc((void**)&pr->persist, pr->persist_bytes) != hipSuccess) return fail("cannot allocate the persistent block");

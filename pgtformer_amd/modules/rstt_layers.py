@@ -109,7 +109,7 @@ def _f32(t, device):
 class Conv2d(nn.Conv2d, HipModule):
     """nn.Conv2d parameter container + implicit-GEMM launch. Weight (Cout,Cin,KH,KW) is repacked to
     (Cout, KH*KW*Cin) K-major; `bn` folds an eval-mode BatchNorm2d; `cin_pad` zero-pads input channels
-    (3->8, 57->64) to the 16-byte gather granule."""
+    (57->64; "chunk": 3 -> one 16-byte chunk of the layer's dtype, 4 in fp32 / 8 in 16 bits) to the 16-byte gather granule."""
 
     def __init__(self, cin, cout, k, stride=1, padding=0, bias=True, pad4=None, cin_pad=None):
         nn.Conv2d.__init__(self, cin, cout, k, stride=stride, padding=padding, bias=bias)
@@ -125,7 +125,10 @@ class Conv2d(nn.Conv2d, HipModule):
             scale, b = ops.fold_batchnorm(_f32(bn.weight, device), _f32(bn.bias, device), _f32(bn.running_mean, device),
                                           _f32(bn.running_var, device), bn.eps, b)
         cout, cin, kh, kw = self.weight.shape
-        cin_k = self._fold_cin = self.cin_pad if (self.cin_pad is not None and self.cin_pad > cin) else cin
+        cpad = self.cin_pad
+        if cpad == "chunk":      # the 3-channel input layers: one 16-byte chunk per pixel (ops.prep_input writes exactly that)
+            cpad = ops.input_channels(dtype) if isinstance(dtype, torch.dtype) else 8
+        cin_k = self._fold_cin = cpad if (cpad is not None and cpad > cin) else cin
         self.pw = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale)
         self.pb = b
         self.pdef = _defect_t(self.weight, self.pw, scale=scale) if _wants_wcomp(dtype) else None

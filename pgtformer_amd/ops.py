@@ -1146,8 +1146,15 @@ def zero_(t):
     return t
 
 
+def input_channels(dtype):
+    """Channels the 3-channel input frames are padded to: one 16-byte chunk (the K granularity of pgt_conv2d's gather) - 4 in
+    fp32 (K = 36 / 196 for the 3x3 / 7x7 input layers instead of 72 / 392), 8 in bf16 / half."""
+    return 16 // torch.empty((), dtype=dtype).element_size()
+
+
 def prep_input(src, dtype, want_raw=True, want_norm=True):
-    """src: uint8 (N,H,W,3) or float32 (N,3,H,W) -> raw, norm as (N,H,W,8) channel-padded tensors."""
+    """src: uint8 (N,H,W,3) or float32 (N,3,H,W) -> raw, norm as (N,H,W,input_channels(dtype)) channel-padded tensors
+    (one 16-byte chunk per pixel: 4 channels in fp32, 8 in a 16-bit dtype)."""
     if src.dtype == torch.uint8:
         n, h, w, _ = src.shape
         kind = 0
@@ -1156,8 +1163,9 @@ def prep_input(src, dtype, want_raw=True, want_norm=True):
         n, _, h, w = src.shape
         kind = 1
     assert src.is_contiguous()
-    raw = torch.empty((n, h, w, 8), device=src.device, dtype=dtype) if want_raw else None
-    norm = torch.empty((n, h, w, 8), device=src.device, dtype=dtype) if want_norm else None
+    cp = input_channels(dtype)
+    raw = torch.empty((n, h, w, cp), device=src.device, dtype=dtype) if want_raw else None
+    norm = torch.empty((n, h, w, cp), device=src.device, dtype=dtype) if want_norm else None
     ref = raw if raw is not None else norm
     hip.check(hip.lib().pgt_prep_input(_dt(ref), _p(src), kind, n, h, w, _p(raw), _p(norm), _stream()),
               "pgt_prep_input")

@@ -566,6 +566,10 @@ def zero_(t):
     return t
 
 
+def input_channels(dtype):
+    return 16 // torch.empty((), dtype=dtype).element_size()
+
+
 def prep_input(src, dtype, want_raw=True, want_norm=True):
     if src.dtype == torch.uint8:
         r = src.float() / 255.0
@@ -574,7 +578,7 @@ def prep_input(src, dtype, want_raw=True, want_norm=True):
     mean = torch.tensor([0.485, 0.456, 0.406])
     std = torch.tensor([0.229, 0.224, 0.225])
     nn_ = (r - mean) / std
-    pad = lambda t: F.pad(t, (0, 5)).to(dtype).contiguous()  # noqa: E731
+    pad = lambda t: F.pad(t, (0, input_channels(dtype) - 3)).to(dtype).contiguous()  # noqa: E731
     return (pad(r) if want_raw else None), (pad(nn_) if want_norm else None)
 
 

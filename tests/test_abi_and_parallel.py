@@ -271,3 +271,19 @@ def test_program_file_format_round_trip_and_error_paths(tmp_path):
     rc, hh, msg = load(bad)
     assert rc == -22 and "descriptor" in msg
     assert load(str(tmp_path / "missing.prog"))[0] == -22
+    # call records are checked against the parameter list of the function they name: a missing argument, an integer where a pointer
+    # goes, a device pointer where the host descriptor goes, a stream that is not the last argument
+    for what, recs, expect in (
+            ("short", tape[0][1][:3] + [tape[0][1][-1]], "argument count"),
+            ("int_for_ptr", [(k.K_INT, 0, 7)] + tape[0][1][1:], "wrong class"),
+            ("ptr_for_int", [tape[0][1][0], (k.K_PTR, k.R_WORK, 0)] + tape[0][1][2:], "wrong class"),
+            ("float_for_int", [tape[0][1][0], (k.K_F32, 0, 0)] + tape[0][1][2:], "wrong class"),
+            ("stream_early", [(k.K_STREAM, 0, 0)] + tape[0][1][1:], "wrong class")):
+        path = str(tmp_path / (what + ".prog"))
+        export.write_program(path, [(fid, recs)], {}, 4096, 100, 50, b"", storages={})
+        rc, hh, msg = load(path)
+        assert rc == -22 and not hh.value and expect in msg, (what, rc, msg)
+    path = str(tmp_path / "ptr_for_desc.prog")
+    export.write_program(path, [(names.index("pgt_conv2d"), [(k.K_PTR, k.R_WORK, 0)] + tape[1][1][1:])], {}, 4096, 100, 50, b"", storages={})
+    rc, hh, msg = load(path)
+    assert rc == -22 and "wrong class" in msg, msg

@@ -107,6 +107,35 @@ def test_conv2d(dtype, case):
     check(name, got, want, dtype)
 
 
+@pytest.mark.parametrize("case", [("in3x3", 3, 24, 40, 3, 64, 3, 1, 1), ("in7x7_s2", 2, 32, 32, 3, 64, 7, 2, 3), ("k108", 2, 9, 10, 12, 72, 3, 1, 1),
+                                  ("k20", 1, 1, 300, 20, 40, 1, 1, 0), ("k52", 2, 6, 6, 52, 24, 1, 1, 0)], ids=lambda c: c[0])
+def test_conv2d_fp32_k_tail(case):
+    """fp32 layers whose K is not a multiple of the 32-wide K tile: the steps of the last tile that lie past K are skipped (1, 2 or
+    3 of 4 run).  The two input layers in their shipping form - 3 channels padded to ONE 16-byte chunk (4 channels in fp32: K = 36
+    and 196) - against the emulation AND against the same conv on 8-channel padding (what bf16 / half inputs use): same products,
+    paired differently inside the fp32 MFMA, so equal to rounding."""
+    name, n, h, w_, cin, cout, k, stride, pad = case
+    x3 = rnd((n, h, w_, cin), 20, torch.float32)
+    w3 = rnd((cout, k * k, cin), 21, torch.float32, 1.0 / np.sqrt(k * k * cin))
+    b = rnd((cout,), 22, torch.float32, 0.1)
+    kw = dict(kh=k, kw=k, stride=stride, pad=(pad,) * 4)
+
+    def padded(cp):
+        xx = torch.zeros((n, h, w_, cp))
+        xx[..., :cin] = x3
+        ww = torch.zeros((cout, k * k, cp))
+        ww[..., :cin] = w3
+        return xx, ww.reshape(cout, -1).contiguous()
+    cp = (cin + 3) // 4 * 4
+    x4, w4 = padded(cp)
+    want = E.conv2d(x4, w4, b, **kw)
+    got = ops().conv2d(g(x4), g(w4), g(b), **kw)
+    check(name, got, want, torch.float32)
+    x8, w8 = padded((cin + 7) // 8 * 8)
+    got8 = ops().conv2d(g(x8), g(w8), g(b), **kw)
+    assert (got - got8).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()), name
+
+
 V2_CASES = [
     ("v2_c3x3", 2, 20, 24, 64, 128, 3, 1, (1, 1, 1, 1), False),
     ("v2_c3x3_s2_asym", 3, 16, 16, 128, 64, 3, 2, (0, 1, 0, 1), False),
