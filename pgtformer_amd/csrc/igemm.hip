@@ -190,37 +190,49 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(ConvP p) {
     const char* a_rd = As + (wm * (BM / 2) + (lane & 31)) * kRowStride + (lane >> 5) * 16;
     const char* b_rd = Bs + (wn * (BN / 2) + (lane & 31)) * kRowStride + (lane >> 5) * 16;
     // the last K tile may hold fewer than four 32-byte steps (K = 36 or 196 of the 3-channel input layers, padded to 4 channels):
-    // the steps past K multiply zeros and are skipped
+    // the steps past K multiply zeros; that tile is taken out of the main loop (whose body stays as it is) and runs only its steps
     const int ns_last = (p.K - (nk_all - 1) * BK + BK / 4 - 1) / (BK / 4);
-    auto mma_step = [&](int s) __attribute__((always_inline)) {
-        uint4 af[MI], bfr[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const uint4*>(a_rd + i * 32 * kRowStride + s * 32);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const uint4*>(b_rd + j * 32 * kRowStride + s * 32);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
-    };
-    for (int kt = kt0; kt < nk; ++kt) {
+    const bool tail = ns_last < 4 && nk == nk_all;
+    const int nk_main = tail ? nk - 1 : nk;
+    for (int kt = kt0; kt < nk_main; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) {
             gload();
             advance();
         }
-        if (kt + 1 < nk_all || ns_last == 4) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma_step(s);
-        } else {
-#pragma unroll 1
-            for (int s = 0; s < ns_last; ++s) mma_step(s);
+        for (int s = 0; s < 4; ++s) {
+            uint4 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const uint4*>(a_rd + i * 32 * kRowStride + s * 32);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const uint4*>(b_rd + j * 32 * kRowStride + s * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
         }
         __syncthreads();
         if (more) {
             sstore();
             __syncthreads();
         }
+    }
+
+    if (tail) {
+#pragma unroll 1
+        for (int s = 0; s < ns_last; ++s) {
+            uint4 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const uint4*>(a_rd + i * 32 * kRowStride + s * 32);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const uint4*>(b_rd + j * 32 * kRowStride + s * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+        }
+        __syncthreads();
     }
 
     // epilogue: bias, activation, residual, (post-ReLU | SFT modulate), store
