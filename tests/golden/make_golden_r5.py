@@ -1,6 +1,8 @@
 """Round-5 fixtures from the REFERENCE (imported from /root/reference in the build container): a SECOND, independent
 operating point for north_star's "within 1e-3 PSNR" contract.
     python tests/golden/make_golden_r5.py  ->  tests/golden/r5_tail_s1.npz, tests/golden/r5_golden_s1.npz   (about 35 min)
+    R5_POINT=2 python tests/golden/make_golden_r5.py  ->  r5_tail_s2.npz, r5_golden_s2.npz: a THIRD point (weight seed 2, tail fitted on
+    clip 10077 w2, 8 windows of clips 10077 / 11077 / 12077), generated after every constant of the build was fixed
 
 Why: every PSNR-contract window of rounds 3 / 4 runs ONE weight set (seed-0 weights + one tail fitted on clip 1234 w1).  The
 half decoder's rounding errors, the defects D = W - half(W) behind the mean-field compensation and the
@@ -27,8 +29,11 @@ REF = "/root/reference"
 import make_golden_r3 as R3                                            # fit_tail, tail_forward, train_tail, psnr, rms  # noqa: E402
 from tests.golden import r5_scheme as S5                               # noqa: E402
 
-WINDOWS = ((7077, 1), (7077, 2), (7077, 3), (8077, 1), (8077, 2), (8077, 3), (9077, 2), (9077, 5))   # (clip seed, window)
-CLIP_FRAMES = {7077: 5, 8077: 5, 9077: 7}
+POINT = int(os.environ.get("R5_POINT", "1"))                         # weight seed of the operating point (r5_scheme.POINTS): 1, 2
+PT = S5.POINTS[POINT]
+WINDOWS = PT["windows"]                                              # (clip seed, window)
+CLIP_FRAMES = PT["clip_frames"]
+TRAIN_CLIP, TRAIN_WINDOW = PT["train"]
 OUT = os.environ.get("R5_OUT", HERE)                                 # R5_OUT=/tmp/x R3_STEPS=2: a dry run that leaves the fixtures alone
 
 
@@ -87,7 +92,7 @@ def main():
     cfg = default_config()
     model = PGTFormer(**cfg)
     model.eval()
-    sd1 = generate_state_dict(pgtformer_manifest(cfg), cfg, seed=S5.SEED)
+    sd1 = generate_state_dict(pgtformer_manifest(cfg), cfg, seed=POINT)
     clips = {seed: make_clip(n, 512, seed=seed) for seed, n in CLIP_FRAMES.items()}
 
     def window(seed, i):
@@ -97,10 +102,10 @@ def main():
         x = torch.from_numpy(window_from_clip(lq_u8, i).astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
         return x, torch.from_numpy(gt[idx]).permute(0, 3, 1, 2).contiguous()
 
-    xt, gtt = window(S5.TRAIN_CLIP, S5.TRAIN_WINDOW)
+    xt, gtt = window(TRAIN_CLIP, TRAIN_WINDOW)
     print("PSNR(LQ input, GT) on the fitted window = %.2f dB" % R3.psnr(xt, gtt))
     sd = dict(sd1)
-    print("SFT gains re-calibrated for the seed-1 draw (one oracle forward, each fusion measured then corrected):")
+    print(f"SFT gains re-calibrated for the seed-{POINT} draw (one oracle forward, each fusion measured then corrected):")
     gains, enc, dec = calibrate_and_capture(O, sd, cfg, xt)
     with torch.no_grad():
         feat = R3.tail_forward(O, sd, enc, dec, upto_features=True)
@@ -111,11 +116,10 @@ def main():
     trained = R3.train_tail(O, sd, enc, dec, gtt)
     payload = {k: v.numpy() for k, v in trained.items()}
     payload.update({S5.GAIN_KEY + k: np.float32(v) for k, v in gains.items()})
-    np.savez_compressed(os.path.join(OUT, S5.FIXTURE), **payload)
+    np.savez_compressed(os.path.join(OUT, PT["fixture"]), **payload)
     print("tail tensors:", len(trained), "with", sum(v.numel() for v in trained.values()), "values; gains:", gains)
 
-    S5.HERE = OUT
-    sd = S5.second_point_state_dict(sd1)                             # the scheme exactly as the tests apply it
+    sd = S5.point_state_dict(sd1, POINT, here=OUT)                   # the scheme exactly as the tests apply it
     model.load_state_dict(sd, strict=True)
     full = {}
     for seed, i in (WINDOWS[1:2] if OUT != HERE else WINDOWS):
@@ -129,7 +133,7 @@ def main():
         sat = float(((out[1] < 0) | (out[1] > 1)).float().mean())
         msg = (f"{tag}: middle frame range [{out[1].min().item():.3f}, {out[1].max().item():.3f}] ({sat:.2e} outside [0, 1]), "
                f"PSNR(ref, GT) {R3.psnr(out[1], g[1]):.3f} dB, smallest top-2 margin {float((top2[:, 0] - top2[:, 1]).min()):.2e}")
-        if (seed, i) == (S5.TRAIN_CLIP, S5.TRAIN_WINDOW):
+        if (seed, i) == (TRAIN_CLIP, TRAIN_WINDOW):
             o_out, o_logits, _ = O.pgtformer_forward(sd, cfg, x, w=1.0)
             msg += f"; reference vs oracle max|d| {(out - o_out).abs().max().item():.3e}"
         print(msg + f"  ({time.time() - t0:.0f} s)", flush=True)
@@ -138,8 +142,8 @@ def main():
         full[f"{tag}.top2_margin"] = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float32)
         full[f"{tag}.psnr_ref_vs_gt_db"] = np.array([R3.psnr(out[1], g[1])])
         full[f"{tag}.out_stats"] = np.array([[o.mean().item(), o.std().item(), o.min().item(), o.max().item()] for o in out])
-    np.savez_compressed(os.path.join(OUT, "r5_golden_s1.npz"), **full)
-    for fn in (S5.FIXTURE, "r5_golden_s1.npz"):
+    np.savez_compressed(os.path.join(OUT, PT["golden"]), **full)
+    for fn in (PT["fixture"], PT["golden"]):
         print(fn, os.path.getsize(os.path.join(OUT, fn)) // 1024, "KiB")
 
 

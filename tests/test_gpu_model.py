@@ -381,21 +381,24 @@ def test_psnr_contract_sweep_against_reference_fixtures(tail_models):
 NEAR_TIE_WINDOWS = {(4077, 6)}
 
 
-@pytest.fixture(scope="module")
-def tail_models_s1(cfg, manifest):
-    """the SECOND operating point (tests/golden/r5_scheme.py: weight seed 1, re-calibrated SFT gains, its own fitted tail) in the
-    default mode and fp32"""
+@pytest.fixture(scope="module", params=[1, 2], ids=["weight_seed_1", "weight_seed_2"])
+def tail_models_s1(request, cfg, manifest):
+    """the SECOND and THIRD operating points (tests/golden/r5_scheme.py POINTS: weight seed 1 / 2, re-calibrated SFT gains, their own
+    fitted tails) in the default mode and fp32"""
     from pgtformer_amd import PGTFormer
     from pgtformer_amd.weightgen import generate_state_dict
-    from tests.golden.r5_scheme import SEED, second_point_state_dict
+    from tests.golden.r5_scheme import POINTS, point_state_dict
 
-    sd = second_point_state_dict(generate_state_dict(manifest, cfg, seed=SEED))
-    out = {}
+    seed = request.param
+    sd = point_state_dict(generate_state_dict(manifest, cfg, seed=seed), seed)
+    out = {"point": POINTS[seed], "seed": seed}
     for prec in ("x3f16", "fp32"):
         m = PGTFormer(**cfg)
         m.load_state_dict(sd, strict=True)
         out[prec] = m.prepare(DEV, prec)
-    return out
+    yield out
+    out.clear()
+    torch.cuda.empty_cache()
 
 
 def test_psnr_contract_at_a_second_operating_point(tail_models_s1):
@@ -408,18 +411,22 @@ def test_psnr_contract_at_a_second_operating_point(tail_models_s1):
       * every code equals the reference's (the smallest reference margin over the 8 windows is 1.1e-4: no near-tie to excuse);
       * |PSNR(build, GT) - PSNR(reference, GT)| <= 1e-3 dB and PSNR(build, reference) >= 75 dB on every window;
       * no half store of the forward sits at the saturation limit (check_range);
-    fp32 mode: every code equal, <= 1e-4 dB."""
+    fp32 mode: every code equal, <= 1e-4 dB.
+    [weight_seed_2]: the same at a THIRD draw (weight seed 2, tail fitted on clip 10077 w2, 8 windows of clips 10077 / 11077 / 12077,
+    r5_golden_s2.npz), generated after every constant of the build - bands of the mean field, sample sizes - was fixed: a point
+    that took no part in choosing them."""
     from pgtformer_amd.synth import make_clip
 
-    g = np.load(os.path.join(GOLD, "r5_golden_s1.npz"))
+    pt = tail_models_s1["point"]
+    g = np.load(os.path.join(GOLD, pt["golden"]))
     tags = sorted({k.split(".")[0] for k in g.files})
     assert len(tags) == 8
     recs = []
     clips = {}
     for tag in tags:
-        seed, i = int(tag[1:5]), int(tag[6:])
+        seed, i = (int(v) for v in tag[1:].split("w"))
         if seed not in clips:
-            clips[seed] = make_clip({7077: 5, 8077: 5, 9077: 7}[seed], 512, seed=seed)
+            clips[seed] = make_clip(pt["clip_frames"][seed], 512, seed=seed)
         lq_u8, gt = clips[seed]
         frames = torch.from_numpy(lq_u8[i - 1:i + 2]).to(DEV)
         ref = torch.from_numpy(g[f"{tag}.out_mid_rows"]).double()
@@ -434,15 +441,15 @@ def test_psnr_contract_at_a_second_operating_point(tail_models_s1):
             rec[prec] = {"dpsnr_db": psnr(rows, gt_rows) - psnr(ref, gt_rows), "psnr_build_vs_ref_db": psnr(rows, ref),
                          "differing_tokens": int((codes != ref_codes).sum())}
         recs.append(rec)
-        assert rec["psnr_ref_vs_gt_db"] >= 25.0, rec
+        assert rec["psnr_ref_vs_gt_db"] >= pt["min_psnr_ref_gt_db"], rec      # (the fitted tail restores: the contract is not about noise)
         assert rec["x3f16"]["differing_tokens"] == 0 and rec["fp32"]["differing_tokens"] == 0, rec
         assert abs(rec["x3f16"]["dpsnr_db"]) <= 1e-3 and rec["x3f16"]["psnr_build_vs_ref_db"] >= 75.0, rec
         assert abs(rec["fp32"]["dpsnr_db"]) <= 1e-4 and rec["fp32"]["psnr_build_vs_ref_db"] >= 90.0, rec
     m = tail_models_s1["x3f16"]
-    fr = torch.from_numpy(clips[7077][0][:4]).to(DEV)
+    fr = torch.from_numpy(clips[pt["train"][0]][0][:4]).to(DEV)
     bad = m.check_range(fr, w=1.0, win=m.window_index(2, 3, DEV))
-    _LOG["operating_point_2/x3f16_vs_reference"] = {"windows": recs, "tensors_range_checked": m.last_range_launches,
-                                                    "saturating": [list(map(str, r)) for r in bad]}
+    _LOG[f"operating_point_{tail_models_s1['seed'] + 1}/x3f16_vs_reference"] = {"windows": recs, "tensors_range_checked": m.last_range_launches,
+                                                                                "saturating": [list(map(str, r)) for r in bad]}
     assert m.last_range_launches > 300 and bad == [], bad
 
 
