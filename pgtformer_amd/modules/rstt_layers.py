@@ -61,7 +61,11 @@ def _is_x3f(dtype):
 def _pack_matrix(w, device, dtype, cin_pad=None, scale=None, fold=False):
     """reference weight - (Cout, Cin, KH, KW), or any K-major (Cout, K) matrix - -> kernel operand on `device`: the repack is
     the library's (pgt_pack_conv_weight: K-major rows, channel padding, rounding to the compute type, the split-half forms)"""
-    return ops.pack_conv_weight(w.detach().to(device=device, dtype=torch.float32), dtype, cin_pad=cin_pad, scale=scale, fold=fold)
+    w = w.detach().to(device=device, dtype=torch.float32)
+    if (ops.USE_TAP_DIFFUSION and w.dim() == 4 and w.shape[2] * w.shape[3] > 1 and scale is None
+            and dtype in (torch.float16, torch.bfloat16)):
+        w = ops.tap_diffused(w, dtype)      # single-plane 16-bit k x k layers: rounding errors cancel over the taps of a filter
+    return ops.pack_conv_weight(w, dtype, cin_pad=cin_pad, scale=scale, fold=fold)
 
 
 def _wants_wcomp(dtype):

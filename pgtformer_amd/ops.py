@@ -117,6 +117,33 @@ def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
     return out
 
 
+USE_TAP_DIFFUSION = _os.environ.get("PGT_TAP_DIFFUSION", "1") != "0"      # k x k half / bf16 layers: tap-diffused weight rounding
+
+
+def tap_diffused(w, dtype):
+    """(Cout, Cin, KH, KW) fp32 -> fp32 values that are exact in `dtype` (half / bf16), rounded so that the rounding errors CANCEL over
+    the taps of every (cout, cin) filter: taps are taken in order of decreasing magnitude, each rounded to the value nearest to
+    (w - carried error); the sum over taps of q - w ends below half an ulp of the smallest tap.  The defect D = q - W of a k x k
+    layer then does not respond to the spatially smooth part of its operand - the part of the weight-rounding error the
+    per-band mean field removes only for the band mean - at the price of up to one ulp instead of half
+    an ulp on single taps.  Oracle ablation (tests/precision_study3.py, profiles/r5_u_third_point_oracle_ablation.md): the
+    uncompensated contract figure of the 3x3 layers of the 512 x 512 stage falls from -1.7e-3 to +2e-5 dB, of the 32 x 32 stage
+    from -8.2e-4 to -1.6e-5.  Deterministic (stable sort), runs once per layer at prepare time."""
+    assert w.dim() == 4 and w.dtype == torch.float32
+    o, c, kh, kw = w.shape
+    flat = w.reshape(o * c, kh * kw).double()
+    order = flat.abs().argsort(dim=1, descending=True, stable=True)
+    ws = flat.gather(1, order)
+    q = torch.empty_like(ws)
+    e = torch.zeros(o * c, dtype=torch.float64, device=w.device)
+    for t in range(kh * kw):
+        q[:, t] = (ws[:, t] - e).to(dtype).double()
+        e = e + q[:, t] - ws[:, t]
+    out = torch.empty_like(q)
+    out.scatter_(1, order, q)
+    return out.reshape(o, c, kh, kw).float().contiguous()
+
+
 def fold_batchnorm(gamma, beta, mean, var, eps, bias=None):
     """eval-BatchNorm2d folded into the preceding conv: (scale, bias') fp32 (C,) on the device (pgt_fold_batchnorm)."""
     c = gamma.numel()
