@@ -117,7 +117,9 @@ def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
     return out
 
 
-USE_TAP_DIFFUSION = _os.environ.get("PGT_TAP_DIFFUSION", "1") != "0"      # k x k half / bf16 layers: tap-diffused weight rounding
+# k x k half / bf16 layers: tap-diffused weight rounding - a STUDY switch, off: measured on the GPU build it does not help on top of
+# the mean-field compensation (third operating point: worst window 9.5e-4 -> 1.49e-3 dB; profiles/r5_w_tap_diffusion_spread.jsonl)
+USE_TAP_DIFFUSION = _os.environ.get("PGT_TAP_DIFFUSION", "0") == "1"
 
 
 def tap_diffused(w, dtype):
@@ -128,7 +130,9 @@ def tap_diffused(w, dtype):
     per-band mean field removes only for the band mean - at the price of up to one ulp instead of half
     an ulp on single taps.  Oracle ablation (tests/precision_study3.py, profiles/r5_u_third_point_oracle_ablation.md): the
     uncompensated contract figure of the 3x3 layers of the 512 x 512 stage falls from -1.7e-3 to +2e-5 dB, of the 32 x 32 stage
-    from -8.2e-4 to -1.6e-5.  Deterministic (stable sort), runs once per layer at prepare time."""
+    from -8.2e-4 to -1.6e-5 - in the ORACLE, without compensation and with exact activations.  On the GPU build (mean-field
+    compensation on, half activations) it made the third operating point worse, so it is not applied by default.
+    Deterministic (stable sort), runs once per layer at prepare time."""
     assert w.dim() == 4 and w.dtype == torch.float32
     o, c, kh, kw = w.shape
     flat = w.reshape(o * c, kh * kw).double()

@@ -396,9 +396,7 @@ def tail_models_s1(request, cfg, manifest):
         m = PGTFormer(**cfg)
         m.load_state_dict(sd, strict=True)
         out[prec] = m.prepare(DEV, prec)
-    yield out
-    out.clear()
-    torch.cuda.empty_cache()
+    return out
 
 
 def test_psnr_contract_at_a_second_operating_point(tail_models_s1):
