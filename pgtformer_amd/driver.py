@@ -118,9 +118,12 @@ class WindowRunner:
         if self._range_pending or (self._range_every > 0 and lane == 0 and self._launches % self._range_every == 0 and self._launches > 1):
             kw = {"win": self.win} if self.overlap else {}
             bad = self.model.check_range(self.static_ins[lane], w=self.w, full_tail=self.full_tail, **kw)
-            # the eager pass's activations (one more set on top of the graph pools) go back to the driver before the replay
+            # the eager pass's activations (one more set on top of the graph pools) are free for re-use by the allocator
             torch.cuda.synchronize(self.dev)
-            torch.cuda.empty_cache()
+            # (returning the eager pass's blocks to the driver here is opt-in: in one long test process a graph replay right
+            #  after torch.cuda.empty_cache() died inside the HIP runtime's graph launch - not reproduced in isolation)
+            if os.environ.get("PGT_EMPTY_CACHE_AFTER_CHECK", "0") == "1":
+                torch.cuda.empty_cache()
             if bad:
                 self._range_bad = bad          # stays set: a caller that catches the error and calls again is refused again
                 self._raise_range()
