@@ -68,6 +68,9 @@ def parse():
                          "(BASELINE.json configs 4 / 5 points)")
     ap.add_argument("--dump-clip", default="",
                     help="--clip-frames mode, rank 0: write the sha256 of the restored clip (uint8 frames in order) to this file")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launcher / rendezvous check without a model (runs on a host without a GPU under PGT_DIST_BACKEND=gloo): "
+                         "every rank joins the process group, the timing collectives run, rank 0 prints the world it saw")
     ap.add_argument("--clip-frames", type=int, default=0,
                     help="BASELINE.json configs[2]: ONE synthetic clip of this many frames (256 in the config), sharded by "
                          "output-frame range over the --gpus ranks with one all_gather of boundary frames, restored frames gathered "
@@ -369,12 +372,61 @@ DTYPE_NAMES = {"x3f16": "f16 / bf16 (16-bit MFMA, fp32 accumulate: IEEE-half dec
                "mixed": "bf16 (decoder) / f32 (code branch)", "fp32": "f32"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: re-run this command line as N ranks (one per GPU) under
+    `python -m torch.distributed.run` on 127.0.0.1 and hand back its exit code; rank 0's JSON line goes to this stdout."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_only(args, world, rank, backend):
+    """what every rank does around the timed region, without the model: barrier, max-over-ranks all_reduce, one JSON line"""
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher plumbing (no model)", "n_gpus": world, "ranks": dist.get_world_size(),
+                          "backend": dist.get_backend(), "max_over_ranks": float(t.item()), "gpus_arg": args.gpus}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("PGT_DIST_BACKEND", "nccl")      # "gloo": several ranks on ONE GPU (a test rig for the N > 1 control flow)
+    if args.plumbing_only:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        return plumbing_only(args, world, rank, backend)
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
     # under torchrun (RANK set) the process group exists even in a 1-rank world when PGT_FORCE_COLLECTIVE=1: the collectives of
@@ -469,6 +521,8 @@ def main():
     res = {"metric": "restored 512x512 frames/sec", "value": round(n_local * world / dt, 3), "unit": "frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "rccl_ranks": (torch.distributed.get_world_size() if dist_on and backend == "nccl" else (1 if not dist_on else 0)),
+           "dist_backend": (torch.distributed.get_backend() if dist_on else "none"),
            "dtype": DTYPE_NAMES[args.precision],
            "data": "synthetic",
            "config": {"workload": "pgtformer-base, 3-frame 512x512 window -> 1 restored frame, synthetic degraded "

@@ -150,6 +150,26 @@ def test_configs2_clip_sharding_world8_gloo(tmp_path):
         assert b"OK" in out
 
 
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT a launcher re-runs itself as two ranks under torch.distributed.run (the shape of the
+    driver's scaling command when it does not wrap the call): rank 0's line says n_gpus = 2 and the process group has 2 ranks.
+    `--plumbing-only` leaves the model out (no GPU here); PGT_DIST_BACKEND=gloo in place of RCCL.  A launcher that started a
+    different number of ranks than --gpus is an error, not a silently flat scaling line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PGT_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--plumbing-only"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["max_over_ranks"] == 2.0, rec
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--plumbing-only"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert bad.returncode != 0 and b"--gpus 4" in bad.stderr
+
+
 def test_synth_clip_is_deterministic():
     from pgtformer_amd.synth import make_clip, window_from_clip
 
