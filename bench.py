@@ -79,10 +79,11 @@ def parse():
 
 
 def _lib_sha16():
-    """identity of the kernel build: sha256 over the HIP sources and headers libpgt_hip.so is compiled from (stable across
-    rebuilds of the same sources, unlike the bytes of the .so)"""
-    from tools.pmc_traffic import source_sha16
-    return source_sha16()
+    """identity of the kernel build: the source sha256 compiled INTO the loaded libpgt_hip.so (pgt_version() ends in
+    src:<sha16>; pgtformer_amd/build.py) - the stamp of the binary that runs, whatever sources lie next to it"""
+    from pgtformer_amd import hip
+    v = hip.lib().pgt_version().decode()
+    return v.rsplit("src:", 1)[1] if "src:" in v else "unstamped"
 
 
 def live_roofline(runner, frames, precision, nwin):

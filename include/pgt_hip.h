@@ -112,6 +112,14 @@ typedef struct pgt_conv_desc {
                                  * (3 input channels) feeding the split-half levels without a conversion pass
                                  * (archs/tdcrqvae3_arch.py:540-546).  16-byte epilogue only: Cout % 8 == 0, y / ldy 16-byte aligned,
                                  * y_lo % 8 == 0, no residual, no split-K (anything else: -22).                                     */
+    int32_t w2;                 /* PGT_F16 / PGT_BF16 only: EXACT-WEIGHT form.  w holds two 16-bit planes per filter row (the form
+                                 * pgt_pack_conv_weight(..., x3_fold = 2) writes): 2 * ceil(Cout / 32) * 32 rows of KH*KW*Cin, per group of
+                                 * 32 output channels [32 rows w_hi | 32 rows (w - w_hi) * 2048]; the kernels multiply the single-plane
+                                 * operand by both (two MFMAs per product) and add acc_hi + acc_lo / 2048 in fp32 before the epilogue: the
+                                 * layer computes with 22-bit weights, i.e. the weight-rounding error of a 16-bit layer (DESIGN.md section
+                                 * 2.3; reference layers are fp32: modules/rstt_layers.py:875-904, archs/pgtformer_arch.py:421-484) is gone
+                                 * and no mean-field bias is needed.  Kernel 8 (the 64-channel ring kernel, incl. pgt_conv2d_affine_in)
+                                 * where it is legal, else kernel 4 (Cin % 64 == 0, 16-byte epilogue); no split-K.                      */
 } pgt_conv_desc;
 
 int pgt_conv2d(const pgt_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -347,6 +355,8 @@ int pgt_sample_rows(const float* prob, int32_t ld, int32_t rows, int32_t K, cons
  * `dtype` from the reference tensor on the device: (Cout, KH*KW*Cin_pad) in fp32 / bf16 / half with the input channels
  * zero-padded to Cin_pad (3 -> 8, 57 -> 64, the [enc | dec | fut] concats -> multiples of 64); PGT_F16X3: the
  * [w_hi | w_hi | w_lo]-per-64-channel-block form, or with x3_fold (Cout == 64) the folded (128, KH*KW*2*Cin_pad) form.
+ * PGT_F16 / PGT_BF16 with x3_fold == 2: the EXACT-WEIGHT form of pgt_conv_desc::w2 - (2 * ceil(Cout / 32) * 32, KH*KW*Cin_pad), per
+ * group of 32 output channels 32 rows of w_hi = rn16(w) followed by 32 rows of rn16((w - w_hi) * 2048) (rows past Cout zero).
  * out_scale (Cout floats or NULL) multiplies every output channel in fp32 before the rounding: the eval-BatchNorm fold
  * of BiSeNet (archs/pgtformer_arch.py:40-68), whose factors and folded bias pgt_fold_batchnorm computes
  * (scale = gamma / sqrt(var + eps), bias = (conv_bias - mean) * scale + beta).  pgt_packed_weight_bytes sizes `packed`. */

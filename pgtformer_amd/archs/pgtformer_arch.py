@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules.rstt_layers import (Conv2d, HipModule, LayerNorm, Linear, TDResnetBlock, _defect_t, _f32, _frame_bias, _is_x3,  # noqa: F401
+from ..modules.rstt_layers import (Conv2d, HipModule, LayerNorm, Linear, TDResnetBlock, _defect_t, _exact, _f32, _frame_bias, _is_x3,  # noqa: F401
                                     _pack_matrix, _wants_wcomp)
 from ..ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU
 from ..registry import ARCH_REGISTRY
@@ -283,6 +283,9 @@ class Fuse_sft_block(HipModule):
         wss = torch.cat([self.scale[0].weight.detach(), self.shift[0].weight.detach()], 0)
         self.w_ss0 = _pack_matrix(wss, device, dtype)
         self.d_ss0 = _defect_t(wss, self.w_ss0) if _wants_wcomp(dtype) else None
+        # exact-weight block: two-plane operands of the stacked scale.0 | shift.0 conv and of the temporal mix
+        exact = _exact(self, dtype, self.in_ch)
+        self.w_ss0_2 = _pack_matrix(wss, device, dtype, w2=True) if exact else None
         self.b_ss0 = _f32(torch.cat([self.scale[0].bias.detach(), self.shift[0].bias.detach()], 0), device)
         # bf16: tconvenc/tconvdec -> stack over T -> tfusion0 -> tfusion1 are all 1x1 and linear (reference :467-473), so
         # fut of output frame `to` is ONE linear map of the window's T [enc|dec] pixels: a (T x 1)-tap conv over the
@@ -295,7 +298,7 @@ class Fuse_sft_block(HipModule):
             w0, b0 = self.tfusion0.weight.detach().float().view(t * tcc, 2 * t * tcc), self.tfusion0.bias.detach().float()
             w1, b1 = self.tfusion1.weight.detach().float().view(tcc, tcc), self.tfusion1.bias.detach().float()
             bcat = torch.cat([be] * t + [bd] * t)
-            self.w_mix, self.b_mix, self.d_mix = [], [], []
+            self.w_mix, self.b_mix, self.d_mix, self.w_mix2 = [], [], [], []
             for to in range(t):
                 rows = w0[to * tcc:(to + 1) * tcc]                                           # (tcc, 2*t*tcc)
                 taps = [torch.cat([w1 @ rows[:, ti * tcc:(ti + 1) * tcc] @ we,
@@ -304,6 +307,7 @@ class Fuse_sft_block(HipModule):
                 self.w_mix.append(_pack_matrix(wm, device, dtype))     # K-major (tcc, T*2C)
                 # every tap reads its own frame of the window: the defect keeps one row per (frame, channel)
                 self.d_mix.append(_defect_t(wm, self.w_mix[-1]) if _wants_wcomp(dtype) else None)
+                self.w_mix2.append(_pack_matrix(wm, device, dtype, w2=True) if exact and (2 * c) % 64 == 0 else None)
                 self.b_mix.append(_f32(w1 @ (rows @ bcat + b0[to * tcc:(to + 1) * tcc]) + b1, device))
 
     def concat_width(self):
@@ -352,21 +356,29 @@ class Fuse_sft_block(HipModule):
             per = max(1, ((1 << 31) - 1) // (t * h * wd * ctp * cat.element_size()))
             # per-window means of the T [enc | dec] frames, (b, T*2C), for the weight-rounding compensation of the mix
             wmean = None
-            if self.d_mix[0] is not None and (h * wd) % 512 == 0:
+            mix2 = self.w_mix2[0] is not None and src.dtype == torch.float16 and ctp % 8 == 0
+            if self.d_mix[0] is not None and (h * wd) % 512 == 0 and not mix2:
                 wmean = ops.sampled_channel_mean(cat.view(n, h * wd, ctp)[..., :2 * c]).view(b, t * 2 * c)
             for i0 in range(0, b, per):
                 i1 = min(b, i0 + per)
                 for to in (range(t) if keep is None else (keep,)):
-                    bm = self.b_mix[to] if wmean is None else ops.mean_field_bias(wmean[i0:i1], self.d_mix[to], self.b_mix[to])
                     # output pixel m = window*h*w + pix  ->  row (window*T + to)*h*w + pix
+                    if mix2:      # exact weights: nothing to compensate
+                        ops.conv2d(src[i0:i1], self.w_mix2[to], self.b_mix[to], kh=t, kw=1, out=dst[i0 * t:i1 * t],
+                                   out_rows=(t, 1 - t, to * h * wd), w2=tcc)
+                        continue
+                    bm = self.b_mix[to] if wmean is None else ops.mean_field_bias(wmean[i0:i1], self.d_mix[to], self.b_mix[to])
                     ops.conv2d(src[i0:i1], self.w_mix[to], bm, kh=t, kw=1, out=dst[i0 * t:i1 * t],
                                out_rows=(t, 1 - t, to * h * wd))
             if keep is not None:     # frame `keep` of every window: [enc | dec | fut | 0] rows of B frames
                 cat = ops.gather_frames(cat, self._frame_index(b, keep, dev))
                 dec_feat = cat[..., c:2 * c]
             e = self.encode_enc(cat if self.encode_enc.cpad is not None else cat[..., :ct])
-            ss = ops.conv2d(e, self.w_ss0, _frame_bias(e, self.d_ss0, self.b_ss0), kh=3, kw=3, pad=(1, 1, 1, 1), act=ACT_LEAKY02)
             co = self.out_ch
+            if self.w_ss0_2 is not None and ops.w2_ok(e, 2 * co, e.shape[-1], 3, 3, 1, (1, 1, 1, 1), act=ACT_LEAKY02):
+                ss = ops.conv2d(e, self.w_ss0_2, self.b_ss0, kh=3, kw=3, pad=(1, 1, 1, 1), act=ACT_LEAKY02, w2=2 * co)
+            else:
+                ss = ops.conv2d(e, self.w_ss0, _frame_bias(e, self.d_ss0, self.b_ss0), kh=3, kw=3, pad=(1, 1, 1, 1), act=ACT_LEAKY02)
             shift = self.shift[2].run(ss[..., co:])
             return self.scale[2].run(ss[..., :co], sft=(dec_feat, shift, w))
         # per-frame 1x1 -> T frames stacked on channels: [enc t0..t2 | dec t0..t2]

@@ -17,8 +17,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _defect_t, _is_x3, _pack_matrix,
-                                    _wants_wcomp, prepare_tree)
+from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _defect_t, _exact, _is_x3, _pack_matrix,
+                                    _wants_wcomp, mark_exact_weights, prepare_tree)
 from ..ops import ACT_SILU, X3
 from ..config import DEFAULT_PRECISION
 from ..registry import ARCH_REGISTRY
@@ -43,13 +43,16 @@ class Upsample(HipModule):
         if dtype == torch.float32:
             return
         w = self.conv.weight.detach().float()                       # (Cout, Cin, 3, 3)
-        self.sub_w, self.sub_def, self._def4 = {}, {}, None
+        self.sub_w, self.sub_def, self._def4, self.sub_w2 = {}, {}, None, {}
+        exact = _exact(self, dtype, w.shape[1]) and w.shape[0] % 8 == 0      # exact-weight stage: two-plane sub-pixel filters
         for py in (0, 1):
             for px in (0, 1):
                 w2 = torch.stack([torch.stack([sum(w[:, :, ky, kx] for ky in self._ROWS[py][a] for kx in self._ROWS[px][b])
                                                for b in (0, 1)], -1) for a in (0, 1)], -2)      # (Cout, Cin, 2, 2)
                 self.sub_w[(py, px)] = _pack_matrix(w2, device, dtype)
                 self.sub_def[(py, px)] = _defect_t(w2, self.sub_w[(py, px)]) if _wants_wcomp(dtype) else None
+                if exact:
+                    self.sub_w2[(py, px)] = _pack_matrix(w2, device, dtype, w2=True)
 
     def forward(self, x):
         if self.sub_w is None:
@@ -60,6 +63,11 @@ class Upsample(HipModule):
         # a TDResnetBlock's GroupNorm follows: the four launches share one statistics workspace (4 sub-ranges)
         st = ops.GnStats(n, 4, h * w, cout, 32, x.device) if (ops.USE_EPILOGUE_GN and ops.gn_ok(n, h * w, cout)) else None
         mean = fb = None
+        if self.sub_w2 and x.dtype == torch.float16 and x.data_ptr() % 16 == 0 and ops._ld_img(x) % 8 == 0:
+            for i, ((py, px), w2) in enumerate(self.sub_w2.items()):      # exact weights: nothing to compensate
+                ops.conv2d(x, w2, self.conv.pb, kh=2, kw=2, pad=(1 - py, py, 1 - px, px), out=out, out_parity=(py, px),
+                           gn=None if st is None else (st, i), w2=cout)
+            return out if st is None else st.bind(out, cout)
         if self.sub_def[(0, 0)] is not None and (h * w) % 512 == 0:
             if ops.USE_FRAME_BIAS and x.dtype in (torch.float16, torch.bfloat16):
                 # the four sub-pixel convolutions read ONE operand: their defects side by side, one launch, (4, N, Cout) biases
@@ -626,6 +634,11 @@ class TDCRQVAE3(HubMixin, HipModule):
         self.enc_dt, self.dec_dt = dts[precision]
         self.precision = precision
         self.dev = torch.device(device)
+        # exact-weight stages of the half decoder: marked before the repack; other modes: no layer is marked
+        mark_exact_weights(self, False)
+        if self.dec_dt == torch.float16:
+            for mod in self.exact_weight_modules(ops.EXACT_W_STAGES):
+                mark_exact_weights(mod, True)
         for name, child in self.named_children():
             if name not in self.ENC_SIDE:
                 prepare_tree(child, self.dev, self.dec_dt)
@@ -645,6 +658,27 @@ class TDCRQVAE3(HubMixin, HipModule):
 
     def _prepare_extra(self):
         pass
+
+    # decoder stages by the resolution of their feature maps -> parameter-name prefixes (the stages of the weight-rounding ablation,
+    # tests/precision_study3.py / profiles/r5_u_third_point_oracle_ablation.md)
+    DECODER_STAGES = {"512": ("decoder.up.0.", "decoder.conv_out", "decoder.norm_out"),
+                      "256": ("decoder.up.1.", "fuse_convs_dict.256."),
+                      "128": ("decoder.up.2.", "fuse_convs_dict.128."),
+                      "64": ("decoder.up.3.", "fuse_convs_dict.64."),
+                      "32": ("decoder.up.4.", "decoder.mid.", "decoder.conv_in", "fuse_convs_dict.32.")}
+
+    def exact_weight_modules(self, stages):
+        """the sub-modules of the decoder stages `stages` (keys of DECODER_STAGES) that exist in this model"""
+        out = []
+        for st in stages:
+            if st not in self.DECODER_STAGES:
+                raise ValueError(f"PGT_EXACT_W: unknown decoder stage {st!r} (one of {list(self.DECODER_STAGES)})")
+            for prefix in self.DECODER_STAGES[st]:
+                try:
+                    out.append(self.get_submodule(prefix.rstrip(".")))
+                except AttributeError:
+                    pass            # (stage-I models have no fusion blocks)
+        return out
 
     def _check_ready(self):
         if self.enc_dt is None:

@@ -50,10 +50,9 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 // X3: q, k, v and out are split rows (two half planes), lo planes qlo / klo / vlo / olo elements after the hi planes; S^T and O^T
 // take three MFMAs per product (hi*hi + lo*hi + hi*lo), P is split in registers after the exp.
-// PLITE (X3 only; a study switch, PGT_MHA_PLITE=1 - DESIGN.md section 3.5 has the verdict): P enters P.V on its hi plane only -
-// the product V_hi . P_lo is dropped (5 MFMA products per key tile instead of 6, no lo plane of P formed).  P is in [0, 2^8]
-// and its rounding errors average over the keys of a row, unlike those of K / Q / V.
-template <bool X3, int NW = 4, bool PLITE = false>
+// (P on its hi plane only in P.V - 5 products per key tile - was measured in round 5 and rejected: logits error 1.7e-5 -> 3.5e-5,
+// profiles/r5_mha_p_single_plane_study.jsonl; the switch is gone.)
+template <bool X3, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k,
                                                        int ldk, const uint16_t* __restrict__ v, int ldv,
                                                        uint16_t* __restrict__ out, int ldo, int L, float c /* scale*log2(e) */,
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __res
             }
             pf[kb][0] = make_uint4(E::pack2(p[0], p[1]), E::pack2(p[2], p[3]), E::pack2(p[4], p[5]), E::pack2(p[6], p[7]));
             pf[kb][1] = make_uint4(E::pack2(p[8], p[9]), E::pack2(p[10], p[11]), E::pack2(p[12], p[13]), E::pack2(p[14], p[15]));
-            if constexpr (X3 && !PLITE) {
+            if constexpr (X3) {
                 x3_opaque(pf[kb][0]);      // the lo plane is taken against the packed hi bits (common.h)
                 x3_opaque(pf[kb][1]);
 #pragma unroll
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __res
                         const uint2 lhi = *reinterpret_cast<const uint2*>(pa + PLANE + 16);
                         const uint4 al = make_uint4(llo.x, llo.y, lhi.x, lhi.y);
                         o[d] = E::mma(al, pf[kb][s2], o[d]);
-                        if constexpr (!PLITE) o[d] = E::mma(a, pfl[kb][s2], o[d]);
+                        o[d] = E::mma(a, pfl[kb][s2], o[d]);
                     }
                     o[d] = E::mma(a, pf[kb][s2], o[d]);
                 }
@@ -297,19 +296,15 @@ int pgt_mha_mfma_bf16(const void* q, int ldq, const void* k, int ldk, const void
     const float c = scale * 1.44269504088896340736f;
     const int nw = L >= 512 ? 8 : 4;            // 256 queries per workgroup once the sequence is long enough to fill the chip
     const dim3 grid((L + 32 * nw - 1) / (32 * nw), heads, B);
-    static const bool plite = [] { const char* e = getenv("PGT_MHA_PLITE"); return e && e[0] == '1'; }();
-#define MHA_GO(X3_, NW_, PL_, QLO, KLO, VLO, OLO)                                                                                  \
-    hipLaunchKernelGGL((mha_mfma_kernel<X3_, NW_, PL_>), grid, dim3(64 * NW_), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, \
+#define MHA_GO(X3_, NW_, QLO, KLO, VLO, OLO)                                                                                  \
+    hipLaunchKernelGGL((mha_mfma_kernel<X3_, NW_>), grid, dim3(64 * NW_), 0, st, (const uint16_t*)q, ldq, (const uint16_t*)k, \
                        ldk, (const uint16_t*)v, ldv, (uint16_t*)out, ldo, L, c, QLO, KLO, VLO, OLO)
-    if (x3 && plite) {
-        if (nw == 8) MHA_GO(true, 8, true, qlo, klo, vlo, olo);
-        else MHA_GO(true, 4, true, qlo, klo, vlo, olo);
-    } else if (x3) {
-        if (nw == 8) MHA_GO(true, 8, false, qlo, klo, vlo, olo);
-        else MHA_GO(true, 4, false, qlo, klo, vlo, olo);
+    if (x3) {
+        if (nw == 8) MHA_GO(true, 8, qlo, klo, vlo, olo);
+        else MHA_GO(true, 4, qlo, klo, vlo, olo);
     } else {
-        if (nw == 8) MHA_GO(false, 8, false, 0, 0, 0, 0);
-        else MHA_GO(false, 4, false, 0, 0, 0, 0);
+        if (nw == 8) MHA_GO(false, 8, 0, 0, 0, 0);
+        else MHA_GO(false, 4, 0, 0, 0, 0);
     }
 #undef MHA_GO
     PGT_LAUNCH_CHECK();

@@ -14,4 +14,9 @@ void pgt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pgt_last_error(void) { return g_err; }
-extern "C" const char* pgt_version(void) { return "pgt_hip 0.2 (gfx950)"; }
+// the sha256 (16 hex digits) over every source this library was compiled from, set by pgtformer_amd/build.py: measurement files
+// quote the stamp of the binary that ran
+#ifndef PGT_SOURCE_SHA16
+#define PGT_SOURCE_SHA16 "unstamped-build!"
+#endif
+extern "C" const char* pgt_version(void) { return "pgt_hip 0.3 (gfx950) src:" PGT_SOURCE_SHA16; }

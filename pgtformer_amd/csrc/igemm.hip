@@ -436,7 +436,7 @@ template <typename T> int dispatch(const ConvP& p, hipStream_t st, int force_bm,
 
 // number of K slices pgt_conv2d_ws would use for this layer (1 = single pass)
 static int planned_splitk(const pgt_conv_desc* d) {
-    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_F16X3 || d->gn_groups > 0 || d->out_split) return 1;
+    if (d->splitk == 1 || d->kernel == 2 || d->scalar_epilogue || d->Cout % 8 != 0 || d->dtype == PGT_F16X3 || d->gn_groups > 0 || d->out_split || d->w2) return 1;
     const long M = (long)d->N * d->Ho * d->Wo;
     const int K = d->KH * d->KW * d->Cin;
     const int bk = d->dtype == PGT_F32 ? 32 : 64;
@@ -469,7 +469,11 @@ static bool ring_legal(const pgt_conv_desc* d, bool aligned, bool has_res) {
            d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ups == 0 && d->pad_t == 1 && d->pad_l == 1 && d->Ho == d->H &&
            d->Wo == d->W && pow2(d->W) && pow2(d->H) && d->W >= 128 && d->H >= 4 && d->ldx % 8 == 0 && d->epi == 0 && d->act == 0 &&
            !d->post_relu && d->gn_groups == 0 && d->splitk <= 1 && d->force_bm == 0 && d->force_bn == 0 && (aligned || d->Cout <= 32) &&
-           (!has_res || (long)d->N * d->H * d->W * d->ldr * 2 < (1L << 32));
+           (!has_res || (long)d->N * d->H * d->W * d->ldr * 2 < (1L << 32)) &&
+           // a strip of >= 4 rows x 128 columns takes ONE bias vector: bias bands (bias_rows pixels of the raster) must be whole strips
+           (d->bias_rows == 0 || d->bias_rows % (4 * d->W) == 0) &&
+           // exact weights: IEEE half only (the ring kernel's two-plane form)
+           (!d->w2 || (d->dtype == PGT_F16 && (aligned || d->Cout <= 16)));
 }
 
 extern "C" size_t pgt_conv2d_workspace_bytes(const pgt_conv_desc* d) {
@@ -530,7 +534,10 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.f16 = f16 ? 1 : 0;
     p.dlo = d->dec_lo ? d->dec_lo : d->Cout;
     p.slo = d->shift_lo ? d->shift_lo : d->Cout;
-    p.nw = (x3 && d->x3_fold) ? 128 : d->Cout;
+    p.nw = (x3 && d->x3_fold) ? 128 : (d->w2 ? (d->Cout + 31) / 32 * 64 : d->Cout);
+    p.w2 = d->w2 ? 1 : 0;
+    PGT_CHECK(!d->w2 || ((f16 || d->dtype == PGT_BF16) && d->splitk <= 1 && !d->ups && !d->out_split && !d->x3_fold && (d->kernel == 0 || d->kernel == 4 || d->kernel == 8)),
+              "pgt_conv2d: the exact-weight form (w2) takes PGT_F16 / PGT_BF16 operands, kernel 0, 4 or 8, no split-K, no fused up-sampling");
     p.bias_rows = d->bias_rows;
     p.out_split = d->out_split ? 1 : 0;
     PGT_CHECK(d->bias_rows == 0 || (bias && d->bias_rows > 0 && d->bias_rows % 512 == 0 && p.M % d->bias_rows == 0 && !x3 &&
@@ -568,7 +575,19 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
                   "W >= 128 and H >= 4 powers of two, bias (+ residual) epilogue without activation, 16-byte aligned rows unless Cout <= 32");
         PGT_CHECK(!p.in_scale || (v8 && (d->kernel == 0 || d->kernel == 8) && p.in_shift && (p.in_act == ACT_NONE || p.in_act == ACT_SILU)),
                   "pgt_conv2d_affine_in: this launch has no fused-operand form (pgt_conv2d_affine_in_ok), or in_act is neither none nor SiLU");
-        if (v8 && (d->kernel == 8 || p.in_scale || (d->kernel == 0 && use_ring_kernel()))) return pgt_igemm8_launch(&p, st);
+        if (v8 && (d->kernel == 8 || p.in_scale || d->w2 || (d->kernel == 0 && use_ring_kernel()))) return pgt_igemm8_launch(&p, st);
+    }
+    if (d->w2) {      // exact-weight form outside the ring kernel: the phased LDS-DMA kernel, both planes against one staged operand tile
+        PGT_CHECK(f16 && d->Cin % 64 == 0 && p.vec_epi && ((uintptr_t)x & 15) == 0 && d->ldx % 8 == 0 && d->KH * d->KW <= 30 &&
+                  (long)p.nw * p.K * 2 < (1L << 31),
+                  "pgt_conv2d: the exact-weight form needs IEEE half, Cin %% 64 == 0 (Cin=%d), a 16-byte-legal epilogue (Cout %% 8 == 0, aligned rows) "
+                  "and <= 30 taps - or a launch the ring kernel covers", d->Cin);
+        const int bn = d->force_bn ? d->force_bn : (p.nw <= 128 ? 128 : 256);
+        PGT_CHECK(!p.gn_part || (p.gn_hw % (bn == 256 ? 256 : 512) == 0 && (bn / 2) % p.gn_cpg == 0),
+                  "pgt_conv2d: exact-weight form with epilogue statistics needs Ho*Wo %% %d == 0 and whole channel groups per %d-channel tile", bn == 256 ? 256 : 512, bn / 2);
+        const int rc = pgt_igemm4_launch(&p, bn, st);
+        PGT_CHECK(rc != 1, "pgt_conv2d: the exact-weight form has no %d-row weight tile (128, 256)", bn);
+        return rc;
     }
 
     if (x3) {   // split-half operands: the phase-interleaved LDS-DMA kernel with the three-segment K order

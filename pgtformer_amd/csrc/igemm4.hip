@@ -60,8 +60,13 @@ constexpr int lds_bytes4(int wr, int wc) {
     return stages > epi ? stages : epi;
 }
 
-template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T = bf16_t>
+// W2: exact-weight form (pgt_conv_desc::w2): the weight matrix has 2 * ceil32(Cout) rows, per 32 output channels [32 rows w_hi |
+// 32 rows w_lo * 2048], so a wave's 64 tile columns are the hi and lo products of the SAME 32 output channels: after the main
+// loop acc[.][0] += acc[.][1] / 2048 and the epilogue runs on a tile of half the columns.  The operand tile is staged once and
+// multiplied by both planes (2x the MFMA and weight traffic, 1x the activation traffic).
+template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T = bf16_t, bool W2 = false>
 __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
+    static_assert(!(W2 && X3), "exact weights are a single-plane form");
     static_assert(WR * WC == 8, "8 waves");
     constexpr int BM = WR * 128, BN = WC * 64;
     constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;   // bytes; K tile = 64 bf16 = 128 B
@@ -326,11 +331,19 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
     return;
 #endif
 
-    epilogue_128x64<WR, WC, X3, GN, T>(p, acc, smem, m0, n0, tid, lane, wr, wc);
+    if constexpr (W2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][0][e] = __builtin_fmaf(acc[i][1][e], kW2Inv, acc[i][0][e]);
+        epilogue_128x64<WR, WC, false, GN, T, 1>(p, acc, smem, m0, n0 >> 1, tid, lane, wr, wc);
+    } else {
+        epilogue_128x64<WR, WC, X3, GN, T>(p, acc, smem, m0, n0, tid, lane, wr, wc);
+    }
     PGT_STAMP(3);
 }
 
-template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T = bf16_t> int launch4(const ConvP& p0, hipStream_t st) {
+template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T = bf16_t, bool W2 = false> int launch4(const ConvP& p0, hipStream_t st) {
     ConvP p = p0;
     constexpr int BM = WR * 128, BN = WC * 64, bytes = lds_bytes4(WR, WC);
     const bool pow2 = (p.Wo & (p.Wo - 1)) == 0 && (p.Ho & (p.Ho - 1)) == 0;
@@ -338,18 +351,18 @@ template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T
     p.ho_shift = pow2 ? __builtin_ctz(p.Ho) : -1;
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.nw + BN - 1) / BN;
-    if (GN) PGT_CHECK(p.gn_hw % BM == 0 && BN % p.gn_cpg == 0, "igemm4: GroupNorm statistics need HW %% %d == 0 (HW=%d) and whole groups per tile", BM, p.gn_hw);
+    if (GN) PGT_CHECK(p.gn_hw % BM == 0 && (W2 ? BN / 2 : BN) % p.gn_cpg == 0, "igemm4: GroupNorm statistics need HW %% %d == 0 (HW=%d) and whole groups per tile", BM, p.gn_hw);
     // the attribute is per device and per function: set it once per (device, instantiation), thread-safe
     static std::atomic<unsigned long long> attr_set{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_set.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS, X3, GN, T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm4_kernel<WR, WC, UPS, X3, GN, T, W2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { pgt_set_error("igemm4: cannot reserve %d B of LDS: %s", bytes, hipGetErrorString(e)); return -12; }
         attr_set.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS, X3, GN, T>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
+    hipLaunchKernelGGL((igemm4_kernel<WR, WC, UPS, X3, GN, T, W2>), dim3(p.nbm * p.nbn), dim3(512), bytes, st, p);
     PGT_LAUNCH_CHECK();
     return 0;
 }
@@ -360,6 +373,17 @@ template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T
 // tiles; bn = 128: 512x128 tiles.  Returns 1 if the tile is not built.
 int pgt_igemm4_launch(const void* pv, int bn, hipStream_t st) {
     const ConvP& p = *reinterpret_cast<const ConvP*>(pv);
+    if (p.w2) {   // exact-weight form: IEEE half, plain (not up-sampled) inputs; bn counts WEIGHT rows (2 per output channel)
+        if (!p.f16 || p.x3 || p.ups) return 1;
+        if (p.gn_part) {
+            if (bn == 256) return launch4<2, 4, false, false, true, half_t, true>(p, st);
+            if (bn == 128) return launch4<4, 2, false, false, true, half_t, true>(p, st);
+            return 1;
+        }
+        if (bn == 256) return launch4<2, 4, false, false, false, half_t, true>(p, st);
+        if (bn == 128) return launch4<4, 2, false, false, false, half_t, true>(p, st);
+        return 1;
+    }
     if (p.x3) {   // split operands on two half planes (no up-sampled inputs on that path)
         if (p.ups) return 1;
         if (p.gn_part) {

@@ -21,6 +21,14 @@
 //   * one barrier per output row; the residual row is requested before the MFMAs, the stores of row y drain under row y + 1;
 //   * 77 KiB of LDS and <= 256 VGPRs: two workgroups per CU, one multiplies while the other stores / transforms.
 //
+// Exact-weight form (W2, pgt_conv_desc::w2; IEEE half): the weight-rounding error of these layers is what the PSNR contract's margin
+// hung on (profiles/r5_u_third_point_oracle_ablation.md: -1.7e-3 dB from the 3x3 layers of the 512x512 stage alone), so the kernel
+// also exists with BOTH planes of the weights in registers: a wave owns 16 output channels instead of 32 and its 32 MFMA rows
+// are [w_hi (16 channels) | w_lo * 2048 (the same 16 channels)] - still 144 weight registers -, row permutation such that a
+// lane's accumulators e and e + 8 are the hi and lo products of ONE (pixel, channel): y = acc[e] + acc[e + 8] / 2048.  The four
+// waves cover 64 channels x all 128 pixels of the row in two passes of 64 pixels (32 accumulator registers live, as before):
+// twice the MFMAs and fragment reads per output row, no extra L2 -> LDS traffic, the fused GroupNorm apply unchanged.
+//
 // Preconditions (caller): 16-bit single-plane operands, KH = KW = 3, stride 1, pad 1, no up-sampling, Cin == 64, Cout <= 64,
 // Ho == H, Wo == W, W a power of two >= 128, H a power of two >= 4, epilogue = bias (+ residual) only (no activation, no
 // SFT: what the residual blocks and conv_out need), in_act none or SiLU, input < 2 GiB, residual < 4 GiB.
@@ -60,6 +68,7 @@ __device__ __forceinline__ void wait_all(u32x4& a, u32x4& b, u32x4& c, u32x4& d)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
 __device__ __forceinline__ void wait_all(u32x4& a, u32x4& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+__device__ __forceinline__ void wait_all(u32x4& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); }
 __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename T> __device__ __forceinline__ void unpack_u(const u32x4& q, float* f) {
@@ -68,15 +77,20 @@ template <typename T> __device__ __forceinline__ void unpack_u(const u32x4& q, f
 
 // NCB = 32-channel blocks of the output (2: waves 2 x 2, 64 pixels x 32 channels each; 1: four waves of 32 pixels);
 // FUSE: the operand is act(x * in_scale[n][c] + in_shift[n][c]) (the GroupNorm apply of the preceding Normalize + SiLU)
-template <typename T, int NCB, bool FUSE>
+//   W2: exact-weight form - NCB = 2: wave w owns channels 16 w .. 16 w + 15 and the whole row (two passes of two 32-pixel blocks);
+//       NCB = 1 (Cout <= 16): four waves of 32 pixels, channels 0 .. 15
+template <typename T, int NCB, bool FUSE, bool W2 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R, int nys, int nxs, int nitems) {
     constexpr unsigned kOob = 0x80000000u;
-    constexpr int NPB = NCB == 2 ? 2 : 1;         // 32-pixel blocks per wave
+    constexpr int NPB = NCB == 2 ? 2 : 1;         // 32-pixel blocks per wave (and pass)
+    constexpr int NPASS = (W2 && NCB == 2) ? 2 : 1;   // passes of 64 pixels over the row
+    constexpr int NH2 = W2 ? 1 : 2;               // runs of 8 consecutive output channels per lane
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = NCB == 2 ? wave >> 1 : wave, wc = NCB == 2 ? wave & 1 : 0;
+    const int wr = W2 ? (NCB == 2 ? 0 : wave) : (NCB == 2 ? wave >> 1 : wave);
+    const int wc = W2 ? (NCB == 2 ? wave : 0) : (NCB == 2 ? wave & 1 : 0);
     const int hh = lane >> 5, l31 = lane & 31;
     const unsigned lds0 = lds_addr(smem);
     float* tab = reinterpret_cast<float*>(smem + kTab8);
@@ -86,12 +100,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
     // ---- weights: A fragment of (tap, ks) for A row i = lane & 31 -> output channel wc * 32 + sigma(i); row 8q + 4h + j of
     // the 32x32 result sits in accumulator e = 4q + j of the lanes with lane >> 5 == h, so sigma(8q + 4h + j) =
     // 16 (q >> 1) + 8 h + 4 (q & 1) + j gives those lanes channels 8h .. 8h + 7 in e = 0..7 and 16 + 8h .. in e = 8..15
+    // W2: rows q = 0, 1 carry w_hi and q = 2, 3 w_lo * 2048 of channel wc * 16 + 8 h + 4 (q & 1) + j: e < 8 and e + 8 pair up
     uint4 wreg[9][4];
     {
         const int q = l31 >> 3, h = (l31 >> 2) & 1, j = l31 & 3;
-        const int n = wc * 32 + 16 * (q >> 1) + 8 * h + 4 * (q & 1) + j;
+        const int n = W2 ? wc * 16 + 8 * h + 4 * (q & 1) + j : wc * 32 + 16 * (q >> 1) + 8 * h + 4 * (q & 1) + j;
         const bool live = n < p.Cout;      // (rows past Cout multiply zeros)
-        const uint4* wp = reinterpret_cast<const uint4*>(p.w + ((long)(live ? n : 0) * p.K + hh * 8) * 2);
+        // row of the weight matrix: channel n, or in the exact-weight form plane (q >> 1) of channel n
+        const long wrow = W2 ? (long)(n >> 5) * 64 + (q >> 1) * 32 + (n & 31) : (long)n;
+        const uint4* wp = reinterpret_cast<const uint4*>(p.w + ((live ? wrow : 0) * p.K + hh * 8) * 2);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -101,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
                 wreg[t][ks] = v;
             }
     }
-    const int cb = wc * 32 + 8 * hh;              // this lane's channels: cb .. cb + 7 and cb + 16 .. cb + 23
-    const int pxb = (NCB == 2 ? wr * 64 : wr * 32) + l31;      // its pixel (block i: + 32 i) inside the 128-pixel row
+    const int cb = (W2 ? wc * 16 : wc * 32) + 8 * hh;   // this lane's channels: cb .. cb + 7 (and cb + 16 .. cb + 23 without W2)
+    const int pxb = (NCB == 2 ? wr * 64 : wr * 32) + l31;      // its pixel (block i: + 32 i; pass ps: + 64 ps) inside the 128-pixel row
     const char* lbase = smem + pxb * kRowB + hh * 16;          // B fragment of (slot, i, kx, ks): + slot*kSlot8 + (32 i + kx)*kRowB + 32 ks
     // chunk (s % 9; 8 = the padding) of the 16 bytes this lane moves in its k-th DMA piece: 4 bits each, the same for every row
     unsigned cpack = 0;
@@ -200,16 +217,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
             const int y = y0 + t;
             const int mrow = (img * p.H + y) * p.W + x0;            // first pixel of this output row
             if (t + 3 <= R + 1) issue_row(t + 3, (PH + 3) & 3);     // the row the NEXT step needs; its slot was last read in step t - 1
-            u32x4 rr[NPB][2];
+            char* yrow = p.y + (long)mrow * p.ldy * ysz;
 #pragma unroll
-            for (int i = 0; i < NPB; ++i) rr[i][0] = rr[i][1] = u32x4{0u, 0u, 0u, 0u};
+            for (int ps = 0; ps < NPASS; ++ps) {
+            const char* lb = lbase + ps * 64 * kRowB;         // (second pass: + 64 pixels; a register add, the rest stays immediate)
+            // the residual chunks of this pass are requested before its MFMAs (the second pass's after the first pass's stores)
+            u32x4 rr[NPB][NH2];
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+#pragma unroll
+                for (int h2 = 0; h2 < NH2; ++h2) rr[i][h2] = u32x4{0u, 0u, 0u, 0u};
             if (has_res && vec) {
                 const int soff = (int)((unsigned)mrow * (unsigned)p.ldr * 2u);      // (< 4 GiB by the launcher's check: 32-bit unsigned)
 #pragma unroll
                 for (int i = 0; i < NPB; ++i) {
-                    const unsigned vo = (unsigned)(((pxb + 32 * i) * p.ldr + cb) * 2);
+                    const unsigned vo = (unsigned)(((pxb + 64 * ps + 32 * i) * p.ldr + cb) * 2);
                     rr[i][0] = bufload16(cb < p.Cout ? vo : kOob, rsrc_r, soff, 0);
-                    rr[i][1] = bufload16_32(cb + 16 < p.Cout ? vo : kOob, rsrc_r, soff);
+                    if constexpr (NH2 == 2) rr[i][1] = bufload16_32(cb + 16 < p.Cout ? vo : kOob, rsrc_r, soff);
                 }
             }
             f32x16 acc[NPB];
@@ -217,8 +241,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
                 float bv[16];
                 *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(tab + cb);
                 *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(tab + cb + 4);
-                *reinterpret_cast<float4*>(bv + 8) = *reinterpret_cast<const float4*>(tab + cb + 16);
-                *reinterpret_cast<float4*>(bv + 12) = *reinterpret_cast<const float4*>(tab + cb + 20);
+                if constexpr (W2) {
+#pragma unroll
+                    for (int e = 8; e < 16; ++e) bv[e] = 0.f;          // the lo products start from zero
+                } else {
+                    *reinterpret_cast<float4*>(bv + 8) = *reinterpret_cast<const float4*>(tab + cb + 16);
+                    *reinterpret_cast<float4*>(bv + 12) = *reinterpret_cast<const float4*>(tab + cb + 20);
+                }
 #pragma unroll
                 for (int i = 0; i < NPB; ++i)
 #pragma unroll
@@ -231,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
                 uint4 fb[D + 1][NPB];
                 auto frag = [&](int g, int i) __attribute__((always_inline)) {
                     const int tap = g >> 2, ks = g & 3, ky = tap / 3, kx = tap - 3 * ky;
-                    return *reinterpret_cast<const uint4*>(lbase + ((PH + ky) & 3) * kSlot8 + (32 * i + kx) * kRowB + 32 * ks);
+                    return *reinterpret_cast<const uint4*>(lb + ((PH + ky) & 3) * kSlot8 + (32 * i + kx) * kRowB + 32 * ks);
                 };
 #pragma unroll
                 for (int g = 0; g < D; ++g)
@@ -248,20 +277,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if constexpr (NPB == 2) wait_all(rr[0][0], rr[0][1], rr[1][0], rr[1][1]);
-            else wait_all(rr[0][0], rr[0][1]);
+            // the row requested at the top of the step has landed by now, and so have this pass's residual chunks
+            if constexpr (NPB == 2 && NH2 == 2) wait_all(rr[0][0], rr[0][1], rr[1][0], rr[1][1]);
+            else if constexpr (NPB == 2) wait_all(rr[0][0], rr[1][0]);
+            else if constexpr (NH2 == 2) wait_all(rr[0][0], rr[0][1]);
+            else wait_all(rr[0][0]);
             // ---- epilogue straight from the accumulators: 8 consecutive channels of one pixel per 16-byte store
-            char* yrow = p.y + (long)mrow * p.ldy * ysz;
 #pragma unroll
             for (int i = 0; i < NPB; ++i)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
+                for (int h2 = 0; h2 < NH2; ++h2) {
                     const int ch = cb + 16 * h2;
                     if (ch >= p.Cout) continue;
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = acc[i][8 * h2 + e];
-                    const int yo = (pxb + 32 * i) * p.ldy + ch;       // (element offset inside the output row: small)
+                    for (int e = 0; e < 8; ++e) v[e] = W2 ? __builtin_fmaf(acc[i][8 + e], kW2Inv, acc[i][e]) : acc[i][8 * h2 + e];
+                    const int px = pxb + 64 * ps + 32 * i;
+                    const int yo = px * p.ldy + ch;       // (element offset inside the output row: small)
                     if (vec) {
                         if (has_res) {
                             float r[8];
@@ -277,12 +309,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
                         for (int e = 0; e < 8; ++e) {
                             if (ch + e >= p.Cout) continue;
                             float u = v[e];
-                            if (has_res) u += ldf(res + ((long)mrow + pxb + 32 * i) * p.ldr + ch + e);
+                            if (has_res) u += ldf(res + ((long)mrow + px) * p.ldr + ch + e);
                             if (p.out_f32) reinterpret_cast<float*>(yrow)[yo + e] = u;
                             else stf(reinterpret_cast<T*>(yrow) + yo + e, u);
                         }
                     }
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);      // (keeps the transform's registers out of the epilogue's live range)
             if (t + 3 <= R + 1) transform_row(t + 3, (PH + 3) & 3);
             __syncthreads();
@@ -297,10 +330,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_ring_kernel(ConvP p, int R
     }
 }
 
-template <typename T, int NCB, bool FUSE> int launch8(const ConvP& p, int R, int nys, int nxs, int nitems, int grid, hipStream_t st) {
+template <typename T, int NCB, bool FUSE, bool W2 = false> int launch8(const ConvP& p, int R, int nys, int nxs, int nitems, int grid, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_ring_kernel<T, NCB, FUSE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_ring_kernel<T, NCB, FUSE, W2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
         if (e != hipSuccess) {
             pgt_set_error("igemm8: cannot reserve %d bytes of LDS: %s", kLds8, hipGetErrorString(e));
@@ -308,13 +341,20 @@ template <typename T, int NCB, bool FUSE> int launch8(const ConvP& p, int R, int
         }
         configured = true;
     }
-    hipLaunchKernelGGL((conv3x3_c64_ring_kernel<T, NCB, FUSE>), dim3(grid), dim3(256), kLds8, st, p, R, nys, nxs, nitems);
+    hipLaunchKernelGGL((conv3x3_c64_ring_kernel<T, NCB, FUSE, W2>), dim3(grid), dim3(256), kLds8, st, p, R, nys, nxs, nitems);
     PGT_LAUNCH_CHECK();
     return 0;
 }
 
 template <typename T> int launch8_t(const ConvP& p, int R, int nys, int nxs, int nitems, int grid, hipStream_t st) {
     const bool fuse = p.in_scale != nullptr;
+    if constexpr (std::is_same<T, half_t>::value) {
+        if (p.w2) {      // exact-weight form: 16 output channels per wave
+            if (p.Cout <= 16) return fuse ? launch8<T, 1, true, true>(p, R, nys, nxs, nitems, grid, st) : launch8<T, 1, false, true>(p, R, nys, nxs, nitems, grid, st);
+            return fuse ? launch8<T, 2, true, true>(p, R, nys, nxs, nitems, grid, st) : launch8<T, 2, false, true>(p, R, nys, nxs, nitems, grid, st);
+        }
+    }
+    if (p.w2) { pgt_set_error("igemm8: the exact-weight form is IEEE half only"); return -22; }
     if (p.Cout <= 32) return fuse ? launch8<T, 1, true>(p, R, nys, nxs, nitems, grid, st) : launch8<T, 1, false>(p, R, nys, nxs, nitems, grid, st);
     return fuse ? launch8<T, 2, true>(p, R, nys, nxs, nitems, grid, st) : launch8<T, 2, false>(p, R, nys, nxs, nitems, grid, st);
 }
@@ -340,6 +380,9 @@ int pgt_igemm8_launch(const void* pv, hipStream_t st) {
     int R = p.H < 64 ? p.H : 64;
     while (R > 8 && (long)p.N * (p.H / R) * nxs < 4L * grid_max) R >>= 1;
     if (R > p.H) R = p.H;
+    // a strip takes ONE bias vector (bias_of at its first pixel): with a bias per band of the frame (pgt_conv_desc::bias_rows) a
+    // strip must not straddle bands (the caller - ring_legal - made sure that 4-row strips fit)
+    while (p.bias_rows > 0 && R > 4 && p.bias_rows % (R * p.W) != 0) R >>= 1;
     const int nys = p.H / R;
     const int nitems = p.N * nys * nxs;
     const int grid = nitems < grid_max ? nitems : grid_max;

@@ -63,7 +63,11 @@ struct ConvP {
     const float* in_scale;
     const float* in_shift;
     int in_act;
+    int w2;                     // exact-weight form (pgt_conv_desc::w2): w = per 32 output channels [32 rows w_hi | 32 rows w_lo * 2048], nw rows
 };
+
+// exact-weight layers: y = acc_hi + acc_lo * kW2Inv (the lo plane is stored scaled by 2048 = 2^11: |w - w_hi| <= 2^-11 |w|)
+constexpr float kW2Inv = 1.f / 2048.f;
 
 // bias vector of output pixel m: shared, or the one of m's frame (pgt_conv_desc::bias_rows; a workgroup tile never straddles
 // two frames: bias_rows is a multiple of 512 rows)

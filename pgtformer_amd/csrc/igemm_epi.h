@@ -16,10 +16,13 @@ template <int WR, int WC> constexpr int epi_stage_bytes() { return WR * 64 * (WC
 // X3: split-half output (hi at n, lo at n + p.ylo), split residual (p.rlo) or split SFT operands (p.dlo / p.slo).
 // GN: also reduce the GroupNorm statistics of the tile's outputs (ConvP::gn_*).
 // T: 16-bit storage type of residual / SFT operands / output (bf16_t, or half_t for PGT_F16 launches; X3 is bf16).
-template <int WR, int WC, bool X3 = false, bool GN = false, typename T = bf16_t>
+// NJ: 32-column accumulators per wave that hold outputs (2; 1 for the exact-weight form, whose waves own 128 x 32 outputs after
+// acc[.][0] += acc[.][1] / 2048: the tile then has WC * 32 columns, n0 = its first OUTPUT channel).
+template <int WR, int WC, bool X3 = false, bool GN = false, typename T = bf16_t, int NJ = 2>
 __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&acc)[4][2], char* smem, int m0, int n0,
                                                 int tid, int lane, int wr, int wc) {
-    constexpr int BN = WC * 64;
+    constexpr int BN = WC * 32 * NJ;
+    static_assert(NJ == 2 || (NJ == 1 && !X3), "one or two accumulator columns per wave");
     const int hh = lane >> 5;
     // ---- epilogue in two passes (ih = 0, 1): every wave stages its 64 x 64 half (acc + bias, fp32) in LDS, then each
     //      thread finishes CPT chunks of 8 channels of one pixel: activation, residual / SFT, 16-byte store.  The
@@ -35,10 +38,10 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
     const T* res = reinterpret_cast<const T*>(p.res);
     const T* dec = reinterpret_cast<const T*>(p.dec);
     const T* shf = reinterpret_cast<const T*>(p.shift);
-    float bv[2];
+    float bv[2] = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wc * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wc * (32 * NJ) + j * 32 + (lane & 31);
         bv[j] = (p.bias && n < p.Cout) ? bias_of(p, m0)[n] : 0.f;
     }
     float gs[16];   // GN: per-thread sum / sum of squares of the 8 channels of this thread's chunk column
@@ -75,8 +78,8 @@ __device__ __forceinline__ void epilogue_128x64(const ConvP& p, const f32x16 (&a
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cl = wc * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NJ; ++j) {
+            const int cl = wc * (32 * NJ) + j * 32 + (lane & 31);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll

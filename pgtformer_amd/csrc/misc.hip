@@ -444,6 +444,35 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     if (ci < Cin) v = __fmul_rn(w[((long)co * Cin + ci) * taps + tap], scale ? scale[co] : 1.f);
     stf(out + i, v);
 }
+// exact-weight form of the single-plane 16-bit layers (pgt_conv_desc::w2): (2 * ceil32(Cout), KH*KW*Cin_pad), per group of 32 output
+// channels [32 rows w_hi | 32 rows (w - w_hi) * 2048]: the lo plane is scaled into the weights' own range (no subnormals), the
+// kernels add acc_hi + acc_lo / 2048.  One thread per (padded output channel, k).
+template <typename D>
+__global__ __launch_bounds__(256) void pack_weight_w2_kernel(const float* __restrict__ w, int Cout, int Cin, int KH, int KW, int Cin_pad,
+                                                             const float* __restrict__ scale, D* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int taps = KH * KW;
+    const int c32 = (Cout + 31) / 32 * 32;
+    const long K = (long)taps * Cin_pad;
+    if (i >= (long)c32 * K) return;
+    const int ci = (int)(i % Cin_pad);
+    const int tap = (int)((i / Cin_pad) % taps);
+    const int co = (int)(i / K);
+    float v = 0.f;
+    if (ci < Cin && co < Cout) v = __fmul_rn(w[((long)co * Cin + ci) * taps + tap], scale ? scale[co] : 1.f);
+    D hi;
+    stf(&hi, v);
+    uint16_t hb = __builtin_bit_cast(uint16_t, hi);
+    uint32_t hw = hb;
+    x3_opaque(hw);                                   // (the lo plane is taken against the STORED hi bits: see x3_opaque)
+    hb = (uint16_t)hw;
+    hi = __builtin_bit_cast(D, hb);
+    const float lo = (v - ldf(&hi)) * 2048.f;        // exact in fp32: |v - hi| <= ulp(hi) / 2
+    const long k = i % K;
+    D* o = out + ((long)(co >> 5) * 64 + (co & 31)) * K + k;
+    o[0] = hi;
+    stf(o + 32 * K, lo);
+}
 // split-half forms.  Standard: (Cout, KH*KW*3*Cin_pad), per tap and 64-channel block [w_hi | w_hi | w_lo] (the kernels visit
 // the block's input planes as [x_hi | x_lo | x_hi]).  Folded (Cout == 64): (128, KH*KW*2*Cin_pad), rows 0..63 [w_hi | w_hi],
 // rows 64..127 [w_lo | 0] per tap and block (pgt_conv_desc::x3_fold).
@@ -835,7 +864,7 @@ extern "C" int pgt_count_saturated(const void* x, int64_t ldx, int64_t rows, int
 extern "C" size_t pgt_packed_weight_bytes(int32_t dtype, int32_t Cout, int32_t Cin_pad, int32_t KH, int32_t KW, int32_t x3_fold) {
     const size_t k = (size_t)KH * KW * Cin_pad;
     if (dtype == PGT_F32) return (size_t)Cout * k * 4;
-    if (dtype == PGT_BF16 || dtype == PGT_F16) return (size_t)Cout * k * 2;
+    if (dtype == PGT_BF16 || dtype == PGT_F16) return (x3_fold == 2 ? (size_t)((Cout + 31) / 32 * 64) : (size_t)Cout) * k * 2;
     if (dtype == PGT_F16X3) return x3_fold ? (size_t)128 * 2 * k * 2 : (size_t)Cout * 3 * k * 2;
     return 0;
 }
@@ -853,7 +882,17 @@ extern "C" int pgt_pack_conv_weight(int32_t dtype, const float* w_oihw, int32_t 
         PGT_LAUNCH_CHECK();
         return 0;
     }
-    PGT_CHECK(!x3_fold, "pack_conv_weight: x3_fold goes with dtype PGT_F16X3");
+    if (x3_fold == 2) {      // exact-weight form (pgt_conv_desc::w2)
+        PGT_CHECK(dtype == PGT_F16 || dtype == PGT_BF16, "pack_conv_weight: the exact-weight form (x3_fold = 2) goes with PGT_F16 / PGT_BF16");
+        const dim3 g2 = grid1d((long)((Cout + 31) / 32 * 32) * KH * KW * Cin_pad);
+        if (dtype == PGT_F16)
+            hipLaunchKernelGGL((pack_weight_w2_kernel<half_t>), g2, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (half_t*)packed);
+        else
+            hipLaunchKernelGGL((pack_weight_w2_kernel<bf16_t>), g2, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (bf16_t*)packed);
+        PGT_LAUNCH_CHECK();
+        return 0;
+    }
+    PGT_CHECK(!x3_fold, "pack_conv_weight: x3_fold = 1 goes with dtype PGT_F16X3");
     DT_DISPATCH_T(dtype, "pack_conv_weight",
                   hipLaunchKernelGGL((pack_weight_kernel<T_>), g, dim3(256), 0, st, w_oihw, Cout, Cin, KH, KW, Cin_pad, out_scale, (T_*)packed));
 }

@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                                    "ld_dec", "ld_shift")] + [("sft_w", f32)] + \
                [(n, i32) for n in ("out_f32", "force_bm", "force_bn", "scalar_epilogue", "kernel", "splitk", "stages",
                                    "orow_mul", "orow_xmul", "orow_off", "x_lo", "y_lo", "r_lo", "gn_groups", "gn_sub",
-                                   "gn_nsub", "gn_img0", "gn_nimg", "res_f32", "x3_fold", "dec_lo", "shift_lo", "bias_rows", "out_split")]
+                                   "gn_nsub", "gn_img0", "gn_nimg", "res_f32", "x3_fold", "dec_lo", "shift_lo", "bias_rows", "out_split", "w2")]
 
 
 # name -> argtypes (restype is int32 unless listed in _RESTYPES); must cover every symbol of pgt_hip.h

@@ -58,14 +58,24 @@ def _is_x3f(dtype):
     return isinstance(dtype, str) and dtype == X3F
 
 
-def _pack_matrix(w, device, dtype, cin_pad=None, scale=None, fold=False):
+def _pack_matrix(w, device, dtype, cin_pad=None, scale=None, fold=False, w2=False):
     """reference weight - (Cout, Cin, KH, KW), or any K-major (Cout, K) matrix - -> kernel operand on `device`: the repack is
-    the library's (pgt_pack_conv_weight: K-major rows, channel padding, rounding to the compute type, the split-half forms)"""
+    the library's (pgt_pack_conv_weight: K-major rows, channel padding, rounding to the compute type, the split-half forms;
+    w2: the exact-weight operand of a half layer, two planes per filter row)"""
     w = w.detach().to(device=device, dtype=torch.float32)
-    if (ops.USE_TAP_DIFFUSION and w.dim() == 4 and w.shape[2] * w.shape[3] > 1 and scale is None
-            and dtype in (torch.float16, torch.bfloat16)):
-        w = ops.tap_diffused(w, dtype)      # single-plane 16-bit k x k layers: rounding errors cancel over the taps of a filter
-    return ops.pack_conv_weight(w, dtype, cin_pad=cin_pad, scale=scale, fold=fold)
+    return ops.pack_conv_weight(w, dtype, cin_pad=cin_pad, scale=scale, fold=fold, w2=w2)
+
+
+def mark_exact_weights(m, flag=True):
+    """Every layer of the module tree `m` is to run with EXACT weights where its type allows (IEEE-half layers: two weight planes,
+    pgt_conv_desc::w2) - call before prepare(); DESIGN.md section 2.3"""
+    for sub in m.modules():
+        sub.exact_w = bool(flag)
+
+
+def _exact(m, dtype, k_channels):
+    """does layer `m` keep an exact-weight operand next to its single-plane one? (half layers whose K comes in 64-channel blocks)"""
+    return bool(getattr(m, "exact_w", False)) and dtype == torch.float16 and k_channels % 64 == 0
 
 
 def _wants_wcomp(dtype):
@@ -136,6 +146,8 @@ class Conv2d(nn.Conv2d, HipModule):
         self.pw = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale)
         self.pb = b
         self.pdef = _defect_t(self.weight, self.pw, scale=scale) if _wants_wcomp(dtype) else None
+        # exact-weight layers keep the two-plane operand as well; run() takes it wherever the library has the form for the launch
+        self.pw2 = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale, w2=True) if _exact(self, dtype, cin_k) else None
         # split-half layers with 64 output channels: the folded form fills the 128-column tile (pgt_conv_desc.x3_fold)
         self.pw_fold = None
         if (_is_x3(dtype) or _is_x3f(dtype)) and cout == 64 and cin_k % 64 == 0 and USE_X3_FOLD:
@@ -166,6 +178,11 @@ class Conv2d(nn.Conv2d, HipModule):
             x = ops.affine_act(x, a_in[0], a_in[1], a_in[2], x3=_is_x3(self.dt))      # no fused-operand form for this launch: one apply pass
             kw = {k: v for k, v in kw.items() if k != "affine_in"}
             a_in = None
+        if getattr(self, "pw2", None) is not None and ops.w2_ok(x, self.out_channels, self._fold_cin, self.kernel_size[0], self.kernel_size[1],
+                                                                self.stride[0], self.pad4, bias=b, **{k: v for k, v in kw.items() if k != "affine_in"}):
+            # exact weights (two planes, two MFMAs per product): nothing to compensate
+            return ops.conv2d(x, self.pw2, b, kh=self.kernel_size[0], kw=self.kernel_size[1], stride=self.stride[0], pad=self.pad4,
+                              w2=self.out_channels, **kw)
         if self.pdef is not None and self.stride == (1, 1) and not kw.get("ups"):     # (same-size layers: frames of H*W output pixels)
             b = _frame_bias(x, self.pdef, self.pb, affine_in=a_in)
         return ops.conv2d(x, w, b, kh=self.kernel_size[0], kw=self.kernel_size[1],
@@ -177,10 +194,20 @@ class Linear(nn.Linear, HipModule):
         self.pw = _pack_matrix(self.weight, device, dtype)
         self.pb = _f32(self.bias, device)
         self.pdef = _defect_t(self.weight, self.pw) if _wants_wcomp(dtype) else None
+        self.pw2 = _pack_matrix(self.weight, device, dtype, w2=True) if _exact(self, dtype, self.in_features) and self.out_features % 8 == 0 else None
 
     def run(self, x, frames=None, **kw):
         """frames: the rows of x are the tokens of that many frames (equal counts): enables the per-frame compensation"""
+        if getattr(self, "pw2", None) is not None and _rows_w2_ok(x, kw.get("res"), kw.get("out")):
+            return ops.linear(x, self.pw2, self.pb, w2=self.out_features, **kw)      # exact weights: nothing to compensate
         return ops.linear(x, self.pw, _frame_bias(x, self.pdef, self.pb, frames), x3=_is_x3(self.dt), **kw)
+
+
+def _rows_w2_ok(x, *others):
+    """token-row operands the exact-weight form takes: IEEE half rows, 16-byte aligned with 16-byte row pitch"""
+    if x.dtype != torch.float16:
+        return False
+    return all(t is None or (t.data_ptr() % 16 == 0 and ops._ld_rows(t) % 8 == 0) for t in (x,) + others)
 
 
 class GroupNorm(nn.GroupNorm, HipModule):
@@ -223,23 +250,6 @@ def get_window_size(x_size, window_size, shift_size=None):
     return tuple(use_w) if use_s is None else (tuple(use_w), tuple(use_s))
 
 
-# Residual blocks over frame groups whose maps stay in the Infinity Cache (TDResnetBlock._forward_chunked): group size in MiB
-# of the block's widest map (0 = whole tensors, as up to round 3)
-BLOCK_GROUP_MIB = float(os.environ.get("PGT_BLOCK_GROUP_MIB", "0"))
-
-
-def _chunk_frames(x, c_stored):
-    """frames per group for an (N,H,W,.) map with c_stored 16-bit channels per pixel, or None when the map is run whole"""
-    if BLOCK_GROUP_MIB <= 0 or x.dim() != 4:
-        return None
-    n, h, w = x.shape[:3]
-    per = int(BLOCK_GROUP_MIB * (1 << 20) // max(1, h * w * c_stored * x.element_size()))
-    if per < 1 or per >= n:
-        return None if per >= n else 1
-    groups = -(-n // per)
-    return -(-n // groups)
-
-
 class TDResnetBlock(HipModule):
     """GN-SiLU-conv3x3-GN-SiLU-conv3x3 + (identity | 1x1 nin_shortcut) (reference: rstt_layers.py:835-904).
     x: (N,H,W,Cin) -> (N,H,W,Cout); the residual add is the second conv's epilogue."""
@@ -261,44 +271,11 @@ class TDResnetBlock(HipModule):
         """out: optional (N,H,W,Cout) view (e.g. a channel slice of a concat buffer) that receives the result.
         gn_next: a GroupNorm follows this block - its statistics come out of conv2's epilogue (as norm2's come out of
         conv1's: SURVEY K1/K7 "statistics from the producer")."""
-        per = _chunk_frames(x, max(self.in_channels, self.out_channels) * (2 if _is_x3(self.dt) else 1))
-        if per is not None:
-            return self._forward_chunked(x, per, out, gn_next)
         # GroupNorm apply + SiLU ride in the consuming conv's operand load where the library has that form (the 64-channel
         # 512x512 layers: Conv2d.run falls back to one apply pass elsewhere)
         h = self.conv1.run(x, affine_in=self.norm1.coeffs(x, ACT_SILU), gn=self.norm2.num_groups)
         sc = self.nin_shortcut.run(x) if self.in_channels != self.out_channels else x
         return self.conv2.run(h, affine_in=self.norm2.coeffs(h, ACT_SILU), res=sc, out=out, gn=32 if gn_next else None)
-
-    def _forward_chunked(self, x, per, out, gn_next):
-        """The same block over groups of `per` frames (every operation of it is per frame): the three intermediate maps are
-        group-sized buffers that are rewritten for every group, so the passes between the two convs find their operands in the
-        256 MiB Infinity Cache instead of HBM.  norm1's statistics are those of the whole x (its
-        producer's epilogue left them); the statistics a following GroupNorm wants come out of the groups' conv2 launches into
-        one workspace (pgt_conv_desc::gn_img0)."""
-        n, hh, ww, _ = x.shape
-        x3 = _is_x3(self.dt)
-        cs = (2 if x3 else 1)
-        co = self.out_channels
-        if out is None:
-            out = torch.empty((n, hh, ww, co * cs), device=x.device, dtype=x.dtype)
-        scale, shift = ops.groupnorm_affine(x, self.norm1.pg, self.norm1.pbeta, self.norm1.num_groups, self.norm1.eps, x3=x3)
-        t1 = torch.empty((per, hh, ww, self.in_channels * cs), device=x.device, dtype=x.dtype)
-        t2 = torch.empty((per, hh, ww, co * cs), device=x.device, dtype=x.dtype)
-        t3 = torch.empty((per, hh, ww, co * cs), device=x.device, dtype=x.dtype)
-        st = None
-        if gn_next and ops.USE_EPILOGUE_GN and ops.gn_ok(n, hh * ww, co, 32, co, 3):
-            st = ops.GnStats(n, 1, hh * ww, co, 32, x.device)
-        for f0 in range(0, n, per):
-            f1 = min(n, f0 + per)
-            m = f1 - f0
-            xs = x[f0:f1]
-            a = ops.affine_act(xs, scale[f0:f1], shift[f0:f1], ACT_SILU, out=t1[:m], x3=x3)
-            h = self.conv1.run(a, gn=self.norm2.num_groups, out=t2[:m])
-            h = self.norm2.run(h, ACT_SILU, out=t3[:m])
-            sc = self.nin_shortcut.run(xs) if self.in_channels != self.out_channels else xs
-            self.conv2.run(h, res=sc, out=out[f0:f1], gn=(st, 0, f0) if st is not None else None)
-        return out if st is None else st.bind(out, co * cs)
 
 
 class Mlp(HipModule):
@@ -329,6 +306,7 @@ class WindowAttention3D(HipModule):
         wcat = torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0)
         self.w_qkv = _pack_matrix(wcat, device, dtype)
         self.d_qkv = _defect_t(wcat, self.w_qkv) if _wants_wcomp(dtype) else None
+        self.w_qkv2 = _pack_matrix(wcat, device, dtype, w2=True) if _exact(self, dtype, self.dim) else None
         if self.q.bias is not None:
             self.b_qkv = _f32(torch.cat([self.q.bias.detach(), self.kv.bias.detach()], 0), device)
         else:
@@ -355,6 +333,8 @@ class VSTSREncoderTransformerBlock(HipModule):
         """Operands of the fused token-row chains (ops.ln_linear, ops.attn_proj_mlp: half layers of 256 channels): norm1 folded
         into the [q | k | v] projection, norm2 into fc1 (pgt_fold_layernorm), proj / fc1 / fc2 stacked into one matrix."""
         self.fused = False
+        if _exact(self, dtype, self.dim):
+            return      # exact-weight blocks run layer by layer on the two-plane linears (the chains hold single-plane weights)
         # the chains are built for the shipping blocks: 256 channels, Mlp hidden width == dim (mlp_ratio 1, the reference's
         # EncoderLayer call sites: archs/tdcrqvae3_arch.py:499), biased q / kv; anything else runs layer by layer
         if not (USE_ROWCHAIN and self.dim == 256 and self.attn.q.bias is not None and self.attn.kv.bias is not None and
@@ -418,7 +398,10 @@ class VSTSREncoderTransformerBlock(HipModule):
                 b1, b2 = ops.mean_field_bias(m_ln, self.f_dfc1, self.f_b1), ops.mean_field_bias(m_hid, self.f_dfc2, self.f_b2)
             return ops.attn_proj_mlp(ao, xt, self.f_w3, bp, b1, b2, self.norm2.eps, out=out)
         ln = self.norm1.run(xt)
-        qkv = ops.linear(ln, self.attn.w_qkv, _frame_bias(ln, self.attn.d_qkv, self.attn.b_qkv, nf), x3=x3)
+        if getattr(self.attn, "w_qkv2", None) is not None and _rows_w2_ok(ln):
+            qkv = ops.linear(ln, self.attn.w_qkv2, self.attn.b_qkv, w2=3 * C)
+        else:
+            qkv = ops.linear(ln, self.attn.w_qkv, _frame_bias(ln, self.attn.d_qkv, self.attn.b_qkv, nf), x3=x3)
         ao = ops.window_attention(qkv, self.attn.bias_dense, B, self.num_frames, H, W, C, self.num_heads, win, shift, x3=x3)
         x1 = self.attn.proj.run(ao, frames=nf, res=xt)
         nfm = nf if USE_WCOMP_MLP else None

@@ -97,55 +97,57 @@ def _dtype_code(dtype):
     return {torch.float32: PGT_F32, torch.bfloat16: PGT_BF16, torch.float16: hip.PGT_F16}[dtype], dtype
 
 
-def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
+def w2_rows(cout):
+    """rows of the exact-weight operand of a layer with `cout` output channels: [32 rows w_hi | 32 rows w_lo * 2048] per 32 channels"""
+    return (cout + 31) // 32 * 64
+
+
+def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False, w2=False):
     """Reference weight -> the conv / linear kernels' operand, on the device (pgt_pack_conv_weight).  w: fp32 device tensor
     (Cout, Cin, KH, KW) (nn.Conv2d) or (Cout, Cin) (nn.Linear, or any K-major matrix); dtype: torch.float32 / bfloat16 /
     float16, or X3 / X3F (split-half: [w_hi | w_hi | w_lo] per 64-channel block; fold=True: the 64-output-channel folded form);
-    cin_pad: zero-pad the input channels; scale: optional fp32 (Cout,) factor applied before rounding (BatchNorm fold)."""
+    cin_pad: zero-pad the input channels; scale: optional fp32 (Cout,) factor applied before rounding (BatchNorm fold).
+    w2=True (half / bf16): the EXACT-WEIGHT operand (pgt_conv_desc::w2) - (w2_rows(Cout), K), two 16-bit planes per filter row;
+    conv2d / linear take it with w2=Cout."""
     assert w.dtype == torch.float32 and w.dim() in (2, 4)
     w = w.contiguous()
     cout, cin = w.shape[0], w.shape[1]
     kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
     cp = cin if cin_pad is None or cin_pad < cin else cin_pad
     code, st = _dtype_code(dtype)
+    assert not (w2 and (fold or isinstance(dtype, str) or dtype == torch.float32)), "exact weights: single-plane 16-bit layers"
     L = hip.lib()
-    nbytes = L.pgt_packed_weight_bytes(code, cout, cp, kh, kw, int(bool(fold)))
-    rows = 128 if fold else cout
+    form = 2 if w2 else int(bool(fold))
+    nbytes = L.pgt_packed_weight_bytes(code, cout, cp, kh, kw, form)
+    rows = w2_rows(cout) if w2 else (128 if fold else cout)
     out = torch.empty((rows, nbytes // (rows * torch.empty((), dtype=st).element_size())), device=w.device, dtype=st)
-    hip.check(L.pgt_pack_conv_weight(code, _p(w), cout, cin, kh, kw, cp, _p(scale), int(bool(fold)), _p(out), _stream()),
+    hip.check(L.pgt_pack_conv_weight(code, _p(w), cout, cin, kh, kw, cp, _p(scale), form, _p(out), _stream()),
               "pgt_pack_conv_weight")
     return out
 
 
-# k x k half / bf16 layers: tap-diffused weight rounding - a STUDY switch, off: measured on the GPU build it does not help on top of
-# the mean-field compensation (third operating point: worst window 9.5e-4 -> 1.49e-3 dB; profiles/r5_w_tap_diffusion_spread.jsonl)
-USE_TAP_DIFFUSION = _os.environ.get("PGT_TAP_DIFFUSION", "0") == "1"
+# Exact-weight layers (DESIGN.md section 2.3): the decoder stages whose weight rounding carried the PSNR contract's margin run with
+# two-plane weights (two MFMAs per product, pgt_conv_desc::w2) instead of the mean-field compensation.  PGT_EXACT_W = comma-separated
+# decoder stages ("512,32" default; "" = none: every half layer single-plane + compensated, the round-5 build)
+EXACT_W_STAGES = tuple(t for t in _os.environ.get("PGT_EXACT_W", "512,32").split(",") if t)
 
 
-def tap_diffused(w, dtype):
-    """(Cout, Cin, KH, KW) fp32 -> fp32 values that are exact in `dtype` (half / bf16), rounded so that the rounding errors CANCEL over
-    the taps of every (cout, cin) filter: taps are taken in order of decreasing magnitude, each rounded to the value nearest to
-    (w - carried error); the sum over taps of q - w ends below half an ulp of the smallest tap.  The defect D = q - W of a k x k
-    layer then does not respond to the spatially smooth part of its operand - the part of the weight-rounding error the
-    per-band mean field removes only for the band mean - at the price of up to one ulp instead of half
-    an ulp on single taps.  Oracle ablation (tests/precision_study3.py, profiles/r5_u_third_point_oracle_ablation.md): the
-    uncompensated contract figure of the 3x3 layers of the 512 x 512 stage falls from -1.7e-3 to +2e-5 dB, of the 32 x 32 stage
-    from -8.2e-4 to -1.6e-5 - in the ORACLE, without compensation and with exact activations.  On the GPU build (mean-field
-    compensation on, half activations) it made the third operating point worse, so it is not applied by default.
-    Deterministic (stable sort), runs once per layer at prepare time."""
-    assert w.dim() == 4 and w.dtype == torch.float32
-    o, c, kh, kw = w.shape
-    flat = w.reshape(o * c, kh * kw).double()
-    order = flat.abs().argsort(dim=1, descending=True, stable=True)
-    ws = flat.gather(1, order)
-    q = torch.empty_like(ws)
-    e = torch.zeros(o * c, dtype=torch.float64, device=w.device)
-    for t in range(kh * kw):
-        q[:, t] = (ws[:, t] - e).to(dtype).double()
-        e = e + q[:, t] - ws[:, t]
-    out = torch.empty_like(q)
-    out.scatter_(1, order, q)
-    return out.reshape(o, c, kh, kw).float().contiguous()
+def w2_ok(x, cout, cin, kh, kw, stride, pad, *, ups=False, act=ACT_NONE, res=None, post_relu=False, sft=None, out=None, out_f32=False,
+          tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, out_parity=None, out_rows=None, x3=False, out_x3=False, bias=None,
+          gn=None, **_other):
+    """Does the library have the exact-weight form (pgt_conv_desc::w2) for this launch?  Mirror of the dispatch in csrc/igemm.hip:
+    the 64-channel ring kernel where it is legal, else the phased LDS-DMA kernel (IEEE half, Cin % 64 == 0, 16-byte epilogue)."""
+    if x3 or out_x3 or x.dtype != torch.float16 or x.dim() != 4 or ups or splitk not in (0, 1) or scalar_epi or kernel not in (0, 4, 8):
+        return False
+    al = lambda t: t is None or (t.data_ptr() % 16 == 0 and (_ld_img(t) if t.dim() == 4 else t.stride(-2)) % 8 == 0)      # noqa: E731
+    aligned = cout % 8 == 0 and al(out) and al(res) and (sft is None or (al(sft[0]) and al(sft[1])))
+    if kernel != 4 and cin == 64 and (aligned or cout <= 16) and ring_covers(
+            x, cout, kh, kw, stride, pad, ups=ups, act=act, res=res, post_relu=post_relu, sft=sft, out=out, out_f32=out_f32, tile=tile,
+            scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, out_parity=out_parity, out_rows=out_rows, bias=bias):
+        return True       # the 64-channel ring kernel (two weight planes in registers)
+    if cin % 64 or not aligned or kh * kw > 30 or _ld_img(x) % 8 or x.data_ptr() % 16 or tuple(tile)[0]:
+        return False
+    return w2_rows(cout) * kh * kw * cin * 2 < (1 << 31)
 
 
 def fold_batchnorm(gamma, beta, mean, var, eps, bias=None):
@@ -368,8 +370,10 @@ def _tune_conv(d, args, device, iters=4, gn_ws=None):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0,
-           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False, out_x3=False, affine_in=None):
+           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False, out_x3=False, affine_in=None, w2=None):
     """Implicit-GEMM conv. x: (N,H,W,Cin); w: (Cout, kh*kw*Cin) packed; pad=(top,bottom,left,right).
+    w2: None, or Cout: w is the EXACT-WEIGHT operand pack_conv_weight(..., w2=True) wrote ((w2_rows(Cout), kh*kw*Cin): two 16-bit
+    planes per filter row, two MFMAs per product; launches w2_ok accepts).
     sft=(dec, shift, w_scalar) selects the SFT epilogue. Returns (N,Ho,Wo,Cout).
     out_parity=(py, px): write the (N,Ho,Wo,Cout) result to out[:, py::2, px::2, :] of a required (N,2Ho,2Wo,Cout) `out`
     (sub-pixel convolutions; plain epilogue only).
@@ -384,9 +388,12 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     affine_act pass."""
     n, h, wd, cin = x.shape
     cout = w.shape[0]
+    if w2 is not None:
+        cout = int(w2)
+        assert w.shape[0] == w2_rows(cout) and not x3 and not x3_fold and not out_x3 and x.dtype == torch.float16, (w.shape, cout, x.dtype)
     if affine_in is not None and not affine_in_fuses(x, cout, kh, kw, stride, pad, ups=ups, act=act, res=res, post_relu=post_relu, sft=sft,
                                                     out=out, out_f32=out_f32, tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk,
-                                                    out_parity=out_parity, out_rows=out_rows, x3=x3, out_x3=out_x3, bias=bias):
+                                                    out_parity=out_parity, out_rows=out_rows, x3=x3, out_x3=out_x3, bias=bias, force=w2 is not None):
         x = affine_act(x, affine_in[0], affine_in[1], affine_in[2], x3=x3)
         affine_in = None
     if out_x3:
@@ -428,7 +435,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                    res=None if res is None else res[sl], post_relu=post_relu,
                    sft=None if sft is None else (sft[0][sl], sft[1][sl], sft[2]), out=out[sl], out_f32=out_f32,
                    tile=tile, scalar_epi=scalar_epi, kernel=kernel, splitk=splitk, stages=stages, x3=x3,
-                   gn=None if st is None else (st, 0, i), x3_fold=x3_fold, out_x3=out_x3,
+                   gn=None if st is None else (st, 0, i), x3_fold=x3_fold, out_x3=out_x3, w2=w2,
                    affine_in=None if affine_in is None else (affine_in[0][sl], affine_in[1][sl], affine_in[2]))
         return out if st is None else st.bind(out, cst)
     hv, wv = (h * 2, wd * 2) if ups else (h, wd)
@@ -458,6 +465,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     d.stages = int(stages)
     d.x3_fold = int(bool(x3_fold))
     d.out_split = int(bool(out_x3))
+    d.w2 = int(w2 is not None)
     if bias is not None and bias.dim() == 2:      # one bias vector per frame (mean_field_bias): (frames, Cout) fp32
         assert bias.shape[1] == cout and bias.is_contiguous() and (n * ho * wo) % bias.shape[0] == 0 and bias.shape[0] % n == 0, (bias.shape, n, cout)
         d.bias_rows = (n * ho * wo) // bias.shape[0]
@@ -490,7 +498,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
         e0.record()
     L = hip.lib()
     if (AUTOTUNE is not None and kernel == 0 and tile == (0, 0) and splitk == 0 and not scalar_epi
-            and x.dtype == torch.bfloat16 and not x3):
+            and x.dtype == torch.bfloat16 and not x3 and affine_in is None):
         key = (n, h, wd, cin, d.ldx, d.ups, kh, kw, stride, tuple(pad), cout, d.ldy, act, d.post_relu, d.ldr, d.epi,
                d.ld_dec, d.ld_shift, d.out_f32, bias is None, d.orow_mul, d.orow_xmul, d.orow_off, d.gn_groups, d.bias_rows)
         cfg = AUTOTUNE.get(key)
@@ -526,16 +534,16 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
                      "bytes": float(n * h * wd * x.shape[-1] * es + m * out.shape[-1] * out.element_size() + w.numel() * es
                                     + (m * res.shape[-1] * es if res is not None else 0)),
                      "shape": (n, h, wd, cin, cout, kh, stride, int(ups)), "events": (e0, e1),
-                     "cfg": (d.kernel, d.force_bm, d.force_bn), "x3": bool(x3), "dt": str(x.dtype).replace("torch.", "")})
+                     "cfg": (d.kernel, d.force_bm, d.force_bn), "x3": bool(x3), "dt": str(x.dtype).replace("torch.", ""),
+                     "w2": w2 is not None})
     return out
 
 
-def affine_in_fuses(x, cout, kh, kw, stride, pad, *, ups=False, act=ACT_NONE, res=None, post_relu=False, sft=None, out=None,
-                    out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, out_parity=None, out_rows=None, x3=False,
-                    out_x3=False, bias=None, **_other):
-    """Does the library have the fused-operand form (pgt_conv2d_affine_in) for this conv?  Mirror of ring_legal (csrc/igemm.hip)
-    - the library re-checks (pgt_conv2d_affine_in_ok) and conv2d raises if the two ever disagree."""
-    if not USE_FUSED_GN_APPLY or x3 or out_x3 or x.dtype not in (torch.float16, torch.bfloat16) or x.dim() != 4:
+def ring_covers(x, cout, kh, kw, stride, pad, *, ups=False, act=ACT_NONE, res=None, post_relu=False, sft=None, out=None,
+                out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, out_parity=None, out_rows=None, x3=False,
+                out_x3=False, bias=None, **_other):
+    """Does the 64-channel ring kernel (csrc/igemm8.hip) cover this launch?  Mirror of ring_legal (csrc/igemm.hip)."""
+    if x3 or out_x3 or x.dtype not in (torch.float16, torch.bfloat16) or x.dim() != 4:
         return False
     n, h, wd, cin = x.shape
     p2 = lambda v: v > 0 and (v & (v - 1)) == 0      # noqa: E731
@@ -547,6 +555,8 @@ def affine_in_fuses(x, cout, kh, kw, stride, pad, *, ups=False, act=ACT_NONE, re
         return False
     if kernel not in (0, 8) or tuple(tile) != (0, 0) or splitk not in (0, 1):
         return False
+    if bias is not None and bias.dim() == 2 and ((n * h * wd) // bias.shape[0]) % (4 * wd):
+        return False      # a strip of the ring kernel (>= 4 rows x 128 columns) takes one bias vector: bias bands must be whole strips
     if n * h * wd * _ld_img(x) * x.element_size() >= (1 << 31):
         return True if n > 1 else False       # (conv2d runs frame chunks: each chunk is asked again)
     aligned = cout % 8 == 0 and (out is None or (_ld_img(out) % 8 == 0 and out.data_ptr() % 16 == 0)) and \
@@ -556,12 +566,19 @@ def affine_in_fuses(x, cout, kh, kw, stride, pad, *, ups=False, act=ACT_NONE, re
     return aligned or cout <= 32
 
 
-def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False, gn=None):
+def affine_in_fuses(x, cout, kh, kw, stride, pad, *, force=False, **kw_):
+    """Does the library have the fused-operand form (pgt_conv2d_affine_in) for this conv?  The launches the ring kernel covers -
+    the library re-checks (pgt_conv2d_affine_in_ok) and conv2d raises if the two ever disagree.  force: whatever the
+    PGT_FUSE_GN_APPLY switch says (exact-weight launches on the ring kernel keep their fused operand)."""
+    return (USE_FUSED_GN_APPLY or force) and ring_covers(x, cout, kh, kw, stride, pad, **kw_)
+
+
+def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False, gn=None, w2=None):
     """x: (rows, Cin) -> (rows, Cout); x3: split-half rows (rows, 2*Cin) -> (rows, 2*Cout) (or fp32 (rows, Cout)).
     gn=(groups, n_images): the rows are n_images images of rows / n_images tokens each; the epilogue leaves the GroupNorm
-    statistics of the output per image (attached to the returned tensor, see conv2d)."""
+    statistics of the output per image (attached to the returned tensor, see conv2d).  w2: see conv2d."""
     rows, cin = x.shape
-    cst = w.shape[0] * (2 if x3 and not out_f32 else 1)
+    cst = (w.shape[0] if w2 is None else int(w2)) * (2 if x3 and not out_f32 else 1)
     if out is None:
         out = torch.empty((rows, cst), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     nimg = gn[1] if gn is not None else 1
@@ -577,7 +594,7 @@ def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, 
     x4 = x.as_strided((nimg, 1, hw, cin), (hw * _ld_rows(x), 0, _ld_rows(x), 1))
     o4 = out.as_strided((nimg, 1, hw, cst), (hw * _ld_rows(out), 0, _ld_rows(out), 1))
     r4 = None if res is None else res.as_strided((nimg, 1, hw, cst), (hw * _ld_rows(res), 0, _ld_rows(res), 1))
-    o4 = conv2d(x4, w, bias, act=act, res=r4, out=o4, out_f32=out_f32, x3=x3, gn=None if gn is None else gn[0])
+    o4 = conv2d(x4, w, bias, act=act, res=r4, out=o4, out_f32=out_f32, x3=x3, gn=None if gn is None else gn[0], w2=w2)
     st = getattr(o4, "_pgt_gn", None)
     return out if st is None else st.bind(out, cst)
 

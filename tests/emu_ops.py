@@ -65,7 +65,16 @@ def _unpack_x3_weight(w, taps):
     return (w5[:, :, :, 0] + w5[:, :, :, 2]).reshape(cout, -1)
 
 
-def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
+W2_SCALE = 2048.0       # csrc/igemm_common.h kW2Inv: the lo plane of an exact-weight operand is stored scaled by 2^11
+
+
+def _unpack_w2_weight(w, cout):
+    """exact-weight operand (2 * ceil32(cout) rows: per 32 channels [32 rows hi | 32 rows lo * 2048]) -> fp32 (cout, K) = hi + lo / 2048"""
+    g = w.float().reshape(-1, 2, 32, w.shape[1])
+    return (g[:, 0] + g[:, 1] / W2_SCALE).reshape(-1, w.shape[1])[:cout].contiguous()
+
+
+def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False, w2=False):
     """torch restatement of pgt_pack_conv_weight (K-major rows, zero-padded input channels, optional per-channel factor)"""
     w4 = w.float() if w.dim() == 4 else w.float()[:, :, None, None]
     if scale is not None:
@@ -83,6 +92,13 @@ def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False):
             bot = torch.cat([lo4, torch.zeros_like(lo4)], 3).reshape(cout, -1)
             return torch.cat([top, bot], 0).contiguous()
         return torch.cat([hi4, hi4, lo4], 3).reshape(cout, -1).contiguous()
+    if w2:                                                              # exact-weight form: two planes per filter row
+        k2 = k3.reshape(cout, -1)
+        c32 = (cout + 31) // 32 * 32
+        k2 = F.pad(k2, (0, 0, 0, c32 - cout))
+        hi = k2.to(dtype)
+        lo = ((k2 - hi.float()) * W2_SCALE).to(dtype)
+        return torch.stack([hi.reshape(-1, 32, k2.shape[1]), lo.reshape(-1, 32, k2.shape[1])], 1).reshape(2 * c32, -1).contiguous()
     return k3.reshape(cout, -1).to(dtype).contiguous()
 
 
@@ -121,7 +137,9 @@ def _store(val, out, dtype):
 
 def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False, act=ACT_NONE, res=None,
            post_relu=False, sft=None, out=None, out_f32=False, tile=(0, 0), scalar_epi=False, kernel=0, splitk=0, stages=0, out_x3=False,
-           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False, affine_in=None):
+           out_parity=None, out_rows=None, x3=False, gn=None, x3_fold=False, affine_in=None, w2=None):
+    if w2 is not None:         # exact-weight operand: the layer multiplies by hi + lo / 2048 (fp32 below)
+        w = _unpack_w2_weight(w, int(w2))
     if affine_in is not None:      # the fused operand (pgt_conv2d_affine_in) = the apply pass's result, rounded to the tensor's type
         x = affine_act(x, affine_in[0], affine_in[1], affine_in[2], x3=x3)
     n, h, wd, cin = x.shape
@@ -140,7 +158,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
             w = _unpack_x3_weight(w, kh * kw)
         if res is not None:
             res = res if res.dtype == torch.float32 else _merge(res)      # fp32 residual: fp32-stored tensors (BiSeNet)
-    assert w.shape[1] == kh * kw * cin and w.dtype == x.dtype
+    assert w.shape[1] == kh * kw * cin and (w.dtype == x.dtype or w2 is not None)
     xi = x.float().permute(0, 3, 1, 2)
     if ups:
         xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
@@ -175,7 +193,9 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
     return _store(y, out, torch.float32 if out_f32 else x.dtype)
 
 
-def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False, gn=None):
+def linear(x, w, bias=None, *, act=ACT_NONE, res=None, out=None, out_f32=False, x3=False, gn=None, w2=None):
+    if w2 is not None:
+        w = _unpack_w2_weight(w, int(w2))
     if x3:
         x, w = _merge(x), _unpack_x3_weight(w, 1)
         res = None if res is None else _merge(res)

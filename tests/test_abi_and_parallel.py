@@ -31,7 +31,7 @@ def test_header_symbols_are_exported_and_bound():
     lib.pgt_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.pgt_version()
     # ConvDesc mirrors pgt_conv_desc: 22 int32 + float + 24 int32
-    assert ctypes.sizeof(hip.ConvDesc) == 47 * 4
+    assert ctypes.sizeof(hip.ConvDesc) == 48 * 4      # 22 int32 + float + 25 int32
     fields = re.search(r"typedef struct pgt_conv_desc \{(.*?)\} pgt_conv_desc;", hdr, re.S).group(1)
     names = [n.strip() for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", fields) for n in decl.split(",")]
     assert names == [f[0] for f in hip.ConvDesc._fields_]

@@ -646,6 +646,146 @@ def test_conv2d_c64_ring_kernel(shape, dtype):
     assert torch.equal(small, O.conv2d(O.affine_act(d_x, g(sc[:1].contiguous()), g(sh[:1].contiguous()), E.ACT_SILU), gw, gb, **kw))
 
 
+def _exact_conv_f64(x, w32, b, kh, kw, pad, res=None, act=E.ACT_NONE, stride=1):
+    """conv of the (half) operand x with the EXACT fp32 weights, in float64: what an exact-weight layer approximates"""
+    import torch.nn.functional as F
+    cout = w32.shape[0]
+    xi = F.pad(x.double().permute(0, 3, 1, 2), (pad[2], pad[3], pad[0], pad[1]))
+    wt = w32.double().reshape(cout, kh, kw, -1).permute(0, 3, 1, 2)
+    y = F.conv2d(xi, wt, b.double(), stride=stride).permute(0, 2, 3, 1)
+    y = E._act(y.float(), act).double() if act != E.ACT_NONE else y
+    return y if res is None else y + res.double()
+
+
+W2_CASES = [
+    # name, (n, h, w, cin), cout, k, what
+    ("ring_64_64", (3, 16, 128, 64), 64, 3, "ring"),
+    ("ring_64_3", (2, 8, 256, 64), 3, 3, "ring"),
+    ("ring_64_16", (2, 8, 128, 64), 16, 3, "ring"),
+    ("ring_64_40", (2, 8, 128, 64), 40, 3, "ring"),
+    ("v4_128_64_3x3", (2, 32, 32, 128), 64, 3, "v4"),
+    ("v4_512_512_3x3", (3, 32, 32, 512), 512, 3, "v4"),
+    ("v4_192_96_1x1", (2, 32, 32, 192), 96, 1, "v4"),
+    ("v4_64_64_small_map", (2, 32, 32, 64), 64, 3, "v4"),
+    ("v4_256_24_1x1", (1, 16, 64, 256), 24, 1, "v4"),
+]
+
+
+@pytest.mark.parametrize("case", W2_CASES, ids=[c[0] for c in W2_CASES])
+def test_conv2d_exact_weights(case):
+    """The exact-weight form of the IEEE-half layers (pgt_conv_desc::w2, round 6; DESIGN.md section 2.3): two weight planes
+    (w_hi | (w - w_hi) * 2048), two MFMAs per product, y = acc_hi + acc_lo / 2048 - in the 64-channel ring kernel (16 output channels
+    per wave, both planes in registers) and in the phased LDS-DMA kernel (a wave's 64 tile columns = hi and lo rows of 32 output
+    channels).  With fp32 output the result must sit at fp32-ACCUMULATION distance from the conv with the exact fp32 weights (2e-5 of
+    the output scale), where the single-plane layer of the same launch is 2^-12-per-weight away (asserted: > 5x further) - the test
+    would not pass with the lo plane dropped, mis-scaled or paired with the wrong channel.  Also: half output = one rounding of that
+    result, residual / activation / per-frame bias / SFT epilogues, channel-slice views, epilogue GroupNorm statistics, run-to-run bits."""
+    name, (n, h, w_, cin), cout, k, kind = case
+    O = ops()
+    x = rnd((n, h, w_, cin), 910, torch.float16)
+    w32 = rnd((cout, k * k * cin), 911, torch.float32, 1.0 / np.sqrt(k * k * cin))
+    w32[:, 0] += torch.arange(cout, dtype=torch.float32) * 0.01          # asymmetric in the output channel
+    w4 = w32.reshape(cout, k, k, cin).permute(0, 3, 1, 2).contiguous()    # the reference's (Cout, Cin, KH, KW)
+    b = rnd((cout,), 912, torch.float32, 0.1)
+    pad = (k // 2,) * 4
+    kw = dict(kh=k, kw=k, pad=pad)
+    gx, gb = g(x), g(b)
+    pw2 = O.pack_conv_weight(g(w4), torch.float16, w2=True)
+    pw1 = O.pack_conv_weight(g(w4), torch.float16)
+    assert tuple(pw2.shape) == (O.w2_rows(cout), k * k * cin)
+    assert torch.equal(pw2.cpu(), E.pack_conv_weight(w4, torch.float16, w2=True)), "library and emulation pack different exact-weight operands"
+    assert O.w2_ok(gx, cout, cin, k, k, 1, pad, bias=gb)
+    assert (kind == "ring") == O.ring_covers(gx, cout, k, k, 1, pad, bias=gb)
+    want64 = _exact_conv_f64(x, w32, b, k, k, pad)
+    scale = max(1.0, float(want64.abs().max()))
+    got = O.conv2d(gx, pw2, gb, w2=cout, out_f32=True, **kw)
+    err2 = float((got.double().cpu() - want64).abs().max())
+    one = O.conv2d(gx, pw1, gb, out_f32=True, **kw)
+    err1 = float((one.double().cpu() - want64).abs().max())
+    _LOG.append({"name": f"w2_{name}_f32out", "dtype": "float16 (two weight planes)", "max_abs_err": err2, "single_plane_err": err1,
+                 "ref_absmax": scale, "tol": 2e-5 * scale, "ok": bool(err2 <= 2e-5 * scale)})
+    assert err2 <= 2e-5 * scale, (name, err2, scale)
+    assert err1 > 5 * err2, f"{name}: the single-plane launch is as close to the exact conv as the exact-weight one ({err1:.2e} vs {err2:.2e}): the test cannot see the lo plane"
+    check(f"w2_{name}_emu_f32out", got, E.conv2d(x, E.pack_conv_weight(w4, torch.float16, w2=True), b, w2=cout, out_f32=True, **kw), torch.float32)
+    # half output: ONE rounding of the fp32 result
+    goth = O.conv2d(gx, pw2, gb, w2=cout, **kw)
+    assert float((goth.float() - got.clamp(-65504, 65504).half().float()).abs().max()) == 0.0 or \
+        float((goth.double().cpu() - want64).abs().max()) <= 6e-4 * scale
+    for _ in range(5):
+        assert torch.equal(O.conv2d(gx, pw2, gb, w2=cout, **kw), goth), f"{name}: not run-to-run deterministic"
+    # residual (both kernels), fp32 out
+    res = rnd(tuple(want64.shape), 913, torch.float16)
+    gres = g(res)
+    gotr = O.conv2d(gx, pw2, gb, w2=cout, res=gres, out_f32=True, **kw)
+    assert float((gotr.double().cpu() - (want64 + res.double())).abs().max()) <= 2e-5 * scale
+    if (h * w_) % 512 == 0 and (kind == "v4" or (h * w_) % (4 * w_) == 0):      # one bias vector per frame
+        fb = rnd((n, cout), 914, torch.float32, 0.3)
+        gotb = O.conv2d(gx, pw2, g(fb), w2=cout, out_f32=True, **kw)
+        wantb = _exact_conv_f64(x, w32, torch.zeros(cout), k, k, pad) + fb.double()[:, None, None, :]
+        assert float((gotb.double().cpu() - wantb).abs().max()) <= 2e-5 * scale
+    if kind == "ring":
+        # the fused operand (GroupNorm apply + SiLU in the operand load) with exact weights = apply pass + the same kernel, bit for bit
+        sc = (1.0 + 0.3 * rnd((n, cin), 916)).contiguous()
+        sh = (0.2 * rnd((n, cin), 917)).contiguous()
+        xa = O.affine_act(gx, g(sc), g(sh), E.ACT_SILU)
+        two = O.conv2d(xa, pw2, gb, w2=cout, res=gres if cout % 8 == 0 else None, **kw)
+        fused = O.conv2d(gx, pw2, gb, w2=cout, res=gres if cout % 8 == 0 else None, affine_in=(g(sc), g(sh), E.ACT_SILU), **kw)
+        assert torch.equal(fused, two), f"{name}: fused operand differs from affine_act + conv"
+    else:
+        if cout % 8 == 0:
+            # activation, SFT epilogue, channel-slice views
+            gota = O.conv2d(gx, pw2, gb, w2=cout, act=E.ACT_LEAKY02, out_f32=True, **kw)
+            assert float((gota.double().cpu() - _exact_conv_f64(x, w32, b, k, k, pad, act=E.ACT_LEAKY02)).abs().max()) <= 2e-5 * scale
+            dec, shf = rnd(tuple(want64.shape), 918, torch.float16), rnd(tuple(want64.shape), 919, torch.float16)
+            gots = O.conv2d(gx, pw2, gb, w2=cout, sft=(g(dec), g(shf), 0.7), **kw)
+            wants = dec.double() + 0.7 * (dec.double() * want64 + shf.double())
+            assert float((gots.double().cpu() - wants).abs().max()) <= 2e-3 * max(1.0, float(wants.abs().max()))
+            wide_in = g(rnd((n, h, w_, cin + 16), 920, torch.float16))
+            wide_out = torch.zeros((n, h, w_, cout + 8), dtype=torch.float16, device=DEV)
+            wide_in[..., 8:8 + cin] = gx
+            O.conv2d(wide_in[..., 8:8 + cin], pw2, gb, w2=cout, out=wide_out[..., 8:], **kw)
+            assert torch.equal(wide_out[..., 8:], goth) and float(wide_out[..., :8].abs().max()) == 0.0
+        if cout % 32 == 0 and (h * w_) % 512 == 0:
+            # epilogue GroupNorm statistics of the exact-weight tile (half as many columns per wave)
+            y = O.conv2d(gx, pw2, gb, w2=cout, gn=32, **kw)
+            assert getattr(y, "_pgt_gn", None) is not None
+            gam, bet = g(1.0 + 0.1 * rnd((cout,), 921)), g(0.1 * rnd((cout,), 922))
+            sc1, sh1 = O.groupnorm_affine(y, gam, bet, 32, 1e-6)
+            y2 = y.clone()            # (no statistics attached: the separate pass)
+            sc2, sh2 = O.groupnorm_affine(y2, gam, bet, 32, 1e-6)
+            # epilogue statistics are taken of the fp32 values before the store rounding, the pass reads the rounded tensor
+            assert float((sc1 - sc2).abs().max()) <= 2e-3 * float(sc2.abs().max()) and float((sh1 - sh2).abs().max()) <= 2e-3 * max(1.0, float(sh2.abs().max()))
+    # a launch the library has no exact-weight form for is refused, not silently run on one plane
+    if kind == "v4" and cin % 64 == 0:
+        odd = g(rnd((1, 8, 8, cin + 8), 923, torch.float16))[..., 4:4 + cin]      # operand rows not 16-byte aligned
+        assert not O.w2_ok(odd, cout, cin, k, k, 1, pad)
+        from pgtformer_amd.hip import PgtError
+        with pytest.raises((PgtError, AssertionError)):
+            O.conv2d(odd, pw2, gb, w2=cout, **kw)
+
+
+def test_ring_kernel_banded_bias_with_long_strips():
+    """the ring kernel takes ONE bias vector per strip of R rows, and R grows to 32 / 64 rows once a launch
+    has enough strips (>= 128 frames at 256 x 256 on this chip); with a bias per BAND of the frame (16 bands: 16 rows at 256 x 256)
+    a long strip straddled bands and the later bands got the first band's bias.  The launcher now clamps R to whole bands
+    (ring_legal refuses bias bands that are not whole 4-row strips).  136 frames at 256 x 128: R would be 64, bands are 8 rows."""
+    O = ops()
+    n, h, w_, cin, cout = 136, 256, 128, 64, 64
+    x = rnd((n, h, w_, cin), 930, torch.float16)
+    wt = rnd((cout, 9 * cin), 931, torch.float16, 1.0 / np.sqrt(9 * cin))
+    bands = 32
+    fb = rnd((n * bands, cout), 932, torch.float32, 0.5)
+    kw = dict(kh=3, kw=3, pad=(1, 1, 1, 1))
+    got = O.conv2d(g(x), g(wt), g(fb), kernel=8, **kw)
+    base = O.conv2d(g(x), g(wt), None, kernel=8, out_f32=True, **kw)
+    want = (base.reshape(n * bands, -1, cout) + g(fb)[:, None, :]).reshape(base.shape)
+    err = float((got.float() - want).abs().max())
+    assert err <= 5e-3 * max(1.0, float(want.abs().max())), err
+    # bands that are not whole 4-row strips: the ring kernel is not offered, the launch runs on another kernel with the same result
+    fb2 = rnd((n * 128, cout), 933, torch.float32, 0.5)       # 2-row bands
+    assert not O.ring_covers(g(x), cout, 3, 3, 1, (1, 1, 1, 1), bias=g(fb2))
+
+
 def test_frame_bias_concurrent_streams_need_their_own_counters():
     """The arrival counters of pgt_frame_bias are shared by consecutive launches of ONE stream; launches that run concurrently must
     not share them (found in round 5: in the pure-bf16 mode BiSeNet's compensated convs on the side stream raced with the encoder's,
@@ -939,41 +1079,6 @@ def test_model_with_and_without_epilogue_statistics(monkeypatch):
         check(f"block_gn_on_vs_off_{dtype}", on, off, dtype, 0.5)
 
 
-def test_residual_block_over_frame_groups_is_bit_equal(monkeypatch):
-    """TDResnetBlock over groups of frames (PGT_BLOCK_GROUP_MIB) against the whole-tensor block: the
-    same tiles, the same per-frame biases, the same statistics partials - every stored value equal, for the half / bf16 layers
-    and the split-half ones, with the statistics of the NEXT GroupNorm coming out of the groups' conv2 launches."""
-    import pgtformer_amd.ops as O
-    from pgtformer_amd.modules import rstt_layers as RL
-    torch.manual_seed(11)
-    for cin, cout, hw in ((128, 256, 32), (128, 128, 64)):
-        blk = RL.TDResnetBlock(in_channels=cin, out_channels=cout)
-        nxt = RL.Normalize(cout)
-        for p_ in list(blk.parameters()) + list(nxt.parameters()):
-            torch.nn.init.normal_(p_, std=0.05)
-        x = rnd((7, hw, hw, cin), 231)
-        for dtype in (torch.float16, torch.bfloat16, O.X3):
-            blk.prepare(DEV, dtype)
-            nxt.prepare(DEV, dtype)
-            xd = O.to_x3(g(x)) if dtype == O.X3 else g(x.to(dtype))
-            monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", 0.0)
-            want = blk(xd, gn_next=True)
-            want_n = nxt.run(want)
-            frame_mib = hw * hw * max(cin, cout) * (4 if dtype == O.X3 else 2) / (1 << 20)
-            for per in (1, 3, 4):
-                monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", per * frame_mib)
-                got = blk(xd, gn_next=True)
-                assert (getattr(got, "_pgt_gn", None) is None) == (getattr(want, "_pgt_gn", None) is None)
-                assert torch.equal(got, want), (cin, cout, dtype, per, float((got.float() - want.float()).abs().max()))
-                got_n = nxt.run(got)
-                err = float((got_n.float() - want_n.float()).abs().max())
-                _LOG.append({"name": f"block_groups_{cin}_{cout}_{hw}_{dtype}_per{per}", "max_abs_err_next_groupnorm": err})
-                assert err <= 2e-2 * max(1.0, float(want_n.float().abs().max())), err
-
-
-# ------------------------------------------------------------------------------------------------
-# mean-field compensation of the weight rounding (DESIGN.md section 2.2): sampled channel means, the per-frame bias they give,
-# and the per-frame bias epilogue of every conv / linear kernel
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_sampled_channel_mean_and_mean_field_bias(dtype):
     O = ops()

@@ -224,6 +224,59 @@ def test_overlap_aware_windows_equal_stacked_windows(cpu_model, monkeypatch):
     assert torch.equal(la, lb) and torch.equal(qa, qb)
 
 
+def test_exact_weight_layers_host_logic(cfg, monkeypatch):
+    """DESIGN.md section 2.3 on the CPU emulation: a layer marked for exact weights keeps the two-plane operand (hi | (w - hi) *
+    2048 per 32 output channels, hi + lo / 2048 = w to 2^-21) next to its single-plane one, runs on it where the library has the
+    form for the launch - then WITHOUT compensation - and falls back to the compensated single-plane launch elsewhere; the
+    stage map of the model marks exactly the decoder's 512 x 512 and 32 x 32 stages in the default mode and nothing in the others."""
+    import pgtformer_amd.modules.rstt_layers as R
+    from pgtformer_amd import PGTFormer, ops
+    emu_ops.install(monkeypatch)
+    torch.manual_seed(5)
+    conv = R.Conv2d(128, 64, 3, padding=1)
+    R.mark_exact_weights(conv)
+    R.prepare_tree(conv, torch.device("cpu"), torch.float16)
+    w = conv.weight.detach().float()
+    assert conv.pw2 is not None and tuple(conv.pw2.shape) == (ops.w2_rows(64), 9 * 128) and conv.pw2.dtype == torch.float16
+    back = emu_ops._unpack_w2_weight(conv.pw2, 64).reshape(64, 3, 3, 128).permute(0, 3, 1, 2)
+    assert float((back - w).abs().max()) <= 2.0 ** -20 * float(w.abs().max())
+    assert float((conv.pw.float().reshape(64, 3, 3, 128).permute(0, 3, 1, 2) - w).abs().max()) > 2.0 ** -14 * float(w.abs().max())
+    x = torch.randn(2, 32, 32, 128).half()
+    calls = []
+    real_fb = R._frame_bias
+    monkeypatch.setattr(R, "_frame_bias", lambda *a, **k: calls.append(1) or real_fb(*a, **k))
+    y = conv.run(x).float()
+    assert not calls, "an exact-weight launch asked for the mean-field compensation"
+    want = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w, conv.bias.detach(), padding=1).permute(0, 2, 3, 1)
+    assert float((y - want).abs().max()) <= 1.1 * 2.0 ** -11 * float(want.abs().max())      # the output's own half rounding
+    # a launch without the form (operand rows not 16-byte aligned): single plane + compensation, same layer
+    xo = torch.randn(2, 32, 32, 136).half()[..., 4:132]
+    assert not ops.w2_ok(xo, 64, 128, 3, 3, 1, (1, 1, 1, 1))
+    conv.run(xo)
+    assert calls
+    # unmarked layers, fp32 / bf16 / split layers: no two-plane operand
+    for dt, mark in ((torch.float16, False), (torch.float32, True), (torch.bfloat16, True), (ops.X3, True)):
+        c2 = R.Conv2d(128, 64, 3, padding=1)
+        R.mark_exact_weights(c2, mark)
+        R.prepare_tree(c2, torch.device("cpu"), dt)
+        assert c2.pw2 is None
+    lin = R.Linear(512, 512)
+    R.mark_exact_weights(lin)
+    R.prepare_tree(lin, torch.device("cpu"), torch.float16)
+    t = torch.randn(1024, 512).half()
+    yl = lin.run(t, frames=2).float()
+    wantl = torch.nn.functional.linear(t.float(), lin.weight.detach(), lin.bias.detach())
+    assert float((yl - wantl).abs().max()) <= 1.1 * 2.0 ** -11 * float(wantl.abs().max())
+    # the model's stage map
+    m = PGTFormer(**cfg)
+    mods = m.exact_weight_modules(("512", "32"))
+    names = {n for n, _ in m.named_modules()}
+    got = {n for n, sub in m.named_modules() if any(sub is x_ for x_ in mods)}
+    assert got == {"decoder.up.0", "decoder.conv_out", "decoder.norm_out", "decoder.up.4", "decoder.mid", "decoder.conv_in", "fuse_convs_dict.32"} & names
+    with pytest.raises(ValueError):
+        m.exact_weight_modules(("48",))
+
+
 def test_weight_rounding_compensation_host_logic(monkeypatch):
     """DESIGN.md section 2.2 on the CPU emulation: the defect matrix of a prepared half conv is sum over taps of (W - half(W))
     (also with a folded BatchNorm scale and zero-padded input channels), the per-frame bias it gives puts the frame-constant
@@ -275,29 +328,3 @@ def test_weight_rounding_compensation_host_logic(monkeypatch):
         assert other.pdef is None
 
 
-def test_residual_block_over_frame_groups_matches_whole_tensor(monkeypatch):
-    """TDResnetBlock._forward_chunked (PGT_BLOCK_GROUP_MIB: the block over groups of frames whose maps stay in the Infinity
-    Cache) is the same function as the whole-tensor block: every operation of it is per frame (reference:
-    rstt_layers.py:835-904).  Checked through the CPU emulation of the ops, group sizes that do and do not divide N."""
-    import torch
-    from pgtformer_amd.modules import rstt_layers as RL
-    emu_ops.install(monkeypatch)
-    torch.manual_seed(5)
-    for cin, cout in ((64, 64), (32, 64)):
-        blk = RL.TDResnetBlock(in_channels=cin, out_channels=cout)
-        for p_ in blk.parameters():
-            torch.nn.init.normal_(p_, std=0.05)
-        RL.prepare_tree(blk, "cpu", torch.float32)
-        x = torch.randn(7, 8, 16, cin)
-        monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", 0.0)
-        want = blk(x, gn_next=True)
-        frame_mib = 8 * 16 * max(cin, cout) * 4 / (1 << 20)
-        for per in (1, 2, 3, 7):
-            monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", per * frame_mib)
-            assert RL._chunk_frames(x, max(cin, cout)) == (None if per >= 7 else -(-7 // -(-7 // per)))
-            got = blk(x, gn_next=True)
-            assert torch.allclose(got, want, atol=1e-5, rtol=1e-5), (per, float((got - want).abs().max()))
-        dst = torch.zeros(7, 8, 16, cout + 8)
-        monkeypatch.setattr(RL, "BLOCK_GROUP_MIB", 2 * frame_mib)
-        blk(x, out=dst[..., :cout])
-        assert torch.allclose(dst[..., :cout], want, atol=1e-5, rtol=1e-5) and float(dst[..., cout:].abs().max()) == 0.0

@@ -81,20 +81,35 @@ def test_mfma_utilisation_on_a_synthetic_trace(tmp_path):
     assert abs(m["time_weighted_clock_ghz"] - 2.0) < 1e-9
 
 
-def test_source_sha_tracks_the_kernel_sources(tmp_path, monkeypatch):
-    """the key bench.py compares before quoting a PMC file: changes with any csrc / include source, not with anything else"""
-    import shutil
+def test_binary_stamp_and_source_sha(tmp_path):
+    """the key bench.py compares before quoting a measurement file is the stamp of the BINARY: pgtformer_amd/build.py compiles the
+    sha256 over csrc / include into pgt_version() (\"... src:<sha16>\") and rebuilds by content hash, so a library built from these
+    sources carries exactly build.source_sha16(); the sha changes with any source and with nothing else"""
+    import ctypes
+    from pgtformer_amd import build
     from tools import pmc_traffic
-    root = tmp_path / "r"
-    (root / "tools").mkdir(parents=True)
-    shutil.copytree(os.path.join(REPO, "include"), root / "include")
-    os.makedirs(root / "pgtformer_amd" / "csrc")
-    for fn in ("common.h", "misc.hip"):
-        shutil.copy(os.path.join(REPO, "pgtformer_amd", "csrc", fn), root / "pgtformer_amd" / "csrc" / fn)
-    monkeypatch.setattr(pmc_traffic, "__file__", str(root / "tools" / "pmc_traffic.py"))
-    a = pmc_traffic.source_sha16()
-    (root / "README.md").write_text("x")
-    assert pmc_traffic.source_sha16() == a
-    with open(root / "pgtformer_amd" / "csrc" / "misc.hip", "a") as f:
-        f.write("\n// edit\n")
-    assert pmc_traffic.source_sha16() != a and len(a) == 16
+    lib = build.build(verbose=False)
+    sha = build.source_sha16()
+    assert len(sha) == 16 and build.binary_sha16(lib) == sha == pmc_traffic.source_sha16()
+    import torch  # noqa: F401  (one shared HIP runtime before the .so is loaded)
+    h = ctypes.CDLL(lib)
+    h.pgt_version.restype = ctypes.c_char_p
+    assert h.pgt_version().decode().endswith("src:" + sha)
+    # the source hash follows the sources only
+    csrc, inc = build.CSRC, build.INCLUDE
+    try:
+        build.CSRC, build.INCLUDE = str(tmp_path / "csrc"), str(tmp_path / "include")
+        import shutil
+        shutil.copytree(inc, build.INCLUDE)
+        os.makedirs(build.CSRC)
+        for fn in ("common.h", "misc.hip"):
+            shutil.copy(os.path.join(csrc, fn), os.path.join(build.CSRC, fn))
+        a = build.source_sha16()
+        (tmp_path / "README.md").write_text("x")
+        assert build.source_sha16() == a != sha
+        with open(os.path.join(build.CSRC, "misc.hip"), "a") as f:
+            f.write("\n// edit\n")
+        assert build.source_sha16() != a
+    finally:
+        build.CSRC, build.INCLUDE = csrc, inc
+

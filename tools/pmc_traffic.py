@@ -22,17 +22,13 @@ FAMILY = ("%igemm%_kernel%", "%conv3x3_c64_kernel%", "%conv3x3_c64_x3_kernel%", 
 
 
 def source_sha16():
-    """sha256 (first 16 hex digits) over the sources libpgt_hip.so is built from: csrc/*.{hip,cpp,h,inc} and include/*.h"""
-    import hashlib
+    """identity of the kernels a measurement ran: the source sha compiled into the built libpgt_hip.so (pgtformer_amd.build.
+    binary_sha16: the BINARY's stamp); without a stamped library, the sha of the sources in the tree"""
     import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for d in (os.path.join(root, "pgtformer_amd", "csrc"), os.path.join(root, "include")):
-        for f in sorted(os.listdir(d)):
-            if f.endswith((".hip", ".cpp", ".h", ".inc")):
-                h.update(f.encode())
-                h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pgtformer_amd import build
+    return build.binary_sha16() or build.source_sha16()
 
 
 def per_kernel(db, counter, likes):
