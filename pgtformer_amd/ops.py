@@ -126,10 +126,20 @@ def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False, w2=False):
     return out
 
 
-# Exact-weight layers: the decoder stages whose weight rounding carried the PSNR contract's margin run with
-# two-plane weights (two MFMAs per product, pgt_conv_desc::w2) instead of the mean-field compensation.  PGT_EXACT_W = comma-separated
-# decoder stages ("512,32" default; "" = none: every half layer single-plane + compensated, the round-5 build)
-EXACT_W_STAGES = tuple(t for t in _os.environ.get("PGT_EXACT_W", "512,32").split(",") if t)
+# Exact-weight layers: decoder stages can run with two-plane weights (two MFMAs per product, pgt_conv_desc::w2)
+# instead of the mean-field compensation.  PGT_EXACT_W = comma-separated decoder stages ("512,32", "512,256,128,64,32", ...).
+# DEFAULT: none.  Measured in round 6 (profiles/r6_a_exact_weight_spread.jsonl, r6_b_*): with stages 512 + 32 exact - the ones the
+# oracle ablation of round 5 pointed at - the worst window of the third operating point goes from 9.5e-4 to 1.38e-3 dB, with EVERY
+# decoder stage exact it is 1.03e-3, at -4.3 % frames/s: the residual of that figure is not weight rounding (DESIGN.md section 2.3 has
+# what it is), so the form is an opt-in precision feature, not the default.
+EXACT_W_STAGES = tuple(t for t in _os.environ.get("PGT_EXACT_W", "").split(",") if t)
+
+
+def _w2_gn_ok(hw, cout, groups):
+    """epilogue GroupNorm statistics in the exact-weight form of the phased kernel: whole channel groups per tile of 64 / 128 OUTPUT
+    channels (half the tile's weight rows) and whole 512 / 256-row tiles per image (csrc/igemm.hip)"""
+    wide = w2_rows(cout) > 128
+    return cout % groups == 0 and (128 if wide else 64) % (cout // groups) == 0 and hw % (256 if wide else 512) == 0
 
 
 def w2_ok(x, cout, cin, kh, kw, stride, pad, *, ups=False, act=ACT_NONE, res=None, post_relu=False, sft=None, out=None, out_f32=False,
@@ -478,7 +488,7 @@ def conv2d(x, w, bias=None, *, kh=1, kw=1, stride=1, pad=(0, 0, 0, 0), ups=False
             d.gn_img0, d.gn_nimg = (gn[2], st.n) if len(gn) > 2 else (0, 0)
             assert st.hw == ho * wo and st.c == cout
         elif (USE_EPILOGUE_GN and gn_ok(n, ho * wo, cout, gn, cin, kh) and not out_f32 and not scalar_epi
-              and kernel in (0, 1, 4) and splitk in (0, 1)):
+              and kernel in (0, 1, 4) and splitk in (0, 1) and (w2 is None or _w2_gn_ok(ho * wo, cout, gn))):
             st = GnStats(n, 1, ho * wo, cout, gn, x.device)
         if st is not None:
             d.gn_groups, d.gn_nsub = st.groups, st.nsub
