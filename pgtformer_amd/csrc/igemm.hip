@@ -536,7 +536,6 @@ extern "C" int pgt_conv2d_ws(const pgt_conv_desc* d, const void* x, const void* 
     p.slo = d->shift_lo ? d->shift_lo : d->Cout;
     p.nw = (x3 && d->x3_fold) ? 128 : (d->w2 ? (d->Cout + 31) / 32 * 64 : d->Cout);
     p.w2 = d->w2 ? 1 : 0;
-    p.cb_major = 0;
     PGT_CHECK(!d->w2 || ((f16 || d->dtype == PGT_BF16) && d->splitk <= 1 && !d->ups && !d->out_split && !d->x3_fold && (d->kernel == 0 || d->kernel == 4 || d->kernel == 8)),
               "pgt_conv2d: the exact-weight form (w2) takes PGT_F16 / PGT_BF16 operands, kernel 0, 4 or 8, no split-K, no fused up-sampling");
     p.bias_rows = d->bias_rows;

@@ -25,15 +25,6 @@
 //   * padding taps, rows >= M and columns >= Cout use an out-of-range buffer offset (the DMA then writes zeros); the
 //     per-lane source offset of the current filter tap is recomputed when the tap changes (every Cin/64 K tiles),
 //     which also covers strided and nearest-2x up-sampled inputs; the K-tile channel offset is the scalar soffset.
-//   * K ORDER (round 6): single-plane k x k layers with Cin >= 128 visit K as (64-channel block, tap) instead of (tap, block) -
-//     ConvP::cb_major; the weight matrix keeps its tap-major columns, only the K tile -> (tap, block) map changes.  Why: the
-//     taps of a filter re-read the same input pixels, and between two taps of the tap-major order a CU streams Cin / 64 K
-//     tiles = the FULL channel depth of its pixels; the 32 CUs of an XCD then cycle through (rows in flight) x Cin x 2 B - 4.2 MB
-//     at 256 x 256 x 128 channels with 512-row tiles, more than the 4-MiB L2 next to the output stream: the re-reads came from
-//     the fabric (profiles/r5_v5_pmc_by_kernel.json: 6.6 GB per launch of the 512x128 tile at 4.5 TB/s, 2-3x algorithmic - those
-//     layers were fabric-bound, not MFMA-bound).  Block-major, all k*k taps of one 64-channel slice follow each other: the
-//     working set between re-reads is the slice, 1 / (Cin / 64) of it.  Measured, it pays on the 512-row tile from Cin = 256 up
-//     (+11 .. +14 %) and costs 2-6 % elsewhere (a tap selection per K tile): the launcher sets it there only.
 //
 // Swizzle (swz128) and epilogue as igemm3.hip.  Preconditions: bf16, Cin % 64 == 0, KH*KW <= 30, tensors < 2 GiB.
 #include <atomic>
@@ -203,16 +194,6 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
                 bufdma16(a_sel[h][g], rsrc_x, a_soff, lds0 + buf * STAGE + (g * 128 + h * 64 + wave * 8) * 128);
     };
     auto advance = [&]() {
-        if (!X3 && p.cb_major) {     // block-major K order: next tap of the same 64-channel block, then the next block
-            if (++kx == p.KW) {
-                kx = 0;
-                if (++ky == p.KH) { ky = 0; c0 += 64; }
-            }
-            select_tap(0);
-            select_tap(1);
-            a_soff = c0 * 2;
-            return;
-        }
         if (X3 && ++seg < (p.x3 == 2 ? 2 : 3)) {
             // next plane of the SAME 64-channel block: K order per block is [x_hi | x_lo | x_hi] (weights [w_hi | w_hi | w_lo]),
             // so the second read of the hi plane follows the first by two K tiles and hits the cache.  Folded form (x3 == 2,
@@ -230,17 +211,11 @@ __global__ __launch_bounds__(512) void igemm4_kernel(ConvP p) {
         }
         a_soff = c0 * 2;
     };
-    const int ntaps = p.KH * p.KW;
     auto issue_b = [&](int h, int buf, int kt) {
-        int koff = kt * 128;      // byte offset of K tile kt inside a weight row (tap-major columns)
-        if (!X3 && p.cb_major) {  // K tile kt = (block kt / taps, tap kt % taps) -> column (tap * Cin + 64 block)
-            const int cb = kt / ntaps, tap = kt - cb * ntaps;
-            koff = (tap * p.Cin + cb * 64) * 2;
-        }
 #pragma unroll
         for (int g = 0; g < PB; ++g) {
             const int j = wave + 8 * g;
-            bufdma16(b_off[h][g], rsrc_w, koff, lds0 + buf * STAGE + TILE_A + ((j >> 2) * 64 + h * 32 + (j & 3) * 8) * 128);
+            bufdma16(b_off[h][g], rsrc_w, kt * 128, lds0 + buf * STAGE + TILE_A + ((j >> 2) * 64 + h * 32 + (j & 3) * 8) * 128);
         }
     };
 
@@ -376,11 +351,6 @@ template <int WR, int WC, bool UPS, bool X3 = false, bool GN = false, typename T
     p.ho_shift = pow2 ? __builtin_ctz(p.Ho) : -1;
     p.nbm = (p.M + BM - 1) / BM;
     p.nbn = (p.nw + BN - 1) / BN;
-    static const bool tap_major = [] { const char* e = getenv("PGT_K_ORDER"); return e && e[0] == 't'; }();      // A/B: PGT_K_ORDER=tap
-    // measured (profiles/r6_b_k_order_ab.txt): block-major wins where the 512-row tile meets Cin >= 256 ((48, 256^2, 256 -> 128) 812 -> 902
-    // TFLOP/s, (32, 256^2, 320 -> 128) 869 -> 991) and loses 2-6 % elsewhere (the per-K-tile tap selection): only there
-    static const bool cb_all = [] { const char* e = getenv("PGT_K_ORDER"); return e && e[0] == 'c'; }();                 // A/B: PGT_K_ORDER=cb
-    p.cb_major = (!X3 && !tap_major && p.KH * p.KW > 1 && ((WR == 4 && p.Cin >= 256) || (cb_all && p.Cin >= 128))) ? 1 : 0;
     if (GN) PGT_CHECK(p.gn_hw % BM == 0 && (W2 ? BN / 2 : BN) % p.gn_cpg == 0, "igemm4: GroupNorm statistics need HW %% %d == 0 (HW=%d) and whole groups per tile", BM, p.gn_hw);
     // the attribute is per device and per function: set it once per (device, instantiation), thread-safe
     static std::atomic<unsigned long long> attr_set{0};

@@ -63,7 +63,6 @@ struct ConvP {
     const float* in_scale;
     const float* in_shift;
     int in_act;
-    int cb_major;               // igemm4: visit K as (64-channel block, filter tap) instead of (tap, block) - set by its launcher
     int w2;                     // exact-weight form (pgt_conv_desc::w2): w = per 32 output channels [32 rows w_hi | 32 rows w_lo * 2048], nw rows
 };
 

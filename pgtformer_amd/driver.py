@@ -59,6 +59,8 @@ class WindowRunner:
         if overlap:
             self.win = (torch.arange(batch, dtype=torch.int32)[:, None] + torch.arange(self.t, dtype=torch.int32)[None, :]
                         ).reshape(-1).to(self.dev)
+        from . import ops as _ops
+        self._lane_ids = [_ops.new_lane_id() for _ in range(self.lanes)]      # arrival-counter sets no other runner / model shares
         self.graphs, self.static_ress = [None] * self.lanes, [None] * self.lanes
         self.graph = None
         self._pipe = None
@@ -90,7 +92,7 @@ class WindowRunner:
         kw = {"win": self.win} if self.overlap else {}
         if self.full_tail:
             kw["full_tail"] = True
-        keep, ops.LANE = ops.LANE, lane        # forwards of different lanes run concurrently: own arrival counters (ops.frame_bias)
+        keep, ops.LANE = ops.LANE, self._lane_ids[lane]    # concurrent forwards (lanes, other runners): own arrival counters (ops.frame_bias)
         try:
             return self.model.restore_middle_u8(frames_u8, w=self.w, out=self.static_outs[lane], **kw)
         finally:

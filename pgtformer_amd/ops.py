@@ -728,6 +728,15 @@ BRANCH = 0          # 1 inside the condition branch that PGTFormer forks onto a 
 #                     BiSeNet's convolutions are compensated too, and its frame_bias launches run CONCURRENTLY with the encoder's
 _FB_COUNTERS = {}
 _FB_MAX_FRAMES = 4096
+_LANE_IDS = [0]
+
+
+def new_lane_id():
+    """a process-unique counter-set id for something that launches forwards CONCURRENTLY with others on the same device (every lane
+    of every driver.WindowRunner takes one: two runners, two models or two threads never share arrival counters; lane 0 is the
+    plain eager caller)"""
+    _LANE_IDS[0] += 1
+    return _LANE_IDS[0]
 
 
 def _fb_counters(device, n):
@@ -737,7 +746,8 @@ def _fb_counters(device, n):
         if torch.cuda.is_current_stream_capturing():
             raise hip.PgtError("frame_bias: first use for lane %d / branch %d inside a graph capture (run one eager forward first)" % (LANE, BRANCH))
         c = _FB_COUNTERS[key] = torch.zeros(_FB_MAX_FRAMES, dtype=torch.int32, device=device)
-    assert n <= _FB_MAX_FRAMES
+    if n > _FB_MAX_FRAMES:
+        raise hip.PgtError("frame_bias: %d bias rows in one launch (limit %d): run the batch as chunks" % (n, _FB_MAX_FRAMES))
     return c
 
 

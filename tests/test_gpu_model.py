@@ -406,7 +406,7 @@ def test_psnr_contract_at_a_second_operating_point(tail_models_s1):
     _psnr_contract_at_point(tail_models_s1)
 
 
-def _psnr_contract_at_point(tail_models_s1):
+def _psnr_contract_at_point(tail_models_s1, gate_db=1e-3):
     """the contract at an INDEPENDENT draw of everything it depends on - all 961 tensors from weight seed 1
     (other rounding defects D = W - half(W), other activation ranges for the half decoder), SFT gains re-calibrated on the
     reference for that draw, a decoder tail fitted on a window of another clip (7077 w2) - against REFERENCE fixtures
@@ -417,7 +417,7 @@ def _psnr_contract_at_point(tail_models_s1):
       * |PSNR(build, GT) - PSNR(reference, GT)| <= 1e-3 dB and PSNR(build, reference) >= 75 dB on every window;
       * no half store of the forward sits at the saturation limit (check_range);
     fp32 mode: every code equal, <= 1e-4 dB.
-    (test_psnr_contract_at_a_third_operating_point, last test of this file: the same at weight seed 2.)"""
+    (test_psnr_contract_at_a_third / _fourth_operating_point: the same at weight seeds 2 and 3.)"""
     from pgtformer_amd.synth import make_clip
 
     pt = tail_models_s1["point"]
@@ -446,7 +446,7 @@ def _psnr_contract_at_point(tail_models_s1):
         recs.append(rec)
         assert rec["psnr_ref_vs_gt_db"] >= pt["min_psnr_ref_gt_db"], rec      # (the fitted tail restores: the contract is not about noise)
         assert rec["x3f16"]["differing_tokens"] == 0 and rec["fp32"]["differing_tokens"] == 0, rec
-        assert abs(rec["x3f16"]["dpsnr_db"]) <= 1e-3 and rec["x3f16"]["psnr_build_vs_ref_db"] >= 75.0, rec
+        assert abs(rec["x3f16"]["dpsnr_db"]) <= gate_db and rec["x3f16"]["psnr_build_vs_ref_db"] >= 75.0, rec
         assert abs(rec["fp32"]["dpsnr_db"]) <= 1e-4 and rec["fp32"]["psnr_build_vs_ref_db"] >= 90.0, rec
     m = tail_models_s1["x3f16"]
     fr = torch.from_numpy(clips[pt["train"][0]][0][:4]).to(DEV)
@@ -454,6 +454,63 @@ def _psnr_contract_at_point(tail_models_s1):
     _LOG[f"operating_point_{tail_models_s1['seed'] + 1}/x3f16_vs_reference"] = {"windows": recs, "tensors_range_checked": m.last_range_launches,
                                                                                 "saturating": [list(map(str, r)) for r in bad]}
     assert m.last_range_launches > 300 and bad == [], bad
+
+
+def test_psnr_contract_at_a_third_operating_point(cfg, manifest):
+    """The contract at a THIRD independent draw (tests/golden/r5_scheme.py POINTS[2]: weight seed 2, SFT gains re-calibrated on the
+    reference for it, tail fitted on clip 10077 w2; 8 windows of clips 10077 / 11077 / 12077, r5_golden_s2.npz), whose fixtures were
+    generated AFTER every constant of the build - bands of the mean field, sample sizes - was fixed: a held-out point.  Same asserts
+    as the second point: every code equal, <= 1e-3 dB and >= 75 dB from the reference in the default mode, <= 1e-4 dB in fp32,
+    nothing saturated.  Measured: worst window 9.5e-4 dB (clip 11077 w3) - inside the contract without headroom.  Round 6 found what
+    that window is made of: this draw's code prediction COLLAPSES (1 - 4 distinct codes per window, >= 98.9 %
+    of the tokens on one code), the decoder's input is a constant field per channel, the half decoder's rounding errors are then
+    spatially coherent (a third of the error of a 32 x 32 feature map is a per-channel constant) and the reference's own restoration
+    error on that window is a per-channel DC offset (+0.048 in R): a mean error of 1.2e-5 of the build's R output IS 1e-3 dB.  Exact
+    weights in every decoder stage leave the window at 1.03e-3 (profiles/r6_b_all_exact_spread.jsonl): not a weight-rounding effect."""
+    _psnr_contract_at_point(_point_models(cfg, manifest, 2))
+
+
+def test_psnr_contract_at_a_fourth_operating_point(cfg, manifest):
+    """A FOURTH independent draw (POINTS[3]: weight seed 3, gains re-calibrated x0.91 .. x1.26, tail fitted on clip 13077 w2; 8
+    windows of clips 13077 / 14077 / 15077, tests/golden/r6_golden_s3.npz - fixtures from the reference alone; the build ran on them
+    for the first time with every constant frozen, profiles/r6_d_spread.jsonl).  This draw's code prediction does NOT collapse (10 -
+    13 distinct codes per window, 42 - 64 % of the tokens on the most frequent one; PSNR(reference, GT) 26.1 - 30.9 dB; the
+    reference's smallest top-2 margins 3.3e-6 / 5.7e-6): every code equal, 81.5 - 81.7 dB from the reference, worst window 2.6e-4 dB -
+    asserted <= 5e-4.  The regime of a trained checkpoint (hundreds of distinct codes) is further on this side."""
+    _psnr_contract_at_point(_point_models(cfg, manifest, 3), gate_db=5e-4)
+
+
+def test_graph_replay_after_the_allocator_returned_memory_to_the_driver(models):
+    """a graph replay right after torch.cuda.empty_cache() died ONCE inside the HIP runtime in a long test
+    process (the driver then made that release opt-in).  What a captured graph of this build points at: its lane's static input /
+    output (held by the runner), tensors allocated DURING capture (the graph's private pool: the allocator never returns the blocks
+    of a live graph) and a few tensors created in the eager warm-up that the modules / ops keep for good (ops._FB_COUNTERS, the
+    frame-index tables of the fusion blocks, the grouped sub-pixel defects).  This test drives exactly the incident's sequence - capture
+    two lanes, eager range-check pass, empty_cache(), replay - 10 times, with a second runner created and destroyed in between (its
+    pools become releasable), and checks the replayed frames bit for bit."""
+    import gc
+
+    from pgtformer_amd.driver import WindowRunner
+    from pgtformer_amd.synth import make_clip
+
+    m = models["x3f16"]
+    lq, _ = make_clip(6, 512, seed=77)
+    frames = torch.from_numpy(lq).to(DEV)
+    r = WindowRunner(m, 1.0, True, 512, 512, batch=4, lanes=2, check_range=True)
+    want = r.run(frames).clone()
+    for i in range(10):
+        other = WindowRunner(m, 1.0, True, 512, 512, batch=2, lanes=1, check_range=False)
+        other.run(frames[:4])
+        del other
+        gc.collect()
+        bad = m.check_range(frames, w=1.0, win=r.win)          # the eager pass of the incident
+        assert bad == []
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        got = r.run(frames)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"replay {i} after empty_cache() differs"
+    _LOG["graph_replay_after_empty_cache"] = {"replays": 10, "bit_equal": True}
 
 
 def test_whole_model_pure_bf16_report(models, golden_window):
@@ -876,13 +933,3 @@ def test_exported_program_replays_bit_equal_from_python_and_from_c(models, prec,
     _LOG[f"exported_program/{prec}"] = {"calls": info["calls"], "persistent_mb": round(info["persistent_bytes"] / 1e6, 1),
                                         "workspace_mb": round(info["workspace_bytes"] / 1e6, 1), "c_host_stdout": r.stdout.strip().splitlines()[-3:]}
     assert torch.equal(c_out, want.cpu()), int((c_out.int() - want.cpu().int()).abs().max())
-
-
-def test_psnr_contract_at_a_third_operating_point(cfg, manifest):
-    """The contract at a THIRD independent draw (tests/golden/r5_scheme.py POINTS[2]: weight seed 2, SFT gains re-calibrated on the
-    reference for it, tail fitted on clip 10077 w2; 8 windows of clips 10077 / 11077 / 12077, r5_golden_s2.npz), whose fixtures were
-    generated AFTER every constant of the build - bands of the mean field, sample sizes - was fixed: a held-out point.  Same asserts
-    as the second point: every code equal, <= 1e-3 dB and >= 75 dB from the reference in the default mode (measured: worst window
-    9.5e-4 dB, clip 11077 w3 - inside the contract without headroom), <= 1e-4 dB in fp32, nothing saturated.
-    (Last in the file: the tests that replay HIP graphs run before it, in the order they always ran.)"""
-    _psnr_contract_at_point(_point_models(cfg, manifest, 2))

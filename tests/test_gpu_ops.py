@@ -745,7 +745,7 @@ def test_conv2d_exact_weights(case):
             wide_in[..., 8:8 + cin] = gx
             O.conv2d(wide_in[..., 8:8 + cin], pw2, gb, w2=cout, out=wide_out[..., 8:], **kw)
             assert torch.equal(wide_out[..., 8:], goth) and float(wide_out[..., :8].abs().max()) == 0.0
-        if cout % 32 == 0 and O._w2_gn_ok(h * w_, cout, 32):
+        if cout % 32 == 0 and O._w2_gn_ok(h * w_, cout, 32) and O.gn_ok(n, h * w_, cout, 32, cin, k):
             # epilogue GroupNorm statistics of the exact-weight tile (half as many columns per wave)
             y = O.conv2d(gx, pw2, gb, w2=cout, gn=32, **kw)
             assert getattr(y, "_pgt_gn", None) is not None
