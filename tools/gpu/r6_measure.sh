@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-5 measurement pass on the GPU box: kernel trace (+ the traced conv / linear family json bench.py quotes), PMC traffic
+# Round-6 measurement pass (the round-5 pass with the binary stamp: lib_sha16 = the source sha compiled into the loaded library) on the GPU box: kernel trace (+ the traced conv / linear family json bench.py quotes), PMC traffic
 # (first: the bench line then quotes it), MFMA utilisation per kernel, the rocprofv3 sweep of BASELINE config 5, bench lines
-# (default, bf16-decoder mode, configs[2] at N=1).    usage: bash tools/gpu/r5_measure.sh <tag>      (writes gpurun_out/<tag>_*)
+# (default, bf16-decoder mode, configs[2] at N=1).    usage: bash tools/gpu/r6_measure.sh <tag>      (writes gpurun_out/<tag>_*)
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
