@@ -113,7 +113,10 @@ extern "C" int pgt_program_load(const char* path, pgt_program** out) {
     if (!rd(f, &pool_bytes, 8) || pool_bytes > (1ull << 30)) return fail("bad descriptor pool");
     pr->pool.resize(pool_bytes);
     if (pool_bytes && !rd(f, pr->pool.data(), pool_bytes)) return fail("truncated descriptor pool");
-    // every argument is checked once here, so that pgt_program_run cannot step outside the regions
+    // every argument record is checked once here: descriptor size (another library version), and the START of every pointer against its
+    // region.  The EXTENT a call touches follows from the integer arguments and descriptors the writer recorded and is the called
+    // function's business (its own argument checks): the loader guards against truncation and version skew, not against a hostile
+    // file - pgtformer_amd/export.py only keeps a file whose replay reproduced the recorded frames bit for bit
     for (const ArgRec& r : pr->args) {
         if (r.kind == K_DESC && (r.aux != sizeof(pgt_conv_desc) || r.value > pool_bytes || pool_bytes - r.value < r.aux || r.value % 8 != 0))
             return fail("descriptor of another library version");

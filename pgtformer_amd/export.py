@@ -21,6 +21,7 @@ A program is specific to what was recorded: the checkpoint, the precision mode, 
 """
 import ctypes as C
 import gc
+import os
 import struct
 
 import torch
@@ -201,7 +202,7 @@ def write_program(path, tape, playout, work_bytes, in_bytes, out_bytes, meta=b""
 
 
 @torch.no_grad()
-def export_program(model, n_windows, path, w=1.0, height=512, width=512, overlap=True, full_tail=False):
+def export_program(model, n_windows, path, w=1.0, height=512, width=512, overlap=True, full_tail=False, verify=True):
     """Record `model.restore_middle_u8` on `n_windows` sliding 3-frame windows (uint8 frames in -> restored uint8 middle frames out,
     reference inference.py:12-19) and write the program file.  Returns a dict with the sizes and the example input / output
     (device tensors) of the recorded forward - what pgt_program_run must reproduce bit for bit."""
@@ -232,6 +233,14 @@ def export_program(model, n_windows, path, w=1.0, height=512, width=512, overlap
     meta = (f"precision={getattr(model, 'precision', '?')} windows={n_windows} frames_in={n_in} size={height}x{width} overlap={int(overlap)} "
             f"full_tail={int(full_tail)} w={w} lib={hip.lib().pgt_version().decode()}").encode()
     persist_bytes = write_program(path, tape, playout, work_bytes, frames.numel(), out.numel(), meta, storages=persistent)
+    if verify:
+        # the tape holds C-ABI calls only: an operation of the forward that did not go through the library (a torch-native op) would be
+        # missing from the replay - the file is only kept if the library reproduces the recorded frames bit for bit
+        got = run_program(path, frames).reshape(want.shape)
+        if not torch.equal(got, want):
+            os.remove(path)
+            raise hip.PgtError("export: the replayed program differs from the recorded forward (%d of %d bytes): an operation outside the "
+                               "C-ABI took part in it" % (int((got != want).sum()), want.numel()))
     return {"calls": len(tape), "persistent_bytes": persist_bytes, "workspace_bytes": work_bytes, "input": frames, "output": want,
             "input_bytes": frames.numel(), "output_bytes": out.numel()}
 
