@@ -52,6 +52,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // take three MFMAs per product (hi*hi + lo*hi + hi*lo), P is split in registers after the exp.
 // (P on its hi plane only in P.V - 5 products per key tile - was measured in round 5 and rejected: logits error 1.7e-5 -> 3.5e-5,
 // profiles/r5_mha_p_single_plane_study.jsonl; the switch is gone.)
+// (183 VGPRs at NW = 8: one workgroup per CU.  Forcing 128 registers for two workgroups per CU spills 244 bytes per lane into the tile
+// loop and runs 2.1x slower - 4448 against 2106 us at 32 windows, profiles/r6_g_mha_occupancy_experiment.jsonl)
 template <bool X3, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void mha_mfma_kernel(const uint16_t* __restrict__ q, int ldq, const uint16_t* __restrict__ k,
                                                        int ldk, const uint16_t* __restrict__ v, int ldv,
