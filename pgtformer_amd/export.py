@@ -79,58 +79,76 @@ def record(fn, device):
         pgtformer_arch.SIDE_STREAM = keep_side
 
 
+def pack_by_liveness(bufs):
+    """bufs: [(bytes, first, last)] - buffers live over the closed call ranges [first, last] -> ([offset per buffer], total bytes) such
+    that buffers whose ranges intersect do not overlap in space.  Largest first, each at the lowest ALIGN-ed offset free of the
+    already placed buffers it is ever live with (offline storage allocation by first fit: a few hundred buffers, quadratic is fine)."""
+    order = sorted(range(len(bufs)), key=lambda i: (-bufs[i][0], bufs[i][1]))
+    off = [0] * len(bufs)
+    placed = []
+    total = 0
+    for i in order:
+        nb, a, b = bufs[i]
+        size = _align(max(1, nb))
+        busy = sorted((off[j], off[j] + _align(max(1, bufs[j][0]))) for j in placed if not (bufs[j][2] < a or b < bufs[j][1]))
+        o = 0
+        for lo, hi in busy:
+            if o + size <= lo:
+                break
+            o = max(o, hi)
+        off[i] = o
+        placed.append(i)
+        total = max(total, o + size)
+    return off, total
+
+
 def build_program(calls, persistent, in_t, out_t):
     """calls: record()'s list; persistent: {storage address: bytes} of everything that outlives the forward; in_t / out_t: the
     input / output tensors.  Returns (tape records, persistent layout {addr: (offset, bytes)}, workspace bytes)."""
     in_lo, in_hi = in_t.data_ptr(), in_t.data_ptr() + in_t.numel() * in_t.element_size()
     out_lo, out_hi = out_t.data_ptr(), out_t.data_ptr() + out_t.numel() * out_t.element_size()
     names = {n: i for i, n in enumerate(tape_functions())}
-    used_persist, temps = {}, []
-    # pass 1: classify every pointer
+    used_persist, temps = {}, {}
+    # pass 1: classify every pointer; a temporary = one storage (base, bytes) with the first and last call that touches it
+    idx = -1
     for name, args in calls:
         if name in QUERIES:
             continue
+        idx += 1
         assert name in names, f"{name}: not a tape function"
         for a in args[:-1]:
             if a[0] != "ptr" or a[1] == 0:
                 continue
-            _, v, base, nb = a
+            v, base, nb = a[1], a[2], a[3]
             if in_lo <= v < in_hi or out_lo <= v < out_hi:
                 continue
             assert base is not None, f"{name}: pointer {v:#x} was not handed out by ops._p (cannot be placed)"
             if base in persistent:
                 used_persist[base] = max(persistent[base][0], nb)
             else:
-                temps.append((base, base + nb))
-    # merged address ranges of the temporaries
-    temps.sort()
-    merged = []
-    for lo, hi in temps:
-        if merged and lo <= merged[-1][1]:
-            merged[-1][1] = max(merged[-1][1], hi)
-        else:
-            merged.append([lo, hi])
-    woff, off = [], 0
-    for lo, hi in merged:
-        woff.append(off)
-        off += _align(hi - lo)
-    work_bytes = off
+                # (storage address, bytes, storage object): a block the allocator hands out twice during the forward is two temporaries
+                t = temps.setdefault((base, nb, a[4] if len(a) > 4 else 0), [idx, idx])
+                t[1] = idx
+    # the recorded forward ran on ONE stream in tape order: two temporaries whose [first, last] call ranges do not intersect are
+    # never live together and may share bytes (the torch allocator's address ranges - what the tape used to keep - are its whole
+    # high-water footprint: 2.0 GB for two windows in the default mode; packed by liveness: what is live at the worst moment)
+    keys = list(temps)
+    woff, work_bytes = pack_by_liveness([(k[1], temps[k][0], temps[k][1]) for k in keys])
+    woff = dict(zip(keys, woff))
     playout, off = {}, 0
     for base in sorted(used_persist):
         playout[base] = (off, used_persist[base])
         off += _align(used_persist[base])
 
-    def place(v, base):
+    def place(v, base, nb, sid=0):
         if in_lo <= v < in_hi:
             return R_IN, v - in_lo
         if out_lo <= v < out_hi:
             return R_OUT, v - out_lo
         if base in playout:
             return R_PERSIST, playout[base][0] + (v - base)
-        import bisect
-        i = bisect.bisect_right([m[0] for m in merged], v) - 1
-        assert i >= 0 and merged[i][0] <= v < merged[i][1], hex(v)
-        return R_WORK, woff[i] + (v - merged[i][0])
+        assert base <= v < base + nb, hex(v)
+        return R_WORK, woff[(base, nb, sid)] + (v - base)
 
     tape = []
     for name, args in calls:
@@ -148,7 +166,7 @@ def build_program(calls, persistent, in_t, out_t):
                 if a[1] == 0:
                     recs.append((K_NULL, 0, 0))
                 else:
-                    region, o = place(a[1], a[2])
+                    region, o = place(a[1], a[2], a[3], a[4] if len(a) > 4 else 0)
                     recs.append((K_PTR, region, o))
             elif ty is hip.f32:
                 recs.append((K_F32, 0, struct.unpack("<I", struct.pack("<f", float(a[1])))[0]))

@@ -118,7 +118,7 @@ class PgtError(RuntimeError):
 # ---- call tracing (pgtformer_amd.export: the launch schedule of a forward as a tape a non-Python host replays) ------------------
 # TRACE = None, or a list that receives (function name, [argument objects as passed]) for every call made through lib().
 TRACE = None
-TRACE_TENSORS = None       # {data_ptr: (storage base address, storage bytes)} of the tensors ops._p handed out while tracing
+TRACE_TENSORS = None       # {data_ptr: (storage base address, storage bytes, storage object id)} of the tensors ops._p handed out while tracing
 
 
 class _TracedLib:
@@ -136,7 +136,7 @@ class _TracedLib:
                 for a in args:      # pointer arguments are resolved to their storage NOW: the allocator may hand the address out again later
                     if isinstance(a, C.c_void_p):
                         v = a.value or 0
-                        rec.append(("ptr", v) + tuple(TRACE_TENSORS.get(v, (None, None))))
+                        rec.append(("ptr", v) + tuple(TRACE_TENSORS.get(v, (None, None, 0))))
                     elif a is None:
                         rec.append(("ptr", 0, None, None))
                     elif hasattr(a, "_obj"):           # C.byref(struct)

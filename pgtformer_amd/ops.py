@@ -270,7 +270,8 @@ def _p(t):
         return None
     if hip.TRACE_TENSORS is not None:      # export: which storage a pointer argument belongs to (pgtformer_amd.export)
         st = t.untyped_storage()
-        hip.TRACE_TENSORS[t.data_ptr()] = (st.data_ptr(), st.nbytes())
+        # (the storage object's address tells two tensors apart that the allocator placed at the same address one after the other)
+        hip.TRACE_TENSORS[t.data_ptr()] = (st.data_ptr(), st.nbytes(), st._cdata)
     return C.c_void_p(_dev(t).data_ptr())
 
 

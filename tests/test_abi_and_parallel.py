@@ -218,19 +218,37 @@ def test_program_dispatch_table_is_current_and_tape_placement():
     inp, out = T(0x1000, 100), T(0x2000, 50)
     persistent = {0x9000: (64, None)}
     P = lambda v, base=None, nb=None: ("ptr", v, base, nb)      # noqa: E731
+    # temporaries: A (0x5000, 300 B) written by call 0 and read again by call 3; B (0x5100, 64 B: the allocator re-used part of a freed
+    # block - its address range overlaps A's, its life does not matter for that) live in call 1 only; C (0x7000, 16 B) in call 3
     calls = [("pgt_zero2d", [P(0x5000, 0x5000, 300), ("val", 3), ("val", 100), ("val", 1), P(0)]),
              ("pgt_version", []),
              ("pgt_copy2d", [("val", 0), P(0x1010), ("val", 8), ("val", 8), P(0x5100, 0x5100, 64), ("val", 8), ("val", 4), ("val", 8), P(0)]),
              ("pgt_copy2d", [("val", 0), P(0x9020, 0x9000, 64), ("val", 8), ("val", 8), P(0x2008), ("val", 8), ("val", 4), ("val", 8), P(0)]),
-             ("pgt_zero2d", [P(0x7000, 0x7000, 16), ("val", 1), ("val", 16), ("val", 1), P(0)])]
+             ("pgt_copy2d", [("val", 0), P(0x5010, 0x5000, 300), ("val", 8), ("val", 8), P(0x7000, 0x7000, 16), ("val", 8), ("val", 2), ("val", 8), P(0)])]
     tape, playout, work = export.build_program(calls, persistent, inp, out)
     assert len(tape) == 4 and playout == {0x9000: (0, 64)}
-    assert work == 512 + 256                                   # [0x5000, 0x512c) merged with [0x5100, 0x5140) -> 300 B -> 512; 16 B -> 256
+    # packed by liveness (round 6): A is live over calls 0..3, so B and C sit behind it - and share their bytes with each other
+    assert work == 512 + 256
     k = export
     assert tape[0][1][0] == (k.K_PTR, k.R_WORK, 0) and tape[0][1][-1] == (k.K_STREAM, 0, 0)
-    assert tape[1][1][1] == (k.K_PTR, k.R_IN, 0x10) and tape[1][1][4] == (k.K_PTR, k.R_WORK, 0x100)
+    assert tape[1][1][1] == (k.K_PTR, k.R_IN, 0x10) and tape[1][1][4] == (k.K_PTR, k.R_WORK, 512)
     assert tape[2][1][1] == (k.K_PTR, k.R_PERSIST, 0x20) and tape[2][1][4] == (k.K_PTR, k.R_OUT, 8)
-    assert tape[3][1][0] == (k.K_PTR, k.R_WORK, 512)
+    assert tape[3][1][1] == (k.K_PTR, k.R_WORK, 0x10) and tape[3][1][4] == (k.K_PTR, k.R_WORK, 512)
+    # the packer alone: buffers that are ever live together never share bytes, the total stays near the liveness bound
+    import random
+    rng = random.Random(1)
+    bufs = []
+    for _ in range(300):
+        a = rng.randint(0, 400)
+        bufs.append((rng.randint(1, 1 << 20), a, a + rng.randint(0, 40)))
+    off, total = export.pack_by_liveness(bufs)
+    al = lambda n: (n + export.ALIGN - 1) // export.ALIGN * export.ALIGN      # noqa: E731
+    for i in range(len(bufs)):
+        for j in range(i):
+            if not (bufs[j][2] < bufs[i][1] or bufs[i][2] < bufs[j][1]):
+                assert off[i] + al(bufs[i][0]) <= off[j] or off[j] + al(bufs[j][0]) <= off[i], (i, j)
+    peak = max(sum(al(b[0]) for b in bufs if b[1] <= t <= b[2]) for t in range(450))
+    assert peak <= total <= 1.15 * peak and total < 0.2 * sum(al(b[0]) for b in bufs)
     assert torch is not None
 
 
