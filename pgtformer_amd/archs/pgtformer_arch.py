@@ -282,7 +282,7 @@ class Fuse_sft_block(HipModule):
         # scale.0 and shift.0 read the same tensor: one conv with the two filter banks stacked on Cout
         wss = torch.cat([self.scale[0].weight.detach(), self.shift[0].weight.detach()], 0)
         self.w_ss0 = _pack_matrix(wss, device, dtype)
-        self.d_ss0 = _defect_t(wss, self.w_ss0) if _wants_wcomp(dtype) else None
+        self.d_ss0 = _defect_t(wss, self.w_ss0) if _wants_wcomp(dtype, self) else None
         # exact-weight block: two-plane operands of the stacked scale.0 | shift.0 conv and of the temporal mix
         exact = _exact(self, dtype, self.in_ch)
         self.w_ss0_2 = _pack_matrix(wss, device, dtype, w2=True) if exact else None
@@ -306,7 +306,7 @@ class Fuse_sft_block(HipModule):
                 wm = torch.stack(taps, 1).reshape(tcc, -1)
                 self.w_mix.append(_pack_matrix(wm, device, dtype))     # K-major (tcc, T*2C)
                 # every tap reads its own frame of the window: the defect keeps one row per (frame, channel)
-                self.d_mix.append(_defect_t(wm, self.w_mix[-1]) if _wants_wcomp(dtype) else None)
+                self.d_mix.append(_defect_t(wm, self.w_mix[-1]) if _wants_wcomp(dtype, self) else None)
                 self.w_mix2.append(_pack_matrix(wm, device, dtype, w2=True) if exact and (2 * c) % 64 == 0 else None)
                 self.b_mix.append(_f32(w1 @ (rows @ bcat + b0[to * tcc:(to + 1) * tcc]) + b1, device))
 

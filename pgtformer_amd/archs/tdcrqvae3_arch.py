@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..modules.rstt_layers import (Conv2d, EncoderLayer, HipModule, Normalize, TDResnetBlock, _defect_t, _exact, _is_x3, _pack_matrix,
-                                    _wants_wcomp, mark_exact_weights, prepare_tree)
+                                    _wants_wcomp, mark_exact_weights, mark_uncompensated, prepare_tree)
 from ..ops import ACT_SILU, X3
 from ..config import DEFAULT_PRECISION
 from ..registry import ARCH_REGISTRY
@@ -50,7 +50,7 @@ class Upsample(HipModule):
                 w2 = torch.stack([torch.stack([sum(w[:, :, ky, kx] for ky in self._ROWS[py][a] for kx in self._ROWS[px][b])
                                                for b in (0, 1)], -1) for a in (0, 1)], -2)      # (Cout, Cin, 2, 2)
                 self.sub_w[(py, px)] = _pack_matrix(w2, device, dtype)
-                self.sub_def[(py, px)] = _defect_t(w2, self.sub_w[(py, px)]) if _wants_wcomp(dtype) else None
+                self.sub_def[(py, px)] = _defect_t(w2, self.sub_w[(py, px)]) if _wants_wcomp(dtype, self) else None
                 if exact:
                     self.sub_w2[(py, px)] = _pack_matrix(w2, device, dtype, w2=True)
 
@@ -636,9 +636,15 @@ class TDCRQVAE3(HubMixin, HipModule):
         self.dev = torch.device(device)
         # exact-weight stages of the half decoder: marked before the repack; other modes: no layer is marked
         mark_exact_weights(self, False)
+        mark_uncompensated(self, False)
         if self.dec_dt == torch.float16:
             for mod in self.exact_weight_modules(ops.EXACT_W_STAGES):
                 mark_exact_weights(mod, True)
+        if ops.WCOMP_STAGES is not None:      # compensation only in the named decoder stages
+            for st in self.DECODER_STAGES:
+                if st not in ops.WCOMP_STAGES:
+                    for mod in self.exact_weight_modules((st,)):
+                        mark_uncompensated(mod, True)
         for name, child in self.named_children():
             if name not in self.ENC_SIDE:
                 prepare_tree(child, self.dev, self.dec_dt)

@@ -78,9 +78,16 @@ def _exact(m, dtype, k_channels):
     return bool(getattr(m, "exact_w", False)) and dtype == torch.float16 and k_channels % 64 == 0
 
 
-def _wants_wcomp(dtype):
-    """single-plane 16-bit operands (half / bf16 layers): their weight rounding is compensated to first order"""
-    return USE_WCOMP and dtype in (torch.float16, torch.bfloat16)
+def _wants_wcomp(dtype, module=None):
+    """single-plane 16-bit operands (half / bf16 layers): their weight rounding is compensated to first order - unless the module
+    belongs to a decoder stage the compensation is switched off for (mark_uncompensated; PGT_WCOMP_STAGES)"""
+    return USE_WCOMP and dtype in (torch.float16, torch.bfloat16) and not getattr(module, "no_wcomp", False)
+
+
+def mark_uncompensated(m, flag=True):
+    """no mean-field compensation for the layers of the module tree `m` (call before prepare())"""
+    for sub in m.modules():
+        sub.no_wcomp = bool(flag)
 
 
 def _defect_t(w, pw, scale=None, sum_taps=True):
@@ -145,7 +152,7 @@ class Conv2d(nn.Conv2d, HipModule):
         cin_k = self._fold_cin = cpad if (cpad is not None and cpad > cin) else cin
         self.pw = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale)
         self.pb = b
-        self.pdef = _defect_t(self.weight, self.pw, scale=scale) if _wants_wcomp(dtype) else None
+        self.pdef = _defect_t(self.weight, self.pw, scale=scale) if _wants_wcomp(dtype, self) else None
         # exact-weight layers keep the two-plane operand as well; run() takes it wherever the library has the form for the launch
         self.pw2 = _pack_matrix(self.weight, device, dtype, cin_pad=cin_k, scale=scale, w2=True) if _exact(self, dtype, cin_k) else None
         # split-half layers with 64 output channels: the folded form fills the 128-column tile (pgt_conv_desc.x3_fold)
@@ -193,7 +200,7 @@ class Linear(nn.Linear, HipModule):
     def _pack(self, device, dtype):
         self.pw = _pack_matrix(self.weight, device, dtype)
         self.pb = _f32(self.bias, device)
-        self.pdef = _defect_t(self.weight, self.pw) if _wants_wcomp(dtype) else None
+        self.pdef = _defect_t(self.weight, self.pw) if _wants_wcomp(dtype, self) else None
         self.pw2 = _pack_matrix(self.weight, device, dtype, w2=True) if _exact(self, dtype, self.in_features) and self.out_features % 8 == 0 else None
 
     def run(self, x, frames=None, **kw):
@@ -305,7 +312,7 @@ class WindowAttention3D(HipModule):
         # one fused (3C,C) projection [q | k | v]; dense per-head bias gathered once from the table
         wcat = torch.cat([self.q.weight.detach(), self.kv.weight.detach()], 0)
         self.w_qkv = _pack_matrix(wcat, device, dtype)
-        self.d_qkv = _defect_t(wcat, self.w_qkv) if _wants_wcomp(dtype) else None
+        self.d_qkv = _defect_t(wcat, self.w_qkv) if _wants_wcomp(dtype, self) else None
         self.w_qkv2 = _pack_matrix(wcat, device, dtype, w2=True) if _exact(self, dtype, self.dim) else None
         if self.q.bias is not None:
             self.b_qkv = _f32(torch.cat([self.q.bias.detach(), self.kv.bias.detach()], 0), device)
@@ -349,12 +356,12 @@ class VSTSREncoderTransformerBlock(HipModule):
             w1, self.f_b1 = ops.fold_layernorm(f32(m.fc1.weight), f32(self.norm2.weight), f32(self.norm2.bias), f32(m.fc1.bias))
             self.f_b2 = f32(m.fc2.bias)
         if dtype == torch.float16:
-            self.f_dqkv = _defect_t(wq, self.f_wqkv) if _wants_wcomp(dtype) else None
+            self.f_dqkv = _defect_t(wq, self.f_wqkv) if _wants_wcomp(dtype, self) else None
             self.f_w3 = torch.cat([_pack_matrix(f32(a.proj.weight), device, dtype), _pack_matrix(w1, device, dtype),
                                    _pack_matrix(f32(m.fc2.weight), device, dtype)], 0).contiguous()
             self.f_bp = f32(a.proj.bias)
             self.f_dproj = self.f_dfc1 = self.f_dfc2 = None
-            if _wants_wcomp(dtype):
+            if _wants_wcomp(dtype, self):
                 d = self.dim
                 self.f_dproj = _defect_t(a.proj.weight, self.f_w3[:d])
                 self.f_dfc1 = _defect_t(w1, self.f_w3[d:2 * d])

@@ -132,6 +132,8 @@ def pack_conv_weight(w, dtype, cin_pad=None, scale=None, fold=False, w2=False):
 # oracle ablation of round 5 pointed at - the worst window of the third operating point goes from 9.5e-4 to 1.38e-3 dB, with EVERY
 # decoder stage exact it is 1.03e-3, at -4.3 % frames/s: the residual of that figure is not weight rounding (DESIGN.md section 2.3 has
 # what it is), so the form is an opt-in precision feature, not the default.
+# PGT_WCOMP_STAGES = decoder stages whose layers keep the mean-field compensation (unset: all of them)
+WCOMP_STAGES = (tuple(t for t in _os.environ["PGT_WCOMP_STAGES"].split(",") if t) if "PGT_WCOMP_STAGES" in _os.environ else None)
 EXACT_W_STAGES = tuple(t for t in _os.environ.get("PGT_EXACT_W", "").split(",") if t)
 
 
