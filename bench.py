@@ -528,7 +528,10 @@ def main():
            "data": "synthetic",
            "config": {"workload": "pgtformer-base, 3-frame 512x512 window -> 1 restored frame, synthetic degraded "
                                   "VFHQ-shape clip, random-init weights (BASELINE.json configs[1])",
-                      "precision": args.precision, "frames_per_step": B, "frames_per_rank": n_local, "hip_graph": not args.no_graph,
+                      "precision": args.precision, "exact_weight_stages": list(__import__("pgtformer_amd.ops", fromlist=["x"]).EXACT_W_STAGES),
+                      "compensated_stages": ("all" if __import__("pgtformer_amd.ops", fromlist=["x"]).WCOMP_STAGES is None
+                                             else list(__import__("pgtformer_amd.ops", fromlist=["x"]).WCOMP_STAGES)),
+                      "frames_per_step": B, "frames_per_rank": n_local, "hip_graph": not args.no_graph,
                       "windows_per_forward": B, "per_frame_reuse": not args.no_overlap,
                       "steps_in_flight": runner.lanes,
                       "decoder_tail": ("all 3 frames of every window" if args.full_tail else
