@@ -29,7 +29,7 @@ REF = "/root/reference"
 import make_golden_r3 as R3                                            # fit_tail, tail_forward, train_tail, psnr, rms  # noqa: E402
 from tests.golden import r5_scheme as S5                               # noqa: E402
 
-POINT = int(os.environ.get("R5_POINT", "1"))                         # weight seed of the operating point (r5_scheme.POINTS): 1, 2
+POINT = int(os.environ.get("R5_POINT", "1"))                         # weight seed of the operating point (r5_scheme.POINTS): 1 .. 4
 PT = S5.POINTS[POINT]
 WINDOWS = PT["windows"]                                              # (clip seed, window)
 CLIP_FRAMES = PT["clip_frames"]
@@ -104,7 +104,7 @@ def main():
 
     xt, gtt = window(TRAIN_CLIP, TRAIN_WINDOW)
     print("PSNR(LQ input, GT) on the fitted window = %.2f dB" % R3.psnr(xt, gtt))
-    sd = dict(sd1)
+    sd = dict(S5.predamp(sd1, POINT))                                 # (points with damped code-transformer branches: r5_scheme.POINTS)
     print(f"SFT gains re-calibrated for the seed-{POINT} draw (one oracle forward, each fusion measured then corrected):")
     gains, enc, dec = calibrate_and_capture(O, sd, cfg, xt)
     with torch.no_grad():
