@@ -489,6 +489,61 @@ def test_psnr_contract_at_a_fifth_operating_point_with_diverse_codes(cfg, manife
     _psnr_contract_at_point(_point_models(cfg, manifest, 4), gate_db=5e-4)
 
 
+def test_exact_weight_mode_end_to_end(cfg, manifest, tail_models_s1, monkeypatch):
+    """The opt-in precision mode (`PGT_EXACT_W` / `ops.EXACT_W_STAGES`: decoder weights on two half planes) through the
+    whole model, second operating point, every decoder stage exact, three windows of the reference fixtures: the marked layers really take
+    the two-plane launches (counted at `ops.conv2d` / `ops.linear`, which set `pgt_conv_desc::w2`), every code equals the reference's, the contract holds, and the frames
+    sit CLOSER to the reference's than the default mode's on every window (measured on 8 windows: 81.1 against 80.7 dB worst,
+    profiles/r6_b_all_exact_spread.jsonl)."""
+    from pgtformer_amd import PGTFormer, ops
+    from pgtformer_amd.synth import make_clip
+    from pgtformer_amd.weightgen import generate_state_dict
+    from tests.golden.r5_scheme import POINTS, point_state_dict
+
+    monkeypatch.setattr(ops, "EXACT_W_STAGES", ("512", "256", "128", "64", "32"))
+    m = PGTFormer(**cfg)
+    m.load_state_dict(point_state_dict(generate_state_dict(manifest, cfg, seed=1), 1), strict=True)
+    m.prepare(DEV, "x3f16")
+    marked = [mod for mod in m.modules() if getattr(mod, "pw2", None) is not None]
+    assert len(marked) >= 40, len(marked)
+    calls = {"w2": 0, "all": 0}
+
+    def counting(real):
+        def f(*a, **k):
+            calls["all"] += 1
+            calls["w2"] += int(bool(k.get("w2")))      # ops.conv2d / ops.linear put it into pgt_conv_desc::w2
+            return real(*a, **k)
+        return f
+
+    monkeypatch.setattr(ops, "conv2d", counting(ops.conv2d))
+    monkeypatch.setattr(ops, "linear", counting(ops.linear))
+    pt = POINTS[1]
+    g = np.load(os.path.join(GOLD, pt["golden"]))
+    tags = sorted({k.split(".")[0] for k in g.files})[:3]
+    default = tail_models_s1["x3f16"]
+    recs = []
+    for tag in tags:
+        seed, i = (int(v) for v in tag[1:].split("w"))
+        lq_u8, gt = make_clip(pt["clip_frames"][seed], 512, seed=seed)
+        frames = torch.from_numpy(lq_u8[i - 1:i + 2]).to(DEV)
+        ref = torch.from_numpy(g[f"{tag}.out_mid_rows"]).double()
+        gt_rows = torch.from_numpy(gt[i]).permute(2, 0, 1)[:, ::8, :].double()
+        rec = {"window": tag}
+        for name, mod in (("exact", m), ("default", default)):
+            out, _, _ = mod.forward_nhwc(frames, w=1.0, win=mod.window_index(1, 3, DEV), middle_only=True)
+            rows = out[0].float().cpu().permute(2, 0, 1)[:, ::8, :].double()
+            codes = mod.last_codes.cpu().numpy().astype(np.int64).reshape(-1)
+            rec[name] = {"dpsnr_db": psnr(rows, gt_rows) - psnr(ref, gt_rows), "psnr_build_vs_ref_db": psnr(rows, ref),
+                         "differing_tokens": int((codes != g[f"{tag}.codes"].astype(np.int64).reshape(-1)).sum())}
+        recs.append(rec)
+        assert rec["exact"]["differing_tokens"] == 0, rec
+        assert abs(rec["exact"]["dpsnr_db"]) <= 1e-3, rec
+        assert rec["exact"]["psnr_build_vs_ref_db"] > rec["default"]["psnr_build_vs_ref_db"], rec
+    _LOG["exact_weight_mode/second_point"] = {"windows": recs, "two_plane_launches": calls["w2"], "conv_launches": calls["all"],
+                                              "modules_with_two_planes": len(marked)}
+    assert calls["w2"] >= 3 * 40, calls
+
+
 def test_graph_replay_after_the_allocator_returned_memory_to_the_driver(models):
     """a graph replay right after torch.cuda.empty_cache() died ONCE inside the HIP runtime in a long test
     process (the driver then made that release opt-in).  What a captured graph of this build points at: its lane's static input /
