@@ -58,7 +58,19 @@ def binary_sha16(lib=None):
 
 
 def build(force=False, verbose=True):
+    """compile what changed and link; concurrent callers (the ranks of one node) take turns behind a file lock"""
+    import fcntl
+
     os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     hdr = hashlib.sha256()
