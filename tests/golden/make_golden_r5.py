@@ -4,7 +4,8 @@ operating point for north_star's "within 1e-3 PSNR" contract.
     R5_POINT=2 python tests/golden/make_golden_r5.py  ->  r5_tail_s2.npz, r5_golden_s2.npz: a THIRD point (weight seed 2, tail fitted on
     clip 10077 w2, 8 windows of clips 10077 / 11077 / 12077), generated after every constant of the build was fixed
     R5_POINT=3 / R5_POINT=4  ->  r6_tail_s3 / r6_golden_s3, r6_tail_s4 / r6_golden_s4 (round 6; about 8 min each): a FOURTH point (seed 3) and a
-    FIFTH one (seed 4) whose code transformer keeps the tokens apart (r5_scheme.predamp): ~100 distinct codes per window instead of 1 - 13
+    FIFTH one (seed 4) whose code transformer keeps the tokens apart (r5_scheme.predamp): ~100 distinct codes per window instead of 1 - 13;
+    R5_POINT=5 -> r6_tail_s5 / r6_golden_s5: the fifth point's scheme at weight seed 5
 
 Why: every PSNR-contract window of rounds 3 / 4 runs ONE weight set (seed-0 weights + one tail fitted on clip 1234 w1).  The
 half decoder's rounding errors, the defects D = W - half(W) behind the mean-field compensation and the
@@ -31,7 +32,7 @@ REF = "/root/reference"
 import make_golden_r3 as R3                                            # fit_tail, tail_forward, train_tail, psnr, rms  # noqa: E402
 from tests.golden import r5_scheme as S5                               # noqa: E402
 
-POINT = int(os.environ.get("R5_POINT", "1"))                         # weight seed of the operating point (r5_scheme.POINTS): 1 .. 4
+POINT = int(os.environ.get("R5_POINT", "1"))                         # weight seed of the operating point (r5_scheme.POINTS): 1 .. 5
 PT = S5.POINTS[POINT]
 WINDOWS = PT["windows"]                                              # (clip seed, window)
 CLIP_FRAMES = PT["clip_frames"]

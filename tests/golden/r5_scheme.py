@@ -40,6 +40,11 @@ POINTS = {
     4: dict(train=(16077, 2), fixture="r6_tail_s4.npz", golden="r6_golden_s4.npz", dither="r6s4:",
             windows=((16077, 1), (16077, 2), (16077, 3), (17077, 1), (17077, 2), (17077, 3), (18077, 2), (18077, 5)),
             clip_frames={16077: 5, 17077: 5, 18077: 7}, min_psnr_ref_gt_db=22.0, damp=0.1),
+    # round 6: a SIXTH draw, the fifth one's scheme repeated at another weight seed (5; tail fitted on clip 19077 w2) - is the diverse-code
+    # figure a property of the regime or of one draw?
+    5: dict(train=(19077, 2), fixture="r6_tail_s5.npz", golden="r6_golden_s5.npz", dither="r6s5:",
+            windows=((19077, 1), (19077, 2), (19077, 3), (20077, 1), (20077, 2), (20077, 3), (21077, 2), (21077, 5)),
+            clip_frames={19077: 5, 20077: 5, 21077: 7}, min_psnr_ref_gt_db=22.0, damp=0.1),
 }
 DAMPED = ("self_attn.out_proj.weight", "self_attn.out_proj.bias", "linear2.weight", "linear2.bias")
 
