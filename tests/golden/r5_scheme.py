@@ -32,7 +32,8 @@ POINTS = {
     # first run on them after the exact-weight layers and every constant of the compensation were fixed.
     3: dict(train=(13077, 2), fixture="r6_tail_s3.npz", golden="r6_golden_s3.npz", dither="r6s3:",
             windows=((13077, 1), (13077, 2), (13077, 3), (14077, 1), (14077, 2), (14077, 3), (15077, 2), (15077, 5)),
-            clip_frames={13077: 5, 14077: 5, 15077: 7}, min_psnr_ref_gt_db=22.0),
+            clip_frames={13077: 5, 14077: 5, 15077: 7}, min_psnr_ref_gt_db=22.0,
+            gen_threads=5),      # (torch threads of the generating process: CPU fp32 sums depend on it at the 4e-7 level; default 8)
     # round 6: a FIFTH draw in the regime of a trained checkpoint - DIVERSE codes.  The random-init code transformer of the other points
     # makes all tokens alike (1 - 13 distinct codes per window); here its residual branches (self_attn.out_proj, linear2 of the nine
     # ft_layers) are scaled by 0.1 before everything else, so that the tokens keep their identity: ~100 distinct codes per window, the

@@ -145,3 +145,39 @@ def test_oracle_on_a_window_of_another_clip(cfg, full_sd):
     out, logits, _ = O.pgtformer_forward(fitted_tail_state_dict(full_sd), cfg, x, w=1.0)
     assert np.array_equal(out[1, :, ::8, :].numpy(), g["c2077w1.out_mid_rows"])
     assert np.array_equal(logits.argmax(-1).numpy().astype(np.int16), g["c2077w1.codes"])
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_oracle_at_the_later_operating_points(cfg, manifest, seed):
+    """tests/golden/r5_golden_s1 / _s2, r6_golden_s3 / _s4 / _s5.npz (make_golden_r5.py: the imported reference at weight seeds 1 .. 5, each with
+    re-calibrated SFT gains and its own fitted tail; seeds 4 and 5 with the damped code transformer): on a HELD-OUT window of every point - the
+    first window of the point's second clip; the generator itself compares on the fitted one - the oracle reproduces the reference's codes
+    and its restored middle frame bit for bit (at the thread count the fixture was generated with) and its top-2 logit margins to 1e-5.  The GPU contract tests of these points compare against the same files."""
+    from oracle import pgt_oracle as O
+    from pgtformer_amd.synth import make_clip, window_from_clip
+    from pgtformer_amd.weightgen import generate_state_dict
+    from tests.golden.r5_scheme import POINTS, point_state_dict
+
+    pt = POINTS[seed]
+    g = np.load(os.path.join(GOLD, pt["golden"]))
+    clip, i = pt["windows"][3]
+    assert (clip, i) != pt["train"]
+    tag = f"c{clip}w{i}"
+    sd = point_state_dict(generate_state_dict(manifest, cfg, seed=seed), seed)
+    lq_u8, _ = make_clip(pt["clip_frames"][clip], 512, seed=clip)
+    x = torch.from_numpy(window_from_clip(lq_u8, i).astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    # CPU fp32 convolutions split their sums by the number of threads: reference and oracle agree bit for bit at the SAME count, and to
+    # ~4e-7 (two ulps at 0.5) across counts.  The fixtures of seed 3 were generated with 5 threads, the others with 8 (r5_scheme.POINTS).
+    nt = torch.get_num_threads()
+    torch.set_num_threads(pt.get("gen_threads", 8))
+    try:
+        out, logits, _ = O.pgtformer_forward(sd, cfg, x, w=1.0)
+    finally:
+        torch.set_num_threads(nt)
+    lg = logits.reshape(-1, logits.shape[-1])
+    assert np.array_equal(out[1, :, ::8, :].numpy(), g[f"{tag}.out_mid_rows"])
+    assert np.array_equal(lg.argmax(-1).numpy().astype(np.int16), g[f"{tag}.codes"].reshape(-1))
+    top2 = lg.topk(2, dim=-1).values
+    # (the oracle's token-major Linear sums in another order than the reference's permuted one: logits agree to ~3e-6, not bit for bit)
+    assert np.abs((top2[:, 0] - top2[:, 1]).numpy().astype(np.float32) - g[f"{tag}.top2_margin"].reshape(-1)).max() < 1e-5
