@@ -2,7 +2,6 @@
 reference's archs/codeformer_arch.py: `TransformerSALayer` :102-137, `adaptive_instance_normalization`
 :15-46). Token matrices are (B*L, E) row-major with rows in (b, t, y, x) order — the reference's
 seq-first (L, B, E) with B=1 is the same memory."""
-import torch
 import torch.nn as nn
 
 from .. import ops

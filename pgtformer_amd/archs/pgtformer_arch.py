@@ -15,7 +15,7 @@ import torch.nn as nn
 from .. import ops
 from ..modules.rstt_layers import (Conv2d, HipModule, LayerNorm, Linear, TDResnetBlock, _defect_t, _exact, _f32, _frame_bias, _is_x3,  # noqa: F401
                                     _pack_matrix, _wants_wcomp)
-from ..ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU
+from ..ops import ACT_LEAKY02, ACT_RELU, ACT_SIGMOID, ACT_SILU
 from ..registry import ARCH_REGISTRY
 from .codeformer_arch import TransformerSALayer, adaptive_instance_normalization
 from .tdcrqvae3_arch import TDCRQVAE3

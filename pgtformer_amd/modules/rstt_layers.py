@@ -12,12 +12,11 @@ forward() is never called.
 """
 import os
 
-import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import ACT_GELU, ACT_NONE, ACT_SILU, X3, X3F
+from ..ops import ACT_GELU, ACT_SILU, X3, X3F
 
 USE_X3_FOLD = os.environ.get("PGT_X3_FOLD", "1") != "0"   # A/B switch of the folded 64-channel split-half convs
 USE_X3_C64 = os.environ.get("PGT_X3_C64", "1") != "0"     # A/B switch of the register-weight split-half 3x3 kernel (igemm6x3.hip)

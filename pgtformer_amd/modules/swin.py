@@ -12,7 +12,6 @@ Precision: `prepare(device, torch.bfloat16)` runs everything in bf16 storage (fp
 `prepare(device, torch.float32)` keeps LayerNorm and the Linears in exact fp32 and rounds only the attention kernel's qkv
 input / output to `attn_dtype` (default torch.float16: BASELINE.json configs[4] quotes the fp16 kernel; the conv / linear
 family has bf16 and fp32 forms only).  Inference only (drop / attn_drop / drop_path must be 0)."""
-import numpy as np
 import torch
 import torch.nn as nn
 
