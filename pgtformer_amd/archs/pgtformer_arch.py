@@ -494,8 +494,17 @@ class PGTFormer(TDCRQVAE3):
             p = c.reshape(bt * c.shape[1] * c.shape[2], c.shape[3])          # rows (b,t,y,x) == (T*H*W, B) order
             return c, (ops.to_x3(p) if x3 else p)                           # fp32 BiSeNet map -> split-half operand
 
+        # NOT inside a stream capture: a captured fork gives the graph a second root, and ROCm 7.0's hipGraphLaunch
+        # (hip::Graph::UpdateStreams) then looks among the executable graph's internal streams for one that sits on another hardware
+        # queue than the launch stream WITHOUT bounding the search - when both internal streams share the launch stream's queue it
+        # reads past the end of the vector and dereferences what it finds (the segfault "inside the HIP runtime's graph launch" of
+        # rounds 5 / 6: DESIGN.md section 3.4; which queue a stream gets depends on every stream the process created before).  A
+        # graph without forks has one root and never enters that loop; with two forwards in flight the fork is worth nothing
+        # (172.9 against 172.9 frames/s), with one +1.4 %.
         side = None
-        if SIDE_STREAM and raw.is_cuda:
+        self.last_forked = False
+        if SIDE_STREAM and raw.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self.last_forked = True
             main = torch.cuda.current_stream(raw.device)
             side = self.__dict__.setdefault("_side_stream", None) or torch.cuda.Stream(device=raw.device)
             self.__dict__["_side_stream"] = side

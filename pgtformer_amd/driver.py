@@ -122,8 +122,8 @@ class WindowRunner:
             bad = self.model.check_range(self.static_ins[lane], w=self.w, full_tail=self.full_tail, **kw)
             # the eager pass's activations (one more set on top of the graph pools) are free for re-use by the allocator
             torch.cuda.synchronize(self.dev)
-            # (returning the eager pass's blocks to the driver here is opt-in: in one long test process a graph replay right
-            #  after torch.cuda.empty_cache() died inside the HIP runtime's graph launch - not reproduced in isolation)
+            # (returning the eager pass's blocks to the driver here is opt-in.  The graph replay that once died right after such a
+            #  release had another cause - ROCm's hipGraphLaunch on multi-root graphs, archs/pgtformer_arch.py: no fork under capture)
             if os.environ.get("PGT_EMPTY_CACHE_AFTER_CHECK", "0") == "1":
                 torch.cuda.empty_cache()
             if bad:

@@ -588,6 +588,27 @@ def test_graph_replay_after_the_allocator_returned_memory_to_the_driver(models):
     _LOG["graph_replay_after_empty_cache"] = {"replays": 10, "bit_equal": True}
 
 
+def test_captured_forward_has_no_fork(models):
+    """The root cause of the segfault inside hipGraphLaunch (DESIGN.md section 3.4): ROCm 7.0's hip::Graph::UpdateStreams searches, for every
+    root of a graph beyond the first, the executable graph's internal streams for one on another hardware queue than the launch stream - without
+    bounding the search (rocgdb: both internal streams on the launch stream's queue, index past the end, null dereference).  A graph with one root
+    never enters the loop, so a forward that is being captured must not fork its condition branch onto the side stream; eager forwards keep the
+    fork; frames are bit-identical either way."""
+    from pgtformer_amd.driver import WindowRunner
+    from pgtformer_amd.synth import make_clip
+
+    m = models["x3f16"]
+    lq, _ = make_clip(4, 512, seed=78)
+    frames = torch.from_numpy(lq).to(DEV)
+    eager = m.restore_middle_u8(frames, w=1.0, win=m.window_index(2, 3, DEV)).clone()
+    assert m.last_forked is True
+    r = WindowRunner(m, 1.0, True, 512, 512, batch=2, lanes=1, check_range=False)
+    assert m.last_forked is False          # (the runner's last forward was the captured one)
+    got = r.run(frames)
+    torch.cuda.synchronize()
+    assert torch.equal(got, eager.reshape(got.shape))
+
+
 def test_whole_model_pure_bf16_report(models, golden_window):
     """Pure bf16 (opt-in speed mode) is reported, not a parity mode: with random-init weights ~2 % of the codes flip."""
     g = np.load(os.path.join(GOLD, "full_golden.npz"))
