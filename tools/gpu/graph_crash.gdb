@@ -18,3 +18,7 @@ x/gx *(long*)(*(long*)$r12+8)+0x1a8
 x/16gx *(long*)(*(long*)(*(long*)$r12+8)+0x1a8)
 echo ---- disassemble head\n
 x/40i $rip-177
+echo ---- class of the object at stream+0x1a8 (vtable symbol) and the compared virtual function\n
+info symbol *(long*)(*(long*)($r15+0x1a8))
+info symbol *(long*)(*(long*)(*(long*)($r15+0x1a8))+0x10)
+x/16i *(long*)(*(long*)(*(long*)($r15+0x1a8))+0x10)
