@@ -562,7 +562,9 @@ def test_graph_replay_after_the_allocator_returned_memory_to_the_driver(models):
     of a live graph) and a few tensors created in the eager warm-up that the modules / ops keep for good (ops._FB_COUNTERS, the
     frame-index tables of the fusion blocks, the grouped sub-pixel defects).  This test drives exactly the incident's sequence - capture
     two lanes, eager range-check pass, empty_cache(), replay - 10 times, with a second runner created and destroyed in between (its
-    pools become releasable), and checks the replayed frames bit for bit."""
+    pools become releasable), and checks the replayed frames bit for bit.
+    (Later in round 6 the crash became reproducible and was traced to something else - hipGraphLaunch on a graph with a captured fork,
+    test_captured_forward_has_no_fork; the empty_cache() call was a bystander.  The sequence stays tested.)"""
     import gc
 
     from pgtformer_amd.driver import WindowRunner
