@@ -603,7 +603,8 @@ def test_captured_forward_has_no_fork(models):
     lq, _ = make_clip(4, 512, seed=78)
     frames = torch.from_numpy(lq).to(DEV)
     eager = m.restore_middle_u8(frames, w=1.0, win=m.window_index(2, 3, DEV)).clone()
-    assert m.last_forked is True
+    from pgtformer_amd.archs import pgtformer_arch
+    assert m.last_forked is pgtformer_arch.SIDE_STREAM      # (PGT_SIDE_STREAM=0 switches the eager fork off as well)
     r = WindowRunner(m, 1.0, True, 512, 512, batch=2, lanes=1, check_range=False)
     assert m.last_forked is False          # (the runner's last forward was the captured one)
     got = r.run(frames)
